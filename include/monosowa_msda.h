@@ -1,0 +1,82 @@
+/*
+ * monosowa_msda.h -- C-ABI of the MI355X-native MultiScaleDeformableAttention (MSDA) library.
+ *
+ * Drop-in boundary for the reference's compiled extension module
+ * `MultiScaleDeformableAttention` (MonoDETR/lib/models/monodetr/ops/src/vision.cpp:13-16):
+ *
+ *   msda_forward_*   replaces ms_deform_attn_forward   (ops/src/ms_deform_attn.h:20-39
+ *                    -> ops/src/cuda/ms_deform_attn_cuda.cu:20-80 -> ms_deform_im2col_cuda.cuh:923-954)
+ *   msda_backward_*  replaces ms_deform_attn_backward  (ops/src/ms_deform_attn.h:41-61
+ *                    -> ops/src/cuda/ms_deform_attn_cuda.cu:83-153 -> ms_deform_im2col_cuda.cuh:956-1326)
+ *
+ * Plain pointers and sizes only (no torch / ATen types).  All pointers are DEVICE pointers on
+ * the current HIP device; tensors are dense row-major:
+ *
+ *   value        [B, S, M, D]        S = sum_l H_l*W_l   (head-interleaved: one token = M*D scalars)
+ *   shapes       [L, 2]  int64       (H_l, W_l)                       (cu:67)
+ *   level_start  [L]     int64       first token of level l           (cu:68)
+ *   loc          [B, Lq, M, L, P, 2] (x, y) normalised to [0,1] over the level, may lie outside
+ *   attn_w       [B, Lq, M, L, P]
+ *   out / grad_out               [B, Lq, M, D]
+ *   grad_value / grad_loc / grad_attn_w   shaped like value / loc / attn_w
+ *
+ * Semantics: out[b,q,m,:] = sum_{l,p} attn_w * bilinear(value_l[b,:,m,:]; loc*(W_l,H_l) - 0.5),
+ * zero outside the level, a point contributing iff -1 < h < H_l and -1 < w < W_l (cuh:274).
+ *
+ * Ownership: the caller owns every buffer.  Inputs are never written.  Output buffers may be
+ * uninitialised: the library zero-fills what its algorithm needs on `stream` (the reference host
+ * code allocates zeroed outputs, cu:54,121-123).  Everything is enqueued on `stream`
+ * (a hipStream_t; NULL = the null stream), asynchronously, with no host synchronisation and no
+ * allocation (`workspace` entry points below), so calls may be captured into a hipGraph.
+ *
+ * Errors: 0 on success; a positive value is a hipError_t from the launch (the reference only
+ * printf's launch errors, cuh:948-952 -- this library returns them); negative values are
+ * MSDA_E_* argument errors.  msda_strerror() names either kind.  Re-entrant, no global state.
+ */
+#ifndef MONOSOWA_MSDA_H_
+#define MONOSOWA_MSDA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSDA_ABI_VERSION 1
+
+#define MSDA_E_NULLPTR (-1)   /* a required pointer is NULL                        */
+#define MSDA_E_SHAPE (-2)     /* a dimension is <= 0 or exceeds the indexing range */
+#define MSDA_E_UNSUPPORTED (-3)
+
+int msda_abi_version(void);
+const char *msda_strerror(int code);
+
+/* Bytes of scratch the backward needs for this geometry (0 if none); the caller allocates it
+ * once and passes it to msda_backward_*; it may be NULL when the answer is 0. */
+size_t msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int Lq, int P, int elem_bytes);
+
+int msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                     const float *loc, const float *attn_w, float *out,
+                     int B, int S, int M, int D, int L, int Lq, int P, void *stream);
+
+int msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,
+                     const double *loc, const double *attn_w, double *out,
+                     int B, int S, int M, int D, int L, int Lq, int P, void *stream);
+
+int msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                      const float *loc, const float *attn_w, const float *grad_out,
+                      float *grad_value, float *grad_loc, float *grad_attn_w,
+                      int B, int S, int M, int D, int L, int Lq, int P,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+int msda_backward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,
+                      const double *loc, const double *attn_w, const double *grad_out,
+                      double *grad_value, double *grad_loc, double *grad_attn_w,
+                      int B, int S, int M, int D, int L, int Lq, int P,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONOSOWA_MSDA_H_ */

@@ -1,0 +1,102 @@
+"""Mirror of the reference's compiled extension module ``MultiScaleDeformableAttention``
+(ops/src/vision.cpp:13-16) on top of the C-ABI HIP library.
+
+Same two functions, same argument order and the same preconditions as the reference host code
+(ops/src/cuda/ms_deform_attn_cuda.cu:28-52,93-119; ops/src/ms_deform_attn.h:38,60):
+
+* every tensor contiguous and on the GPU, else ``RuntimeError``;
+* CPU tensors -> ``RuntimeError("Not implemented on the CPU")``;
+* ``batch % min(batch, im2col_step) == 0``;
+* float32 / float64 values, int64 ``spatial_shapes`` / ``level_start_index``.
+
+Differences: kernel launch errors raise (the reference printf's them, cuh:948-952), and the
+whole batch goes out in one launch on ``torch.cuda.current_stream()`` (64-bit indexing makes the
+reference's im2col_step slicing unnecessary; results are identical for every step).
+
+To make reference code that does ``import MultiScaleDeformableAttention as MSDA``
+(ops/functions/ms_deform_attn_func.py:18) pick this up, call :func:`install`.
+"""
+import sys
+
+import torch
+
+from . import _lib
+
+__all__ = ["ms_deform_attn_forward", "ms_deform_attn_backward", "install"]
+
+
+def _assert(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _check_common(named, im2col_step):
+    value = named[0][1]
+    if not value.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")   # ms_deform_attn.h:38,60
+    for name, t in named:
+        _assert(t.is_contiguous(), "%s tensor has to be contiguous" % name)
+        _assert(t.is_cuda, "%s must be a CUDA tensor" % name)
+        _assert(t.device == value.device, "%s must be on %s" % (name, value.device))
+    _assert(value.dtype in (torch.float32, torch.float64), "value must be float32 or float64")
+    batch = value.size(0)
+    step = min(batch, int(im2col_step))
+    _assert(step > 0 and batch % step == 0, "batch(%d) must divide im2col_step(%d)" % (batch, step))
+
+
+def _dims(value, spatial_shapes, sampling_loc, attn_weight):
+    _assert(value.dim() == 4 and sampling_loc.dim() == 6 and attn_weight.dim() == 5, "bad tensor ranks")
+    B, S, M, D = value.shape
+    L = spatial_shapes.size(0)
+    Lq, P = sampling_loc.size(1), sampling_loc.size(4)
+    _assert(tuple(sampling_loc.shape) == (B, Lq, M, L, P, 2), "sampling_loc shape mismatch")
+    _assert(tuple(attn_weight.shape) == (B, Lq, M, L, P), "attn_weight shape mismatch")
+    _assert(spatial_shapes.dtype == torch.int64 and tuple(spatial_shapes.shape) == (L, 2), "spatial_shapes must be int64 [L,2]")
+    return B, S, M, D, L, Lq, P
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    """-> Tensor [B, Lq, M*D]   (reference: ms_deform_attn_cuda_forward, cu:20-80)"""
+    _check_common([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                   ("sampling_loc", sampling_loc), ("attn_weight", attn_weight)], im2col_step)
+    B, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, attn_weight)
+    _assert(level_start_index.dtype == torch.int64 and level_start_index.numel() == L, "level_start_index must be int64 [L]")
+    _assert(sampling_loc.dtype == value.dtype and attn_weight.dtype == value.dtype, "dtype mismatch")
+    lib = _lib.load()
+    out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    fn = lib.msda_forward_f32 if value.dtype == torch.float32 else lib.msda_forward_f64
+    with torch.cuda.device(value.device):
+        code = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                  sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
+                  B, S, M, D, L, Lq, P, torch.cuda.current_stream().cuda_stream)
+    _lib.check(code, "ms_deform_attn_forward")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight]   (reference: cu:83-153)"""
+    _check_common([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                   ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)], im2col_step)
+    B, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, attn_weight)
+    _assert(grad_output.numel() == B * Lq * M * D and grad_output.dtype == value.dtype, "grad_output shape/dtype mismatch")
+    lib = _lib.load()
+    grad_value = torch.empty_like(value)
+    grad_loc = torch.empty_like(sampling_loc)
+    grad_w = torch.empty_like(attn_weight)
+    ws_bytes = lib.msda_backward_workspace_bytes(B, S, M, D, L, Lq, P, value.element_size())
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device) if ws_bytes else None
+    fn = lib.msda_backward_f32 if value.dtype == torch.float32 else lib.msda_backward_f64
+    with torch.cuda.device(value.device):
+        code = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                  sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+                  grad_value.data_ptr(), grad_loc.data_ptr(), grad_w.data_ptr(),
+                  B, S, M, D, L, Lq, P, ws.data_ptr() if ws is not None else None, ws_bytes,
+                  torch.cuda.current_stream().cuda_stream)
+    _lib.check(code, "ms_deform_attn_backward")
+    return [grad_value, grad_loc, grad_w]
+
+
+def install():
+    """Register this module under the reference's import name."""
+    sys.modules["MultiScaleDeformableAttention"] = sys.modules[__name__]
+    return sys.modules[__name__]

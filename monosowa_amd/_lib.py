@@ -1,0 +1,50 @@
+"""ctypes loader for the C-ABI library (include/monosowa_msda.h).  No fallback: a missing
+library is an error, never a silent CPU path."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmonosowa_msda.so")
+
+# every symbol include/monosowa_msda.h declares
+SYMBOLS = ("msda_abi_version", "msda_strerror", "msda_backward_workspace_bytes",
+           "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64")
+
+_lib = None
+
+
+class MSDALibraryError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MSDALibraryError(
+            "HIP extension %s is missing: build it with `python -m monosowa_amd.build` "
+            "(needs hipcc; there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    P, I, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    lib.msda_abi_version.restype = I
+    lib.msda_strerror.restype = ctypes.c_char_p
+    lib.msda_strerror.argtypes = [I]
+    lib.msda_backward_workspace_bytes.restype = Z
+    lib.msda_backward_workspace_bytes.argtypes = [I] * 8
+    for suf in ("f32", "f64"):
+        f = getattr(lib, "msda_forward_" + suf)
+        f.restype = I
+        f.argtypes = [P] * 6 + [I] * 7 + [P]
+        b = getattr(lib, "msda_backward_" + suf)
+        b.restype = I
+        b.argtypes = [P] * 9 + [I] * 7 + [P, Z, P]
+    if lib.msda_abi_version() != 1:
+        raise MSDALibraryError("ABI version mismatch in %s" % LIB_PATH)
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError("%s failed: %s (code %d)" % (what, load().msda_strerror(code).decode(), code))

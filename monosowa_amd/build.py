@@ -1,0 +1,59 @@
+"""Builds the in-tree HIP shared libraries for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m monosowa_amd.build [--force]
+
+Outputs go to ``monosowa_amd/lib/*.so`` (git-ignored, shipped to the GPU box by gpurun).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+ARCH = "gfx950"
+
+# library name -> (translation unit, extra dependencies that trigger a rebuild)
+LIBS = {
+    "libmonosowa_msda.so": ("msda_capi.hip", ["msda_kernels.hip", "msda_common.h",
+                                               os.path.join("..", "..", "include", "monosowa_msda.h")]),
+}
+
+FLAGS = ["-O3", "--offload-arch=" + ARCH, "-munsafe-fp-atomics", "-fPIC", "-shared", "-std=c++17",
+         "-fno-gpu-rdc", "-Wall"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the MI355X-native kernels cannot be built")
+    return exe
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_all(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    built = []
+    for name, (tu, deps) in LIBS.items():
+        out = os.path.join(LIBDIR, name)
+        src = os.path.join(CSRC, tu)
+        alldeps = [src] + [os.path.normpath(os.path.join(CSRC, d)) for d in deps]
+        if force or _stale(out, alldeps):
+            cmd = [hipcc()] + FLAGS + ["-o", out, src]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        built.append(out)
+    return built
+
+
+if __name__ == "__main__":
+    for p in build_all(force="--force" in sys.argv, verbose=True):
+        print("built", p)

@@ -1,0 +1,68 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol the
+header declares, and the Python mirror keeps the reference's preconditions
+(ops/src/ms_deform_attn.h:38,60; ops/src/cuda/ms_deform_attn_cuda.cu:28-52)."""
+import ctypes
+import os
+import re
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "monosowa_msda.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(msda_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from monosowa_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m monosowa_amd.build` first"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _header_functions()
+    assert len(names) >= 7
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.SYMBOLS) == names
+    assert _lib.load().msda_abi_version() == 1
+    assert b"NULL" in _lib.load().msda_strerror(-1)
+
+
+def test_cpu_tensors_are_rejected_like_the_reference():
+    from monosowa_amd import MultiScaleDeformableAttention as MSDA
+    shapes = torch.tensor([[2, 2]], dtype=torch.long)
+    lsi = torch.zeros(1, dtype=torch.long)
+    v = torch.zeros(1, 4, 1, 4)
+    loc = torch.zeros(1, 1, 1, 1, 1, 2)
+    w = torch.zeros(1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, w, 64)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, w, torch.zeros(1, 1, 4), 64)
+
+
+def test_install_registers_reference_module_name():
+    from monosowa_amd import MultiScaleDeformableAttention as MSDA
+    saved = sys.modules.pop("MultiScaleDeformableAttention", None)
+    try:
+        MSDA.install()
+        import MultiScaleDeformableAttention as again
+        assert again.ms_deform_attn_forward is MSDA.ms_deform_attn_forward
+        assert again.ms_deform_attn_backward is MSDA.ms_deform_attn_backward
+    finally:
+        sys.modules.pop("MultiScaleDeformableAttention", None)
+        if saved is not None:
+            sys.modules["MultiScaleDeformableAttention"] = saved
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "monosowa_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
+                assert "libmsda_oracle" not in src
