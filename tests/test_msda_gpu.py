@@ -38,7 +38,20 @@ def _close(got, want, rel, what):
     assert err <= rel, "%s: max err / max|ref| = %.3e > %.1e" % (what, err, rel)
 
 
-def _run_case(value, shapes, lsi, loc, attw, grad_out, want, rel):
+def _oracle_want(value, shapes, lsi, loc, w, go):
+    """Expected results.  f64 inputs: the f64 oracle.  f32 inputs: the f32 oracle (same arithmetic,
+    hence the same floor()/in-bounds decisions as the kernel -- grad_loc jumps across pixel borders, so
+    it cannot be judged against f64 arithmetic) plus, for the continuous outputs (out, grad_value,
+    grad_attw), the f64 oracle on the same f32-rounded inputs."""
+    want = (O.forward(value, shapes, lsi, loc, w),) + O.backward(value, shapes, lsi, loc, w, go)
+    if value.dtype == np.float64:
+        return want, None
+    d = lambda a: a.astype(np.float64)
+    w64 = (O.forward(d(value), shapes, lsi, d(loc), d(w)),) + O.backward(d(value), shapes, lsi, d(loc), d(w), d(go))
+    return want, w64
+
+
+def _run_case(value, shapes, lsi, loc, attw, grad_out, want, rel, want64=None):
     MSDA = _msda()
     v, s, i, lc, w, go = map(_dev, (value, shapes, lsi, loc, attw, grad_out))
     out = MSDA.ms_deform_attn_forward(v, s, i, lc, w, 64)
@@ -49,6 +62,10 @@ def _run_case(value, shapes, lsi, loc, attw, grad_out, want, rel):
     _close(gv, want[1], rel, "grad_value")
     _close(gl, want[2], rel, "grad_loc")
     _close(gw, want[3], rel, "grad_attw")
+    if want64 is not None:
+        _close(out, want64[0], rel, "out vs f64")
+        _close(gv, want64[1], rel, "grad_value vs f64")
+        _close(gw, want64[3], rel, "grad_attw vs f64")
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -88,12 +105,8 @@ def _random_case(seed, B, M, D, Lq, levels, P, dtype, loc_lo=-0.3, loc_hi=1.3):
 ])
 def test_random_vs_c_oracle(B, M, D, Lq, levels, P, dtype):
     value, shapes, lsi, loc, w, go = _random_case(B * 131 + D, B, M, D, Lq, levels, P, dtype)
-    want = (O.forward(value, shapes, lsi, loc, w),) + O.backward(value, shapes, lsi, loc, w, go)
-    if dtype == np.float32:
-        # judge f32 against the f64 oracle on the same (f32-rounded) inputs
-        d = lambda a: a.astype(np.float64)
-        want = (O.forward(d(value), shapes, lsi, d(loc), d(w)),) + O.backward(d(value), shapes, lsi, d(loc), d(w), d(go))
-    _run_case(value, shapes, lsi, loc, w, go, want, 1e-9 if dtype == np.float64 else 1e-4)
+    want, want64 = _oracle_want(value, shapes, lsi, loc, w, go)
+    _run_case(value, shapes, lsi, loc, w, go, want, 1e-9 if dtype == np.float64 else 1e-4, want64)
 
 
 def test_kitti_geometry_encoder_one_sample_vs_c_oracle():
@@ -114,9 +127,8 @@ def test_kitti_geometry_encoder_one_sample_vs_c_oracle():
     w = np.exp(w) / np.exp(w).sum(-1, keepdims=True)
     w = w.reshape(B, S, M, L, P).astype(np.float32)
     go = rng.standard_normal((B, S, M * D)).astype(np.float32)
-    d = lambda a: a.astype(np.float64)
-    want = (O.forward(d(value), shapes, lsi, d(loc), d(w)),) + O.backward(d(value), shapes, lsi, d(loc), d(w), d(go))
-    _run_case(value, shapes, lsi, loc, w, go, want, 1e-4)
+    want, want64 = _oracle_want(value, shapes, lsi, loc, w, go)
+    _run_case(value, shapes, lsi, loc, w, go, want, 1e-4, want64)
 
 
 def test_full_batch_properties_b16():
@@ -147,8 +159,11 @@ def test_full_batch_properties_b16():
     go = torch.randn(B, S, M * D, device=dev)
     gv, gl, gw = MSDA.ms_deform_attn_backward(v1, shapes, lsi, loc, w, go, 64)
     gv64, gl64, gw64 = MSDA.ms_deform_attn_backward(v1[:2].double(), shapes, lsi, loc[:2].double(), w[:2].double(), go[:2].double(), 64)
-    for a, b, n in ((gv[:2], gv64, "grad_value"), (gl[:2], gl64, "grad_loc"), (gw[:2], gw64, "grad_attw")):
+    for a, b, n in ((gv[:2], gv64, "grad_value"), (gw[:2], gw64, "grad_attw")):
         assert (a.double() - b).abs().max() <= 1e-4 * b.abs().max(), n
+    # grad_loc jumps across pixel borders, where f32 and f64 floor() may differ: allow a handful of points
+    bad = ((gl[:2].double() - gl64).abs() > 1e-4 * gl64.abs().max()).sum().item()
+    assert bad <= 1e-5 * gl64.numel(), bad
     # <grad_out, J v> == <J^T grad_out, v>  (adjoint identity of the value path)
     lhs = (go.double() * o1.double()).sum()
     rhs = (gv.double() * v1.double()).sum()
