@@ -1,0 +1,175 @@
+"""ResNet-50/101 body with frozen batch-norm -> C3/C4/C5 feature maps + sine position encodings.
+
+Reference: lib/models/monodetr/backbone.py (FrozenBatchNorm2d :28-65, BackboneBase :68-91,
+Backbone :94-115, Joiner :118-135, build_backbone :138-144).  The reference takes the network
+from ``torchvision.models`` (pinned 0.14.1, not vendored, not installed here), so the ResNet-v1.5
+bottleneck network is restated locally with torchvision's parameter names: a reference checkpoint
+key such as ``backbone.0.body.layer3.5.conv2.weight`` loads unchanged.  Backbone parity against
+torchvision is UNPINNED in this container.
+
+MI355X notes: frozen BN is a per-channel affine, so each conv is run with the affine folded into
+its weights/bias (one pass over the activation instead of two; exact in real arithmetic, ~1e-7 in
+fp32) and the fold is differentiated through for the trainable stages.  The dense convolutions go
+to MIOpen (MFMA); nothing here is hand-written.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .misc import NestedTensor
+from .position_encoding import build_position_encoding
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """BatchNorm2d with fixed statistics and affine parameters (buffers, as in the reference)."""
+
+    def __init__(self, n, eps=1e-5):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+        self.eps = eps
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys,
+                              unexpected_keys, error_msgs):
+        state_dict.pop(prefix + "num_batches_tracked", None)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys,
+                                      unexpected_keys, error_msgs)
+
+    def scale_shift(self):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        return scale, self.bias - self.running_mean * scale
+
+    def forward(self, x):
+        scale, shift = self.scale_shift()
+        return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+
+
+def conv_bn(x, conv, bn):
+    """conv followed by a frozen BN, evaluated as one convolution with folded weights."""
+    if isinstance(bn, FrozenBatchNorm2d):
+        scale, shift = bn.scale_shift()
+        return F.conv2d(x, conv.weight * scale.view(-1, 1, 1, 1), shift, conv.stride, conv.padding,
+                        conv.dilation, conv.groups)
+    return bn(conv(x))
+
+
+class Bottleneck(nn.Module):
+    """ResNet v1.5 bottleneck: 1x1 -> 3x3 (carries the stride) -> 1x1 (x4), residual add, ReLU."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1, norm_layer=FrozenBatchNorm2d):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = norm_layer(planes)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.bn3 = norm_layer(planes * self.expansion)
+        self.downsample = downsample
+
+    def forward(self, x):
+        out = F.relu(conv_bn(x, self.conv1, self.bn1), inplace=True)
+        out = F.relu(conv_bn(out, self.conv2, self.bn2), inplace=True)
+        out = conv_bn(out, self.conv3, self.bn3)
+        identity = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1])
+        return F.relu(out + identity, inplace=True)
+
+
+_DEPTHS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}
+
+
+class ResNetBody(nn.Module):
+    """conv1 .. layer4 with torchvision's child names; returns the outputs of layer2/3/4."""
+
+    def __init__(self, name, dilation=False, norm_layer=FrozenBatchNorm2d, return_interm_layers=True):
+        super().__init__()
+        if name not in _DEPTHS:
+            raise ValueError("backbone %r is not supported (resnet50 / resnet101)" % name)
+        self.inplanes, self._dil = 64, 1
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = norm_layer(64)
+        self.layer1 = self._make_layer(64, _DEPTHS[name][0], 1, False, norm_layer)
+        self.layer2 = self._make_layer(128, _DEPTHS[name][1], 2, False, norm_layer)
+        self.layer3 = self._make_layer(256, _DEPTHS[name][2], 2, False, norm_layer)
+        self.layer4 = self._make_layer(512, _DEPTHS[name][3], 2, dilation, norm_layer)
+        self.return_interm_layers = return_interm_layers
+        for m in self.modules():   # torchvision's default init (pretrained weights are a download)
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _make_layer(self, planes, blocks, stride, dilate, norm_layer):
+        prev_dil = self._dil
+        if dilate:
+            self._dil *= stride
+            stride = 1
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
+                                       norm_layer(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample, prev_dil, norm_layer)]
+        self.inplanes = planes * 4
+        layers += [Bottleneck(self.inplanes, planes, dilation=self._dil, norm_layer=norm_layer) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = F.relu(conv_bn(x, self.conv1, self.bn1), inplace=True)
+        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        x = self.layer1(x)
+        c3 = self.layer2(x)
+        c4 = self.layer3(c3)
+        c5 = self.layer4(c4)
+        return {"0": c3, "1": c4, "2": c5} if self.return_interm_layers else {"0": c5}
+
+
+class Backbone(nn.Module):
+    """ResNet body with frozen BN; conv1 + layer1 frozen, layer2-4 trainable when ``train_backbone``
+    (backbone.py:72-74)."""
+
+    def __init__(self, name, train_backbone, return_interm_layers, dilation, depth=False, pretrained=False):
+        super().__init__()
+        if depth:
+            raise NotImplementedError("4-channel (RGB-D) input is off in every shipped config (model.depth: False)")
+        if pretrained:
+            raise RuntimeError("model.pretrained: True needs torchvision's ImageNet download, which is not "
+                               "available offline; load a state dict instead and set pretrained: False")
+        assert name not in ("resnet18", "resnet34"), "number of channels are hard coded"
+        self.body = ResNetBody(name, dilation, FrozenBatchNorm2d, return_interm_layers)
+        for pname, p in self.body.named_parameters():
+            if not train_backbone or ("layer2" not in pname and "layer3" not in pname and "layer4" not in pname):
+                p.requires_grad_(False)
+        if return_interm_layers:
+            self.strides, self.num_channels = [8, 16, 32], [512, 1024, 2048]
+        else:
+            self.strides, self.num_channels = [32], [2048]
+        if dilation:
+            self.strides[-1] = self.strides[-1] // 2
+
+    def forward(self, images):
+        out = {}
+        for name, x in self.body(images).items():
+            mask = torch.zeros(x.shape[0], x.shape[2], x.shape[3], dtype=torch.bool, device=x.device)
+            out[name] = NestedTensor(x, mask)
+        return out
+
+
+class Joiner(nn.Sequential):
+    def __init__(self, backbone, position_embedding):
+        super().__init__(backbone, position_embedding)
+        self.strides = backbone.strides
+        self.num_channels = backbone.num_channels
+
+    def forward(self, images):
+        xs = self[0](images)
+        out = [x for _, x in sorted(xs.items())]
+        pos = [self[1](x).to(x.tensors.dtype) for x in out]
+        return out, pos
+
+
+def build_backbone(cfg):
+    position_embedding = build_position_encoding(cfg)
+    return_interm_layers = cfg["masks"] or cfg["num_feature_levels"] > 1
+    backbone = Backbone(cfg["backbone"], cfg["train_backbone"], return_interm_layers, cfg["dilation"],
+                        cfg["depth"], cfg["pretrained"])
+    return Joiner(backbone, position_embedding)

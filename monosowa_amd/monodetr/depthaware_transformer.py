@@ -1,0 +1,303 @@
+"""Depth-aware transformer: 3 visual encoder layers (MSDA self-attention + FFN) and 3 depth-aware
+decoder layers (depth cross-attention -> group-wise self-attention -> MSDA cross-attention -> FFN)
+with iterative box refinement.
+
+Reference: lib/models/monodetr/depthaware_transformer.py (DepthAwareTransformer :68-312,
+VisualEncoderLayer :315-354, VisualEncoder :357-384, DepthAwareDecoderLayer :387-515,
+DepthAwareDecoder :518-626, build :644-660).  Only the branch the shipped configs run is restated
+(two_stage / use_dab / two_stage_dino are all False in configs/monodetr.yaml:69-74 and in the
+released checkpoint's yaml); parameter names -- including the reference's unused ``query_scale``,
+``ref_point_head`` and ``sa_v_proj`` -- are kept so that reference state dicts load unchanged.
+"""
+import copy
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import constant_, normal_, xavier_uniform_
+
+from .misc import inverse_sigmoid
+from ..ms_deform_attn import MSDeformAttn
+
+
+class MLP(nn.Module):
+    """Linear-ReLU stack, ReLU on all but the last layer."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i < self.num_layers - 1:
+                x = F.relu(x)
+        return x
+
+
+def _clones(module, n):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+def _add_pos(x, pos):
+    return x if pos is None else x + pos
+
+
+# ----------------------------------------------------------------------------------------------
+# encoder
+# ----------------------------------------------------------------------------------------------
+class VisualEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        assert activation == "relu"
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+        attn = self.self_attn(_add_pos(src, pos), reference_points, src, spatial_shapes, level_start_index, padding_mask)
+        src = self.norm1(src + self.dropout1(attn))
+        ff = self.linear2(self.dropout2(F.relu(self.linear1(src))))
+        return self.norm2(src + self.dropout3(ff))
+
+
+class VisualEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers):
+        super().__init__()
+        self.layers = _clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        """Pixel-centre grid of every level, normalised by the valid extent, replicated for every
+        target level: [B, S, L, 2] (depthaware_transformer.py:363-376)."""
+        refs = []
+        for lvl, (H_, W_) in enumerate(spatial_shapes.tolist() if torch.is_tensor(spatial_shapes) else spatial_shapes):
+            ys = torch.linspace(0.5, H_ - 0.5, H_, dtype=torch.float32, device=device)
+            xs = torch.linspace(0.5, W_ - 0.5, W_, dtype=torch.float32, device=device)
+            ref_y, ref_x = torch.meshgrid(ys, xs, indexing="ij")
+            ref_y = ref_y.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * H_)
+            ref_x = ref_x.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * W_)
+            refs.append(torch.stack((ref_x, ref_y), -1))
+        reference_points = torch.cat(refs, 1)
+        return reference_points[:, :, None] * valid_ratios[:, None]
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None,
+                spatial_shapes_list=None):
+        shapes_for_ref = spatial_shapes_list if spatial_shapes_list is not None else spatial_shapes
+        reference_points = self.get_reference_points(shapes_for_ref, valid_ratios, device=src.device)
+        out = src
+        for layer in self.layers:
+            out = layer(out, pos, reference_points, spatial_shapes, level_start_index, padding_mask)
+        return out
+
+
+# ----------------------------------------------------------------------------------------------
+# decoder
+# ----------------------------------------------------------------------------------------------
+class DepthAwareDecoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8,
+                 n_points=4, group_num=1, group_size=50):
+        super().__init__()
+        assert activation == "relu"
+        # visual cross attention
+        self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        # depth cross attention
+        self.cross_attn_depth = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout_depth = nn.Dropout(dropout)
+        self.norm_depth = nn.LayerNorm(d_model)
+        # inter-query self attention
+        self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        # ffn
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+
+        self.group_num = group_num
+        self.group_size = group_size       # the reference hard-codes 50 (depthaware_transformer.py:481-482)
+        self.sa_qcontent_proj = nn.Linear(d_model, d_model)
+        self.sa_qpos_proj = nn.Linear(d_model, d_model)
+        self.sa_kcontent_proj = nn.Linear(d_model, d_model)
+        self.sa_kpos_proj = nn.Linear(d_model, d_model)
+        self.sa_v_proj = nn.Linear(d_model, d_model)   # present in checkpoints; its output is unused (:471 vs :477)
+        self.nhead = n_heads
+
+    def _self_attention(self, tgt, query_pos):
+        """q = k = content/pos projections of (tgt + query_pos); v = raw tgt.  In training the
+        group_num query groups attend only within their group (folded into the batch)."""
+        x = _add_pos(tgt, query_pos)
+        q = self.sa_qcontent_proj(x) + self.sa_qpos_proj(x)
+        k = self.sa_kcontent_proj(x) + self.sa_kpos_proj(x)
+        v = tgt
+        B, Lq, C = tgt.shape
+        if self.training:
+            G, n = self.group_num, self.group_size
+            if Lq != G * n:
+                raise NotImplementedError("denoising (extra noise queries) is off in every shipped config; "
+                                          "expected %d x %d queries, got %d" % (G, n, Lq))
+            fold = lambda t: t.reshape(B * G, n, C).transpose(0, 1)
+            out = self.self_attn(fold(q), fold(k), fold(v), need_weights=False)[0]
+            return out.transpose(0, 1).reshape(B, Lq, C)
+        out = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), need_weights=False)[0]
+        return out.transpose(0, 1)
+
+    def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
+                src_padding_mask, depth_pos_embed, mask_depth):
+        # depth cross attention over the stride-16 depth-aware tokens
+        tgt2 = self.cross_attn_depth(tgt.transpose(0, 1), depth_pos_embed, depth_pos_embed,
+                                     key_padding_mask=mask_depth, need_weights=False)[0].transpose(0, 1)
+        tgt = self.norm_depth(tgt + self.dropout_depth(tgt2))
+        # self attention
+        tgt = self.norm2(tgt + self.dropout2(self._self_attention(tgt, query_pos)))
+        # visual cross attention
+        tgt2 = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
+                               level_start_index, src_padding_mask)
+        tgt = self.norm1(tgt + self.dropout1(tgt2))
+        # ffn
+        ff = self.linear2(self.dropout3(F.relu(self.linear1(tgt))))
+        return self.norm3(tgt + self.dropout4(ff))
+
+
+class DepthAwareDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, return_intermediate=False, d_model=None):
+        super().__init__()
+        self.layers = _clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.return_intermediate = return_intermediate
+        self.bbox_embed = None     # set by MonoDETR (iterative box refinement)
+        self.dim_embed = None
+        self.class_embed = None
+        # created by the reference in its default branch and never used (:542-544); kept for checkpoints
+        self.query_scale = MLP(d_model, d_model, d_model, 2)
+        self.ref_point_head = MLP(d_model, d_model, 2, 2)
+
+    def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
+                query_pos=None, src_padding_mask=None, depth_pos_embed=None, mask_depth=None):
+        output = tgt
+        inter, inter_refs, inter_dims = [], [], []
+        for lid, layer in enumerate(self.layers):
+            if reference_points.shape[-1] == 6:
+                ratios = torch.cat([src_valid_ratios, src_valid_ratios, src_valid_ratios], -1)
+                reference_points_input = reference_points[:, :, None] * ratios[:, None]
+            else:
+                assert reference_points.shape[-1] == 2
+                reference_points_input = reference_points[:, :, None] * src_valid_ratios[:, None]
+            output = layer(output, query_pos, reference_points_input, src, src_spatial_shapes,
+                           src_level_start_index, src_padding_mask, depth_pos_embed, mask_depth)
+            if self.bbox_embed is not None:   # iterative refinement, detached between layers (:602-613)
+                tmp = self.bbox_embed[lid](output)
+                if reference_points.shape[-1] == 6:
+                    new_ref = tmp + inverse_sigmoid(reference_points)
+                else:
+                    new_ref = torch.cat([tmp[..., :2] + inverse_sigmoid(reference_points), tmp[..., 2:]], -1)
+                reference_points = new_ref.sigmoid().detach()
+            reference_dims = self.dim_embed[lid](output) if self.dim_embed is not None else None
+            if self.return_intermediate:
+                inter.append(output)
+                inter_refs.append(reference_points)
+                inter_dims.append(reference_dims)
+        if self.return_intermediate:
+            return torch.stack(inter), torch.stack(inter_refs), torch.stack(inter_dims)
+        return output, reference_points
+
+
+# ----------------------------------------------------------------------------------------------
+class DepthAwareTransformer(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=1024,
+                 dropout=0.1, activation="relu", return_intermediate_dec=False, num_feature_levels=4,
+                 dec_n_points=4, enc_n_points=4, two_stage=False, two_stage_num_proposals=50, group_num=11,
+                 use_dab=False, two_stage_dino=False):
+        super().__init__()
+        if two_stage or use_dab or two_stage_dino:
+            raise NotImplementedError("two_stage / use_dab / two_stage_dino are off in every shipped MonoSOWA "
+                                      "config and are outside the MI355X hot path")
+        self.d_model = d_model
+        self.nhead = nhead
+        self.two_stage = False
+        self.two_stage_num_proposals = two_stage_num_proposals
+        self.use_dab = False
+        self.two_stage_dino = False
+        self.group_num = group_num
+
+        enc_layer = VisualEncoderLayer(d_model, dim_feedforward, dropout, activation, num_feature_levels, nhead, enc_n_points)
+        self.encoder = VisualEncoder(enc_layer, num_encoder_layers)
+        dec_layer = DepthAwareDecoderLayer(d_model, dim_feedforward, dropout, activation, num_feature_levels, nhead,
+                                           dec_n_points, group_num=group_num, group_size=two_stage_num_proposals)
+        self.decoder = DepthAwareDecoder(dec_layer, num_decoder_layers, return_intermediate_dec, d_model)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        self.reference_points = nn.Linear(d_model, 2)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        xavier_uniform_(self.reference_points.weight.data, gain=1.0)
+        constant_(self.reference_points.bias.data, 0.)
+        normal_(self.level_embed)
+
+    @staticmethod
+    def get_valid_ratio(mask):
+        _, H, W = mask.shape
+        valid_h = torch.sum(~mask[:, :, 0], 1).float() / H
+        valid_w = torch.sum(~mask[:, 0, :], 1).float() / W
+        return torch.stack([valid_w, valid_h], -1)
+
+    def forward(self, srcs, masks, pos_embeds, query_embed=None, depth_pos_embed=None, depth_pos_embed_ip=None,
+                attn_mask=None):
+        assert query_embed is not None
+        src_flat, mask_flat, pos_flat, shapes = [], [], [], []
+        for lvl, (src, mask, pos) in enumerate(zip(srcs, masks, pos_embeds)):
+            _, _, h, w = src.shape
+            shapes.append((h, w))
+            src_flat.append(src.flatten(2).transpose(1, 2))
+            mask_flat.append(mask.flatten(1))
+            pos_flat.append(pos.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1))
+        src_flat = torch.cat(src_flat, 1)
+        mask_flat = torch.cat(mask_flat, 1)
+        pos_flat = torch.cat(pos_flat, 1)
+        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src_flat.device)
+        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+
+        memory = self.encoder(src_flat, spatial_shapes, level_start_index, valid_ratios, pos_flat, mask_flat,
+                              spatial_shapes_list=shapes)
+
+        bs, _, c = memory.shape
+        query_pos, tgt = torch.split(query_embed, c, dim=1)
+        query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
+        tgt = tgt.unsqueeze(0).expand(bs, -1, -1)
+        reference_points = self.reference_points(query_pos).sigmoid()
+        init_reference_out = reference_points
+
+        depth_tokens = depth_pos_embed.flatten(2).permute(2, 0, 1)
+        mask_depth = masks[1].flatten(1)
+        hs, inter_refs, inter_dims = self.decoder(tgt, reference_points, memory, spatial_shapes, level_start_index,
+                                                  valid_ratios, query_pos, mask_flat, depth_tokens, mask_depth)
+        return hs, init_reference_out, inter_refs, inter_dims, None, None
+
+
+def build_depthaware_transformer(cfg):
+    return DepthAwareTransformer(
+        d_model=cfg["hidden_dim"], dropout=cfg["dropout"], activation="relu", nhead=cfg["nheads"],
+        dim_feedforward=cfg["dim_feedforward"], num_encoder_layers=cfg["enc_layers"],
+        num_decoder_layers=cfg["dec_layers"], return_intermediate_dec=cfg["return_intermediate_dec"],
+        num_feature_levels=cfg["num_feature_levels"], dec_n_points=cfg["dec_n_points"],
+        enc_n_points=cfg["enc_n_points"], two_stage=cfg["two_stage"], two_stage_num_proposals=cfg["num_queries"],
+        use_dab=cfg["use_dab"], two_stage_dino=cfg["two_stage_dino"])

@@ -1,0 +1,65 @@
+"""Hungarian matcher with per-group assignment (reference: lib/models/monodetr/matcher.py:14-112).
+
+Cost = cost_class * focal-style class cost + cost_3dcenter * L1(projected 3D centre)
+     + cost_bbox * L1(l,r,t,b) + cost_giou * (-GIoU); queries are split into ``group_num`` groups
+and each group is matched to the targets independently (one-to-many supervision in training).
+The assignment itself (scipy ``linear_sum_assignment`` on the host, as in the reference :87-103)
+is index bookkeeping and must be bit-exact; one device->host copy of the cost matrix per call.
+"""
+import numpy as np
+import torch
+from scipy.optimize import linear_sum_assignment
+from torch import nn
+
+from .box_ops import box_cxcylrtb_to_xyxy, generalized_box_iou
+
+
+class HungarianMatcher(nn.Module):
+    def __init__(self, cost_class: float = 1, cost_3dcenter: float = 1, cost_bbox: float = 1, cost_giou: float = 1):
+        super().__init__()
+        self.cost_class = cost_class
+        self.cost_3dcenter = cost_3dcenter
+        self.cost_bbox = cost_bbox
+        self.cost_giou = cost_giou
+        assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
+
+    @torch.no_grad()
+    def cost_matrix(self, outputs, targets):
+        bs, num_queries = outputs["pred_boxes"].shape[:2]
+        out_prob = outputs["pred_logits"].flatten(0, 1).sigmoid()
+        tgt_ids = torch.cat([v["labels"] for v in targets]).long()
+        alpha, gamma = 0.25, 2.0
+        neg_cost = (1 - alpha) * (out_prob ** gamma) * (-(1 - out_prob + 1e-8).log())
+        pos_cost = alpha * ((1 - out_prob) ** gamma) * (-(out_prob + 1e-8).log())
+        cost_class = pos_cost[:, tgt_ids] - neg_cost[:, tgt_ids]
+
+        out_box = outputs["pred_boxes"].flatten(0, 1)
+        tgt_box = torch.cat([v["boxes_3d"] for v in targets])
+        cost_3dcenter = torch.cdist(out_box[:, 0:2], tgt_box[:, 0:2], p=1)
+        cost_bbox = torch.cdist(out_box[:, 2:6], tgt_box[:, 2:6], p=1)
+        cost_giou = -generalized_box_iou(box_cxcylrtb_to_xyxy(out_box), box_cxcylrtb_to_xyxy(tgt_box), check=False)
+        C = self.cost_bbox * cost_bbox + self.cost_3dcenter * cost_3dcenter + self.cost_class * cost_class \
+            + self.cost_giou * cost_giou
+        return C.view(bs, num_queries, -1)
+
+    @torch.no_grad()
+    def forward(self, outputs, targets, group_num=11):
+        """-> list (per image) of (query_idx int64, target_idx int64), concatenated over groups."""
+        bs, num_queries = outputs["pred_boxes"].shape[:2]
+        C = self.cost_matrix(outputs, targets).cpu()
+        sizes = [len(v["boxes"]) for v in targets]
+        g_q = num_queries // group_num
+        indices = None
+        for g, C_g in enumerate(C.split(g_q, dim=1)[:group_num]):
+            ind_g = [linear_sum_assignment(c[i]) for i, c in enumerate(C_g.split(sizes, -1))]
+            if indices is None:
+                indices = ind_g
+            else:
+                indices = [(np.concatenate([a[0], b[0] + g_q * g]), np.concatenate([a[1], b[1]]))
+                           for a, b in zip(indices, ind_g)]
+        return [(torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)) for i, j in indices]
+
+
+def build_matcher(cfg):
+    return HungarianMatcher(cost_class=cfg["set_cost_class"], cost_bbox=cfg["set_cost_bbox"],
+                            cost_3dcenter=cfg["set_cost_3dcenter"], cost_giou=cfg["set_cost_giou"])

@@ -1,0 +1,176 @@
+"""MonoDETR detector: backbone -> input projections -> depth predictor -> depth-aware transformer
+-> per-decoder-layer heads.
+
+Reference: lib/models/monodetr/monodetr.py -- ``MonoDETR`` :34-299, ``MLP`` :1278-1290.
+Same constructor arguments, parameter names, forward signature
+``model(images, calibs, targets, img_sizes, dn_args=None)`` and output dict keys
+(pred_logits, pred_boxes, pred_3d_dim, pred_depth, pred_angle, pred_depth_map_logits, aux_outputs).
+Only the branch the shipped configs run is restated (two_stage / use_dab / two_stage_dino /
+use_dn are all False).
+"""
+import copy
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .depthaware_transformer import MLP
+from .misc import NestedTensor, inverse_sigmoid
+
+
+def _clones(module, n):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+class MonoDETR(nn.Module):
+    def __init__(self, backbone, depthaware_transformer, depth_predictor, num_classes, num_queries,
+                 num_feature_levels, aux_loss=True, with_box_refine=False, two_stage=False, init_box=False,
+                 use_dab=False, group_num=11, two_stage_dino=False):
+        super().__init__()
+        if two_stage or use_dab or two_stage_dino:
+            raise NotImplementedError("two_stage / use_dab / two_stage_dino are off in every shipped config")
+        self.num_queries = num_queries
+        self.group_num = group_num
+        self.depthaware_transformer = depthaware_transformer
+        self.depth_predictor = depth_predictor
+        hidden_dim = depthaware_transformer.d_model
+        self.hidden_dim = hidden_dim
+        self.num_feature_levels = num_feature_levels
+        self.two_stage_dino = False
+        self.label_enc = nn.Embedding(num_classes + 1, hidden_dim - 1)   # DN indicator table, unused here
+
+        # prediction heads
+        class_embed = nn.Linear(hidden_dim, num_classes)
+        prior_prob = 0.01
+        class_embed.bias.data = torch.ones(num_classes) * (-math.log((1 - prior_prob) / prior_prob))
+        bbox_embed = MLP(hidden_dim, hidden_dim, 6, 3)       # (cx, cy, l, r, t, b)
+        dim_embed_3d = MLP(hidden_dim, hidden_dim, 3, 2)
+        angle_embed = MLP(hidden_dim, hidden_dim, 24, 2)     # 12 heading bins + 12 residuals
+        depth_embed = MLP(hidden_dim, hidden_dim, 2, 2)      # depth and log-variance
+        self.use_dab = False
+        if init_box:
+            nn.init.constant_(bbox_embed.layers[-1].weight.data, 0)
+            nn.init.constant_(bbox_embed.layers[-1].bias.data, 0)
+
+        self.query_embed = nn.Embedding(num_queries * group_num, hidden_dim * 2)
+
+        if num_feature_levels > 1:
+            projs, in_ch = [], None
+            for in_ch in backbone.num_channels:
+                projs.append(nn.Sequential(nn.Conv2d(in_ch, hidden_dim, kernel_size=1), nn.GroupNorm(32, hidden_dim)))
+            for _ in range(num_feature_levels - len(backbone.num_channels)):
+                projs.append(nn.Sequential(nn.Conv2d(in_ch, hidden_dim, kernel_size=3, stride=2, padding=1),
+                                           nn.GroupNorm(32, hidden_dim)))
+                in_ch = hidden_dim
+            self.input_proj = nn.ModuleList(projs)
+        else:
+            self.input_proj = nn.ModuleList([nn.Sequential(
+                nn.Conv2d(backbone.num_channels[0], hidden_dim, kernel_size=1), nn.GroupNorm(32, hidden_dim))])
+
+        self.backbone = backbone
+        self.aux_loss = aux_loss
+        self.with_box_refine = with_box_refine
+        self.two_stage = False
+        self.num_classes = num_classes
+
+        for proj in self.input_proj:
+            nn.init.xavier_uniform_(proj[0].weight, gain=1)
+            nn.init.constant_(proj[0].bias, 0)
+
+        num_pred = depthaware_transformer.decoder.num_layers
+        if with_box_refine:
+            self.class_embed = _clones(class_embed, num_pred)
+            self.bbox_embed = _clones(bbox_embed, num_pred)
+            nn.init.constant_(self.bbox_embed[0].layers[-1].bias.data[2:], -2.0)
+            self.depthaware_transformer.decoder.bbox_embed = self.bbox_embed      # shared with the decoder
+            self.dim_embed_3d = _clones(dim_embed_3d, num_pred)
+            self.depthaware_transformer.decoder.dim_embed = self.dim_embed_3d
+            self.angle_embed = _clones(angle_embed, num_pred)
+            self.depth_embed = _clones(depth_embed, num_pred)
+        else:
+            nn.init.constant_(bbox_embed.layers[-1].bias.data[2:], -2.0)
+            self.class_embed = nn.ModuleList([class_embed for _ in range(num_pred)])
+            self.bbox_embed = nn.ModuleList([bbox_embed for _ in range(num_pred)])
+            self.dim_embed_3d = nn.ModuleList([dim_embed_3d for _ in range(num_pred)])
+            self.angle_embed = nn.ModuleList([angle_embed for _ in range(num_pred)])
+            self.depth_embed = nn.ModuleList([depth_embed for _ in range(num_pred)])
+            self.depthaware_transformer.decoder.bbox_embed = None
+            # NB: the reference leaves decoder.dim_embed = None here and then fails at :623; kept as is.
+
+    # parameters the shipped forward never touches (no gradient): DDP must not wait for them
+    UNUSED_PARAMETER_PREFIXES = ("label_enc.", "depthaware_transformer.decoder.query_scale.",
+                                 "depthaware_transformer.decoder.ref_point_head.")
+    UNUSED_PARAMETER_SUFFIXES = (".sa_v_proj.weight", ".sa_v_proj.bias")
+
+    def unused_parameter_names(self):
+        return [n for n, _ in self.named_parameters()
+                if n.startswith(self.UNUSED_PARAMETER_PREFIXES) or n.endswith(self.UNUSED_PARAMETER_SUFFIXES)]
+
+    def project_features(self, features, pos):
+        srcs, masks = [], []
+        for l, feat in enumerate(features):
+            src, mask = feat.decompose()
+            assert mask is not None
+            srcs.append(self.input_proj[l](src))
+            masks.append(mask)
+        for l in range(len(srcs), self.num_feature_levels):   # extra stride-2 levels from C5
+            src = self.input_proj[l](features[-1].tensors if l == len(features) else srcs[-1])
+            mask = torch.zeros(src.shape[0], src.shape[2], src.shape[3], dtype=torch.bool, device=src.device)
+            pos.append(self.backbone[1](NestedTensor(src, mask)).to(src.dtype))
+            srcs.append(src)
+            masks.append(mask)
+        return srcs, masks, pos
+
+    def forward(self, images, calibs, targets, img_sizes, dn_args=None):
+        """images [B,3,H,W]; calibs [B,3,4] (only fu = calibs[:,0,0] is read); img_sizes [B,2]
+        (only the height column is read); targets / dn_args unused on the shipped path."""
+        features, pos = self.backbone(images)
+        srcs, masks, pos = self.project_features(features, pos)
+
+        query_embeds = self.query_embed.weight if self.training else self.query_embed.weight[:self.num_queries]
+
+        pred_depth_map_logits, depth_pos_embed, weighted_depth, depth_pos_embed_ip = \
+            self.depth_predictor(srcs, masks[1], pos[1])
+
+        hs, init_reference, inter_references, inter_references_dim, _, _ = self.depthaware_transformer(
+            srcs, masks, pos, query_embeds, depth_pos_embed, depth_pos_embed_ip)
+
+        coords, classes, dims3d, depths, angles = [], [], [], [], []
+        fu = calibs[:, 0, 0].unsqueeze(1)
+        img_h = img_sizes[:, 1:2]
+        for lvl in range(hs.shape[0]):
+            reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
+            tmp = self.bbox_embed[lvl](hs[lvl])
+            if reference.shape[-1] == 6:
+                tmp = tmp + reference
+            else:
+                assert reference.shape[-1] == 2
+                tmp = torch.cat([tmp[..., :2] + reference, tmp[..., 2:]], -1)
+            outputs_coord = tmp.sigmoid()                                   # 3D-centre projection + l,r,t,b
+            coords.append(outputs_coord)
+            classes.append(self.class_embed[lvl](hs[lvl]))
+            size3d = inter_references_dim[lvl]
+            dims3d.append(size3d)
+
+            # geometric depth from the 3D height and the predicted 2D box height (monodetr.py:246-248)
+            box2d_height = torch.clamp((outputs_coord[:, :, 4] + outputs_coord[:, :, 5]) * img_h, min=1.0)
+            depth_geo = size3d[:, :, 0] / box2d_height * fu
+            depth_reg = self.depth_embed[lvl](hs[lvl])
+            # depth read from the predicted depth map at the projected 3D centre (:254-259)
+            centre = ((outputs_coord[..., :2] - 0.5) * 2).unsqueeze(2).detach()
+            depth_map = F.grid_sample(weighted_depth.unsqueeze(1), centre, mode="bilinear",
+                                      align_corners=True).squeeze(1)
+            depth_ave = torch.cat([((1. / (depth_reg[:, :, 0:1].sigmoid() + 1e-6) - 1.)
+                                    + depth_geo.unsqueeze(-1) + depth_map) / 3,
+                                   depth_reg[:, :, 1:2]], -1)
+            depths.append(depth_ave)
+            angles.append(self.angle_embed[lvl](hs[lvl]))
+
+        out = {"pred_logits": classes[-1], "pred_boxes": coords[-1], "pred_3d_dim": dims3d[-1],
+               "pred_depth": depths[-1], "pred_angle": angles[-1],
+               "pred_depth_map_logits": pred_depth_map_logits}
+        if self.aux_loss:
+            out["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b, "pred_3d_dim": c, "pred_angle": d, "pred_depth": e}
+                                  for a, b, c, d, e in zip(classes[:-1], coords[:-1], dims3d[:-1], angles[:-1], depths[:-1])]
+        return out
