@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""Headline benchmark: MonoDETR training img/s on KITTI-shaped 1280x384 synthetic images.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch: forward, set criterion (Hungarian matching
+included), backward, AdamW update -- ResNet-50 MonoDETR, per-GPU batch 16, fp32 (the reference's
+precision), inputs resident in HBM before the timed region.  N > 1: one process per GPU, DDP over
+RCCL, per-GPU work fixed ("weak" scaling), value = all images of all ranks / max-over-ranks time.
+
+One JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline      -- the dominant MSDA kernel: algorithmic bytes per launch / average
+                   launch duration measured here with HIP events on the launch stream / 8 TB/s
+  cpu_baseline  -- the CPU restatement (oracle grid_sample formulation, "port") timed on this host,
+                   bounded sample (N=1, rank 0 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_BYTES_PER_S = 8.0e12      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE configs[1]: 16)")
+    ap.add_argument("--backbone", default="resnet50")
+    ap.add_argument("--resolution", default="1280x384")
+    ap.add_argument("--config", default=os.path.join(ROOT, "configs", "monodetr.yaml"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-batch", type=int, default=2)
+    ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    return ap.parse_args()
+
+
+def msda_alg_bytes(kind, dims):
+    """Algorithmic bytes of one launch (every input read once, every output written once)."""
+    B, S, M, D, L, Lq, P = dims
+    if kind == "fwd":
+        return 4 * B * (S * M * D + Lq * M * L * P * 3 + Lq * M * D)
+    return 4 * B * (Lq * M * D + S * M * D + Lq * M * L * P * 3 + S * M * D + Lq * M * L * P * 3)
+
+
+def build_everything(args, device):
+    import torch
+    import yaml
+    from monosowa_amd.helpers.model_helper import build_model
+    from monosowa_amd.helpers.optimizer_helper import build_optimizer
+    cfg = yaml.safe_load(open(args.config))
+    mcfg = cfg["model"]
+    mcfg["backbone"] = args.backbone
+    mcfg["pretrained"] = False
+    mcfg["device"] = device.type
+    W, H = (int(x) for x in args.resolution.split("x"))
+    mcfg["depth_map_size"] = (W // 16, H // 16)
+    torch.manual_seed(cfg.get("random_seed", 444))
+    model, criterion = build_model(mcfg)
+    model.to(device)
+    criterion.to(device)
+    optimizer = build_optimizer(cfg["optimizer"], model)
+    return cfg, model, criterion, optimizer, (W, H)
+
+
+def train_step_fn(model, criterion, optimizer):
+    from monosowa_amd.synthetic import prepare_targets
+
+    def step(batch):
+        inputs, calibs, targets, info = batch
+        tl = prepare_targets(targets, inputs.shape[0])
+        optimizer.zero_grad(set_to_none=True)
+        outputs = model(inputs, calibs, tl, targets["img_size"])
+        loss_dict = criterion(outputs, tl)
+        wd = criterion.weight_dict
+        total = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+        total.backward()
+        optimizer.step()
+        return total
+    return step
+
+
+def cpu_baseline(args):
+    """The CPU path (our restatement; MSDA core = the oracle's grid_sample port of the reference's only
+    CPU-capable definition, ms_deform_attn_func.py:41-61) on this host's cores, bounded sample."""
+    import torch
+    import monosowa_amd.ms_deform_attn_func as F
+    from oracle import msda_oracle as O
+    from monosowa_amd.synthetic import make_batch
+
+    class _CPUFn:
+        @staticmethod
+        def apply(value, shapes, lsi, loc, w, step):
+            return O.msda_core_torch(value, shapes, loc, w)
+
+    saved = F.MSDeformAttnFunction
+    F.MSDeformAttnFunction = _CPUFn
+    try:
+        cores = torch.get_num_threads()
+        cpu = torch.device("cpu")
+        cfg, model, criterion, optimizer, (W, H) = build_everything(args, cpu)
+        model.train()
+        criterion.train()
+        step = train_step_fn(model, criterion, optimizer)
+        B = args.cpu_baseline_batch
+        batch = make_batch(B, cpu, seed=444, resolution=(W, H))
+        t0 = time.time()
+        n = 0
+        while True:
+            step(batch)
+            n += 1
+            if time.time() - t0 > 12.0 or n >= 3:
+                break
+        dt = time.time() - t0
+        return {"value": B * n / dt, "unit": "img/s", "cores": cores, "kind": "port",
+                "sample": "%d train step(s) (fwd+criterion+bwd+AdamW) at batch %d, %dx%d, fp32, %.1f s" % (n, B, W, H, dt)}
+    finally:
+        F.MSDeformAttnFunction = saved
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the CPU path is only the cpu_baseline leg)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.backends.cudnn.benchmark = True       # MIOpen find on the first call of each conv shape
+
+    from monosowa_amd import MultiScaleDeformableAttention as MSDA
+    from monosowa_amd.helpers.trainer_helper import wrap_ddp
+    from monosowa_amd.synthetic import make_batch
+
+    cfg, model, criterion, optimizer, (W, H) = build_everything(args, device)
+    train = args.mode == "train"
+    model.train(train)
+    criterion.train(train)
+    model = wrap_ddp(model, device)
+    batch = make_batch(args.batch, device, seed=444 + rank, resolution=(W, H))
+
+    if train:
+        step = train_step_fn(model, criterion, optimizer)
+    else:
+        def step(b):
+            with torch.no_grad():
+                return model(b[0], b[1], None, b[2]["img_size"])["pred_logits"]
+
+    for _ in range(args.warmup):
+        step(batch)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    with MSDA.LaunchTimer() as timer:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(batch)
+        sync()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    global_batch = args.batch * world
+    value = global_batch * args.steps / elapsed
+    kernels = []
+    for (kind, dims), d in sorted(timer.summary().items(), key=lambda kv: -kv[1]["total_ms"]):
+        ab = msda_alg_bytes(kind, dims)
+        ach = ab / (d["avg_ms"] * 1e-3)
+        kernels.append({"kernel": "msda_%s" % kind, "Lq": dims[5], "B": dims[0], "launches_per_step": d["launches"] / args.steps,
+                        "avg_ms": d["avg_ms"], "alg_bytes": ab, "achieved_GBps": ach / 1e9, "frac": ach / HBM_PEAK_BYTES_PER_S})
+    roofline = None
+    if kernels:
+        k = kernels[0]
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "msda_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("%s_Lq%d_B%d" % (k["kernel"], k["Lq"], k["B"]))
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "%s(B=%d,Lq=%d,S=10200,M=8,D=32,L=4,P=4)" % (k["kernel"], k["B"], k["Lq"]),
+                    "achieved": k["achieved_GBps"], "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
+                    "frac": k["frac"], "traffic": traffic, "avg_launch_ms": k["avg_ms"],
+                    "alg_bytes_per_launch": k["alg_bytes"], "all_msda_kernels": kernels}
+
+    if rank == 0:
+        line = {
+            "metric": "MonoDETR %s img/s (KITTI 1280x384)" % ("training" if train else "inference"),
+            "value": value, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MonoDETR %s KITTI %dx%d, %s step, per-GPU batch %d, synthetic images + random pseudo-labels"
+                                   % (args.backbone, W, H, "fwd+criterion+bwd+AdamW" if train else "eval fwd (50 queries)", args.batch),
+                       "global_batch": global_batch, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
+                       "queries": 550 if train else 50},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            torch.cuda.empty_cache()
+            line["cpu_baseline"] = cpu_baseline(args)
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,7 +22,44 @@ import torch
 
 from . import _lib
 
-__all__ = ["ms_deform_attn_forward", "ms_deform_attn_backward", "install"]
+__all__ = ["ms_deform_attn_forward", "ms_deform_attn_backward", "install", "LaunchTimer"]
+
+
+class LaunchTimer:
+    """Optional per-launch timing of the C-ABI calls with HIP events recorded on the stream the kernels
+    are launched on (bench.py's roofline leg).  Off by default: no events, no overhead.
+
+        with LaunchTimer() as t: ...train steps...
+        t.summary() -> {("fwd", Lq): {"launches": n, "avg_ms": x, "B": b, ...}, ...}
+    """
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        LaunchTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        LaunchTimer.active = None
+
+    def bracket(self, kind, dims):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        self.records.append((kind, dims, e0, e1))
+        return e0, e1
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, dims, e0, e1 in self.records:
+            d = out.setdefault((kind, dims), {"launches": 0, "total_ms": 0.0})
+            d["launches"] += 1
+            d["total_ms"] += e0.elapsed_time(e1)
+        for d in out.values():
+            d["avg_ms"] = d["total_ms"] / d["launches"]
+        return out
 
 
 def _assert(cond, msg):
@@ -65,10 +102,17 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     lib = _lib.load()
     out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
     fn = lib.msda_forward_f32 if value.dtype == torch.float32 else lib.msda_forward_f64
+    timer = LaunchTimer.active
     with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream()
+        if timer is not None:
+            e0, e1 = timer.bracket("fwd", (B, S, M, D, L, Lq, P))
+            e0.record(stream)
         code = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                   sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
-                  B, S, M, D, L, Lq, P, torch.cuda.current_stream().cuda_stream)
+                  B, S, M, D, L, Lq, P, stream.cuda_stream)
+        if timer is not None:
+            e1.record(stream)
     _lib.check(code, "ms_deform_attn_forward")
     return out
 
@@ -86,12 +130,19 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     ws_bytes = lib.msda_backward_workspace_bytes(B, S, M, D, L, Lq, P, value.element_size())
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device) if ws_bytes else None
     fn = lib.msda_backward_f32 if value.dtype == torch.float32 else lib.msda_backward_f64
+    timer = LaunchTimer.active
     with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream()
+        if timer is not None:
+            e0, e1 = timer.bracket("bwd", (B, S, M, D, L, Lq, P))
+            e0.record(stream)
         code = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                   sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
                   grad_value.data_ptr(), grad_loc.data_ptr(), grad_w.data_ptr(),
                   B, S, M, D, L, Lq, P, ws.data_ptr() if ws is not None else None, ws_bytes,
-                  torch.cuda.current_stream().cuda_stream)
+                  stream.cuda_stream)
+        if timer is not None:
+            e1.record(stream)
     _lib.check(code, "ms_deform_attn_backward")
     return [grad_value, grad_loc, grad_w]
 

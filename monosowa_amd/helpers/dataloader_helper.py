@@ -1,0 +1,34 @@
+"""``build_dataloader(cfg['dataset']) -> (train_loader, test_loader)``
+(reference: lib/helpers/dataloader_helper.py:12-36: batch_size from the config, 4 workers, shuffle on
+train).  ``dataset.type: synthetic`` serves seeded KITTI-shaped samples; under torch.distributed each
+rank gets a disjoint shard (DistributedSampler), which the reference (single process) never needed."""
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+from torch.utils.data.distributed import DistributedSampler
+
+from ..monodetr.misc import get_world_size, is_dist_avail_and_initialized
+from ..synthetic import SyntheticKITTI
+
+
+def my_worker_init_fn(worker_id):
+    np.random.seed(np.random.get_state()[1][0] + worker_id)
+
+
+def build_dataset(cfg, split):
+    if cfg["type"] == "synthetic":
+        return SyntheticKITTI(split=split, cfg=cfg)
+    raise NotImplementedError(
+        "dataset.type %r: the KITTI file loader (lib/datasets/kitti/*) is outside the MI355X hot path; "
+        "any Dataset yielding the (img, P2, targets, info) contract of monosowa_amd.synthetic works" % cfg["type"])
+
+
+def build_dataloader(cfg, workers=4):
+    train_set = build_dataset(cfg, cfg["train_split"])
+    test_set = build_dataset(cfg, cfg["test_split"])
+    sampler = DistributedSampler(train_set, shuffle=True) if is_dist_avail_and_initialized() and get_world_size() > 1 else None
+    train_loader = DataLoader(train_set, batch_size=cfg["batch_size"], num_workers=workers, worker_init_fn=my_worker_init_fn,
+                              shuffle=sampler is None, sampler=sampler, pin_memory=torch.cuda.is_available(), drop_last=False)
+    test_loader = DataLoader(test_set, batch_size=cfg["batch_size"], num_workers=workers, worker_init_fn=my_worker_init_fn,
+                             shuffle=False, pin_memory=torch.cuda.is_available(), drop_last=False)
+    return train_loader, test_loader

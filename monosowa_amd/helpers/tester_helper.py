@@ -1,0 +1,105 @@
+"""Inference loop and KITTI result writer (reference: lib/helpers/tester_helper.py -- ``Tester``
+:14-28, ``test`` :28-78, ``inference`` :80-166, ``save_results`` :168-188, ``evaluate`` :190-194).
+
+Model time is measured with device synchronisation (the reference's ``time.time()`` pair at :94-99
+brackets an asynchronous launch).  Open3D visualisation (:196-258) is out of scope; KITTI AP
+evaluation is delegated to ``dataset.eval`` when the dataset provides it."""
+import glob
+import os
+import time
+
+import numpy as np
+import torch
+import tqdm
+
+from .decode_helper import PinholeCalib, decode_detections, extract_dets_from_outputs
+from .save_helper import load_checkpoint
+
+
+class Tester(object):
+    def __init__(self, cfg, model, dataloader, logger, train_cfg=None, model_name="monodetr"):
+        self.cfg = cfg
+        self.model = model
+        self.dataloader = dataloader
+        self.max_objs = dataloader.dataset.max_objs
+        self.class_name = dataloader.dataset.class_name
+        self.output_dir = os.path.join("./" + train_cfg["save_path"], model_name)
+        self.dataset_type = cfg.get("type", "KITTI")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.logger = logger
+        self.train_cfg = train_cfg
+        self.model_name = model_name
+        self.last_img_per_s = None
+
+    def test(self):
+        assert self.cfg["mode"] in ["single", "all"]
+        if self.cfg["mode"] == "single":
+            path = os.path.join(self.output_dir, "checkpoint_epoch_{}.pth".format(self.cfg["checkpoint"]))
+            load_checkpoint(model=self.model, optimizer=None, filename=path, map_location=self.device, logger=self.logger)
+            self.model.to(self.device)
+            self.inference()
+            return self.evaluate()
+        ckpts = sorted(glob.glob(os.path.join(self.output_dir, "checkpoint_epoch_*.pth")), key=os.path.getmtime)
+        result = None
+        for path in ckpts:
+            load_checkpoint(model=self.model, optimizer=None, filename=path, map_location=self.device, logger=self.logger)
+            self.model.to(self.device)
+            self.inference()
+            result = self.evaluate()
+        return result
+
+    @torch.no_grad()
+    def inference(self):
+        self.model.eval()
+        results, model_time, n_img = {}, 0.0, 0
+        bar = tqdm.tqdm(total=len(self.dataloader), leave=True, desc="Evaluation Progress")
+        for inputs, calibs, targets, info in self.dataloader:
+            inputs = inputs.to(self.device)
+            calibs_dev = calibs.to(self.device)
+            img_sizes = info["img_size"].to(self.device).clone()
+            img_sizes[:, 1] = img_sizes[:, 1] / info["height_crop"].to(self.device)
+            if self.device.type == "cuda":
+                torch.cuda.synchronize()
+            t0 = time.time()
+            outputs = self.model(inputs, calibs_dev, targets, img_sizes, dn_args=0)
+            if self.device.type == "cuda":
+                torch.cuda.synchronize()
+            model_time += time.time() - t0
+            n_img += inputs.shape[0]
+            dets = extract_dets_from_outputs(outputs=outputs, K=self.max_objs, topk=self.cfg["topk"]).cpu().numpy()
+            dataset = self.dataloader.dataset
+            if hasattr(dataset, "get_calib"):
+                cal = [dataset.get_calib(int(i)) for i in info["img_id"]]
+            else:
+                cal = [PinholeCalib(p) for p in calibs.numpy()]
+            info_np = {k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in info.items()}
+            results.update(decode_detections(dets=dets, info=info_np, calibs=cal, cls_mean_size=dataset.cls_mean_size,
+                                             threshold=self.cfg.get("threshold", 0.2)))
+            bar.update()
+        bar.close()
+        self.last_img_per_s = n_img / max(model_time, 1e-9)
+        print("inference on {} images: {:.2f} img/s (model only)".format(n_img, self.last_img_per_s))
+        self.logger.info("==> Saving ...")
+        self.save_results(results)
+        return results
+
+    def save_results(self, results):
+        """One KITTI label file per image: 'Class 0.0 0 alpha x1 y1 x2 y2 h w l x y z ry score', '%.2f'."""
+        output_dir = os.path.join(self.output_dir, "outputs", "data")
+        os.makedirs(output_dir, exist_ok=True)
+        for img_id, preds in results.items():
+            with open(os.path.join(output_dir, "{:06d}.txt".format(int(img_id))), "w") as f:
+                for p in preds:
+                    f.write("{} 0.0 0".format(self.class_name[int(p[0])]))
+                    for j in range(1, len(p)):
+                        f.write(" {:.2f}".format(p[j]))
+                    f.write("\n")
+
+    def evaluate(self):
+        results_dir = os.path.join(self.output_dir, "outputs", "data")
+        assert os.path.exists(results_dir)
+        dataset = self.dataloader.dataset
+        if hasattr(dataset, "eval"):
+            return dataset.eval(results_dir=results_dir, logger=self.logger)
+        self.logger.info("dataset has no KITTI AP evaluator (numba kitti_eval_python is out of scope); returning 0")
+        return 0.0

@@ -1,0 +1,155 @@
+"""Epoch loop (reference: lib/helpers/trainer_helper.py -- ``Trainer.__init__`` :15-63, ``train``
+:65-114, ``train_one_epoch`` :116-178, ``prepare_targets`` :180-191).  Same constructor signature and
+checkpoint naming.  Differences that do not change results:
+
+* ``torch.distributed`` aware: under ``torchrun`` the model is wrapped in DistributedDataParallel
+  (bucketed RCCL all-reduce overlapped with backward); rank 0 alone writes checkpoints and logs.
+* the per-iteration ``.item()`` of ~30 loss terms (a host sync every step, :153-157) happens only on
+  the logging iterations (every 30th, as printed by the reference).
+"""
+import os
+
+import numpy as np
+import torch
+import tqdm
+
+from ..monodetr import misc
+from ..synthetic import prepare_targets as _prepare_targets
+from .save_helper import get_checkpoint_state, load_checkpoint, save_checkpoint, unwrap
+
+
+def wrap_ddp(model, device):
+    """DDP with few large buckets (xGMI rings are per-link bound) and the never-used parameters frozen."""
+    if not (misc.is_dist_avail_and_initialized() and misc.get_world_size() > 1):
+        return model
+    core = unwrap(model)
+    unused = set(core.unused_parameter_names()) if hasattr(core, "unused_parameter_names") else set()
+    for n, p in core.named_parameters():
+        if n in unused:
+            p.requires_grad_(False)
+    ids = [device.index] if device.type == "cuda" else None
+    return torch.nn.parallel.DistributedDataParallel(core, device_ids=ids, bucket_cap_mb=64,
+                                                     gradient_as_bucket_view=True, broadcast_buffers=False)
+
+
+class Trainer(object):
+    def __init__(self, cfg, model, optimizer, train_loader, test_loader, lr_scheduler, warmup_lr_scheduler,
+                 logger, loss, model_name):
+        self.cfg = cfg
+        self.optimizer = optimizer
+        self.train_loader = train_loader
+        self.test_loader = test_loader
+        self.lr_scheduler = lr_scheduler
+        self.warmup_lr_scheduler = warmup_lr_scheduler
+        self.logger = logger
+        self.epoch = 0
+        self.best_result = 0
+        self.best_epoch = 0
+        if torch.cuda.is_available():
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        else:
+            self.device = torch.device("cpu")
+        self.model = wrap_ddp(model, self.device)
+        self.detr_loss = loss
+        self.model_name = model_name
+        self.output_dir = os.path.join("./" + cfg["save_path"], model_name)
+        self.tester = None
+        self.log_interval = 30
+
+        if cfg.get("pretrain_model"):
+            assert os.path.exists(cfg["pretrain_model"])
+            load_checkpoint(model=self.model, optimizer=None, filename=cfg["pretrain_model"],
+                            map_location=self.device, logger=self.logger)
+        if cfg.get("resume_model", None):
+            resume = os.path.join(self.output_dir, "checkpoint.pth")
+            assert os.path.exists(resume)
+            self.epoch, self.best_result, self.best_epoch = load_checkpoint(
+                model=self.model.to(self.device), optimizer=self.optimizer, filename=resume,
+                map_location=self.device, logger=self.logger)
+            self.lr_scheduler.last_epoch = self.epoch - 1
+            self.logger.info("Loading Checkpoint... Best Result:{}, Best Epoch:{}".format(self.best_result, self.best_epoch))
+
+    def train(self):
+        start_epoch = self.epoch
+        best_result, best_epoch = self.best_result, self.best_epoch
+        main = misc.is_main_process()
+        bar = tqdm.tqdm(range(start_epoch, self.cfg["max_epoch"]), dynamic_ncols=True, leave=True, desc="epochs", disable=not main)
+        for epoch in range(start_epoch, self.cfg["max_epoch"]):
+            np.random.seed(np.random.get_state()[1][0] + epoch)
+            sampler = getattr(self.train_loader, "sampler", None)
+            if hasattr(sampler, "set_epoch"):
+                sampler.set_epoch(epoch)
+            self.train_one_epoch(epoch)
+            self.epoch += 1
+            if self.warmup_lr_scheduler is not None and epoch < 5:
+                self.warmup_lr_scheduler.step()
+            else:
+                self.lr_scheduler.step()
+            if (self.epoch % self.cfg["save_frequency"]) == 0 and main:
+                os.makedirs(self.output_dir, exist_ok=True)
+                name = "checkpoint_epoch_%d" % self.epoch if self.cfg["save_all"] else "checkpoint"
+                save_checkpoint(get_checkpoint_state(self.model, self.optimizer, self.epoch, best_result, best_epoch),
+                                os.path.join(self.output_dir, name))
+                if self.tester is not None:
+                    self.logger.info("Test Epoch {}".format(self.epoch))
+                    self.tester.inference()
+                    cur = self.tester.evaluate()
+                    if cur > best_result:
+                        best_result, best_epoch = cur, self.epoch
+                        save_checkpoint(get_checkpoint_state(self.model, self.optimizer, self.epoch, best_result, best_epoch),
+                                        os.path.join(self.output_dir, "checkpoint_best"))
+                    self.logger.info("Best Result:{}, epoch:{}".format(best_result, best_epoch))
+            bar.update()
+        self.logger.info("Best Result:{}, epoch:{}".format(best_result, best_epoch))
+        return None
+
+    def train_step(self, inputs, calibs, targets, info=None):
+        """One optimizer step on a device-resident batch; returns (total loss tensor, loss dict)."""
+        img_sizes = targets["img_size"]
+        target_list = self.prepare_targets(targets, inputs.shape[0])
+        self.optimizer.zero_grad(set_to_none=True)
+        outputs = self.model(inputs, calibs, target_list, img_sizes, dn_args=None)
+        loss_dict = self.detr_loss(outputs, target_list, None, info)
+        weight_dict = self.detr_loss.weight_dict
+        total = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
+        total.backward()
+        self.optimizer.step()
+        return total, loss_dict
+
+    def train_one_epoch(self, epoch):
+        torch.set_grad_enabled(True)
+        self.model.train()
+        self.detr_loss.train()
+        main = misc.is_main_process()
+        if main:
+            print(">>>>>>> Epoch:", str(epoch) + ":")
+        bar = tqdm.tqdm(total=len(self.train_loader), leave=(self.epoch + 1 == self.cfg["max_epoch"]), desc="iters", disable=not main)
+        for batch_idx, (inputs, calibs, targets, info) in enumerate(self.train_loader):
+            inputs = inputs.to(self.device, non_blocking=True)
+            calibs = calibs.to(self.device, non_blocking=True)
+            targets = {k: v.to(self.device, non_blocking=True) for k, v in targets.items()}
+            total, loss_dict = self.train_step(inputs, calibs, targets, info)
+            if batch_idx % self.log_interval == 0:
+                self._log(batch_idx, loss_dict)
+            bar.update()
+        bar.close()
+
+    def _log(self, batch_idx, loss_dict):
+        weight_dict = self.detr_loss.weight_dict
+        reduced = misc.reduce_dict({k: v for k, v in loss_dict.items() if k in weight_dict})
+        if not misc.is_main_process():
+            return
+        logged = {k: (reduced[k] * weight_dict[k]).item() for k in reduced}
+        print("----", batch_idx, "----")
+        print("%s: %.2f, " % ("loss_detr", sum(logged.values())))
+        seen = set()
+        for key, val in logged.items():
+            if key[-1].isdigit() and key[-1] not in seen:
+                print("")
+                seen.add(key[-1])
+            print("%s: %.2f, " % (key, val), end="")
+        print("\n")
+
+    @staticmethod
+    def prepare_targets(targets, batch_size):
+        return _prepare_targets(targets, batch_size)

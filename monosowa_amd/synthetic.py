@@ -1,0 +1,102 @@
+"""Synthetic KITTI-shaped data honouring the reference dataloader's batch contract
+``(inputs f32[B,3,H,W], calibs f32[B,3,4], targets{... [B,50,.]}, info{...})``
+(lib/datasets/kitti/kitti_dataset.py:271-283,397-412,465-489) -- SURVEY.md section 8d, config 2:
+images ~ N(0,1); P2 with fu = fv = 707.05 * (1280/1242), cu = 640, cv = 192; img_size (1242, 375);
+per image n ~ U{1..10} Car objects, boxes_3d = (cx, cy, l, r, t, b) with cx, cy ~ U(0.1, 0.9) and
+l, r, t, b ~ U(0.01, 0.1); boxes = the matching cxcywh; depth ~ U(5, 60);
+size_3d ~ N((1.53, 1.63, 3.88), 0.1); heading_bin ~ U{0..11}; heading_res ~ U(-pi/12, pi/12);
+labels = 1 (Car); padded to 50 slots with mask_2d.  These values are chosen for the synthetic
+benchmark, not taken from the reference."""
+import math
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+MAX_OBJS = 50
+
+
+def synthetic_sample(rng, resolution=(1280, 384), canonical_focal_length=500.0):
+    W, H = resolution
+    img = rng.standard_normal((3, H, W), dtype=np.float32)
+    fu = 707.05 * (W / 1242.0)
+    calib = np.array([[fu, 0, W / 2.0, 0], [0, fu, H / 2.0, 0], [0, 0, 1, 0]], dtype=np.float32)
+    n = int(rng.integers(1, 11))
+    t = {
+        "calibs": np.zeros((MAX_OBJS, 3, 4), dtype=np.float32),      # P2 per object slot (kitti_dataset.py:271,392)
+        "indices": np.zeros((MAX_OBJS,), dtype=np.int64),
+        "img_size": np.array([1242, 375], dtype=np.int32),
+        "labels": np.zeros((MAX_OBJS,), dtype=np.int8),
+        "boxes": np.zeros((MAX_OBJS, 4), dtype=np.float32),
+        "boxes_3d": np.zeros((MAX_OBJS, 6), dtype=np.float32),
+        "depth": np.zeros((MAX_OBJS, 1), dtype=np.float32),
+        "size_2d": np.zeros((MAX_OBJS, 2), dtype=np.float32),
+        "size_3d": np.zeros((MAX_OBJS, 3), dtype=np.float32),
+        "src_size_3d": np.zeros((MAX_OBJS, 3), dtype=np.float32),
+        "heading_bin": np.zeros((MAX_OBJS, 1), dtype=np.int64),
+        "heading_res": np.zeros((MAX_OBJS, 1), dtype=np.float32),
+        "mask_2d": np.zeros((MAX_OBJS,), dtype=bool),
+    }
+    c = rng.uniform(0.1, 0.9, (n, 2)).astype(np.float32)
+    lrtb = rng.uniform(0.01, 0.1, (n, 4)).astype(np.float32)
+    t["boxes_3d"][:n] = np.concatenate([c, lrtb], 1)
+    x0, x1 = c[:, 0] - lrtb[:, 0], c[:, 0] + lrtb[:, 1]
+    y0, y1 = c[:, 1] - lrtb[:, 2], c[:, 1] + lrtb[:, 3]
+    t["boxes"][:n] = np.stack([(x0 + x1) / 2, (y0 + y1) / 2, x1 - x0, y1 - y0], 1)
+    t["size_2d"][:n] = t["boxes"][:n, 2:] * np.array([W, H], dtype=np.float32)
+    canonical_scale = canonical_focal_length / fu          # Canonical Object Space (kitti_dataset.py:232-237)
+    t["depth"][:n, 0] = rng.uniform(5, 60, n).astype(np.float32) * canonical_scale
+    t["size_3d"][:n] = (np.array([1.53, 1.63, 3.88]) + 0.1 * rng.standard_normal((n, 3))).astype(np.float32)
+    t["src_size_3d"][:n] = t["size_3d"][:n]
+    t["heading_bin"][:n, 0] = rng.integers(0, 12, n)
+    t["heading_res"][:n, 0] = rng.uniform(-math.pi / 12, math.pi / 12, n).astype(np.float32)
+    t["labels"][:n] = 1
+    t["calibs"][:n] = calib
+    t["mask_2d"][:n] = True
+    t["indices"][:n] = np.arange(n)
+    info = {"img_id": 0, "img_size": np.array([1242, 375], dtype=np.int32),
+            "bbox_downsample_ratio": np.array([1242 / (W / 16), 375 / (H / 16)], dtype=np.float32),
+            "height_crop": np.float32(1.0), "canonical_scale": np.float32(canonical_scale)}
+    return img, calib, t, info
+
+
+class SyntheticKITTI(Dataset):
+    """Index-seeded synthetic dataset with the KITTI_Dataset item contract (img, calib, targets, info)."""
+
+    def __init__(self, split="train", cfg=None, num_samples=None, seed=444):
+        cfg = cfg or {}
+        self.split = split
+        self.resolution = tuple(cfg.get("resolution", (1280, 384)))
+        self.num_samples = int(num_samples if num_samples is not None else cfg.get("num_samples", 64))
+        self.canonical_focal_length = float(cfg.get("canonical_focal_length", 500.0))
+        self.seed = seed + (0 if split == "train" else 100003)
+        self.max_objs = MAX_OBJS
+        self.class_name = ["Pedestrian", "Car", "Cyclist"]
+        self.cls_mean_size = np.zeros((3, 3), dtype=np.float32)   # meanshape: False
+
+    def __len__(self):
+        return self.num_samples
+
+    def __getitem__(self, i):
+        rng = np.random.default_rng(self.seed * 1000003 + i)
+        img, calib, t, info = synthetic_sample(rng, self.resolution, self.canonical_focal_length)
+        info["img_id"] = i
+        return img, calib, t, info
+
+
+def make_batch(batch_size, device, seed=444, resolution=(1280, 384)):
+    """One pre-collated batch resident on ``device``: (inputs, calibs, targets dict of [B,50,...], info)."""
+    rng = np.random.default_rng(seed)
+    samples = [synthetic_sample(rng, resolution) for _ in range(batch_size)]
+    inputs = torch.from_numpy(np.stack([s[0] for s in samples])).to(device)
+    calibs = torch.from_numpy(np.stack([s[1] for s in samples])).to(device)
+    targets = {k: torch.from_numpy(np.stack([s[2][k] for s in samples])).to(device) for k in samples[0][2]}
+    info = {k: np.stack([np.asarray(s[3][k]) for s in samples]) for k in samples[0][3]}
+    return inputs, calibs, targets, info
+
+
+def prepare_targets(targets, batch_size):
+    """Padded [B,50,...] dict -> list of per-image dicts of the valid objects (trainer_helper.py:180-191)."""
+    keys = ("labels", "boxes", "calibs", "depth", "size_3d", "heading_bin", "heading_res", "boxes_3d")
+    mask = targets["mask_2d"]
+    return [{k: v[b][mask[b]] for k, v in targets.items() if k in keys} for b in range(batch_size)]
