@@ -29,6 +29,16 @@ if ROOT not in sys.path:
 HBM_PEAK_BYTES_PER_S = 8.0e12      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def log(msg):
+    """Progress to stderr (keeps a long run visibly alive; stdout carries only the JSON line)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write("[bench %7.1fs] %s\n" % (time.time() - _T0, msg))
+        sys.stderr.flush()
+
+
+_T0 = time.time()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -41,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-batch", type=int, default=2)
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--miopen-find", action="store_true", help="cudnn.benchmark=True: MIOpen searches per conv shape (slow start)")
     return ap.parse_args()
 
 
@@ -143,7 +154,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=device)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.backends.cudnn.benchmark = True       # MIOpen find on the first call of each conv shape
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    log("torch %s on %s, world %d" % (torch.__version__, torch.cuda.get_device_name(local_rank), world))
 
     from monosowa_amd import MultiScaleDeformableAttention as MSDA
     from monosowa_amd.helpers.trainer_helper import wrap_ddp
@@ -163,8 +175,12 @@ def main():
             with torch.no_grad():
                 return model(b[0], b[1], None, b[2]["img_size"])["pred_logits"]
 
-    for _ in range(args.warmup):
+    log("model + batch ready; warm-up")
+    for i in range(args.warmup):
+        t1 = time.time()
         step(batch)
+        torch.cuda.synchronize()
+        log("warm-up step %d: %.2f s" % (i, time.time() - t1))
 
     def sync():
         if world > 1:
@@ -178,6 +194,7 @@ def main():
             step(batch)
         sync()
         elapsed = time.perf_counter() - t0
+    log("timed %d steps: %.3f s" % (args.steps, elapsed))
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -220,6 +237,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
+            log("cpu_baseline leg (bounded sample)")
             line["cpu_baseline"] = cpu_baseline(args)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)

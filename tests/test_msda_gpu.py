@@ -196,7 +196,7 @@ def test_preconditions_on_gpu():
     with pytest.raises(RuntimeError, match="must divide im2col_step"):
         MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, w, 2)          # 3 % 2 != 0 (cu:50-52)
     with pytest.raises(RuntimeError, match="contiguous"):
-        MSDA.ms_deform_attn_forward(v.transpose(1, 2).contiguous().transpose(1, 2), shapes, lsi, loc, w, 64)
+        MSDA.ms_deform_attn_forward(torch.zeros(3, 4, 2, 4).cuda()[:, :, :1], shapes, lsi, loc, w, 64)
     with pytest.raises(RuntimeError, match="CUDA tensor"):
         MSDA.ms_deform_attn_forward(v, shapes.cpu(), lsi, loc, w, 64)
     out = MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, w, 3)
