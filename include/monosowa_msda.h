@@ -29,6 +29,12 @@
  * (a hipStream_t; NULL = the null stream), asynchronously, with no host synchronisation and no
  * allocation (`workspace` entry points below), so calls may be captured into a hipGraph.
  *
+ * Level geometry on the host: `shapes_host` / `level_start_host` are optional HOST copies of
+ * `shapes` / `level_start` (same values).  The backward's launch plan depends on H_l, W_l; when the
+ * host copies are NULL the library fetches them from the device with a blocking copy on `stream`
+ * (correct, but a host synchronisation and not graph-capturable) -- callers that know the pyramid
+ * (they built it) should pass them.
+ *
  * Errors: 0 on success; a positive value is a hipError_t from the launch (the reference only
  * printf's launch errors, cuh:948-952 -- this library returns them); negative values are
  * MSDA_E_* argument errors.  msda_strerror() names either kind.  Re-entrant, no global state.
@@ -43,17 +49,19 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 1
+#define MSDA_ABI_VERSION 2
 
 #define MSDA_E_NULLPTR (-1)   /* a required pointer is NULL                        */
 #define MSDA_E_SHAPE (-2)     /* a dimension is <= 0 or exceeds the indexing range */
 #define MSDA_E_UNSUPPORTED (-3)
+#define MSDA_E_WORKSPACE (-4)  /* workspace is NULL or smaller than msda_backward_workspace_bytes() */
 
 int msda_abi_version(void);
 const char *msda_strerror(int code);
 
-/* Bytes of scratch the backward needs for this geometry (0 if none); the caller allocates it
- * once and passes it to msda_backward_*; it may be NULL when the answer is 0. */
+/* Bytes of device scratch the backward needs for this geometry (0 if none); the caller allocates
+ * it (any alignment >= 16) and passes it to msda_backward_*; it may be NULL when the answer is 0.
+ * Contents need not be preserved between calls. */
 size_t msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int Lq, int P, int elem_bytes);
 
 int msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
@@ -68,12 +76,14 @@ int msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *
                       const float *loc, const float *attn_w, const float *grad_out,
                       float *grad_value, float *grad_loc, float *grad_attn_w,
                       int B, int S, int M, int D, int L, int Lq, int P,
+                      const int64_t *shapes_host, const int64_t *level_start_host,
                       void *workspace, size_t workspace_bytes, void *stream);
 
 int msda_backward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,
                       const double *loc, const double *attn_w, const double *grad_out,
                       double *grad_value, double *grad_loc, double *grad_attn_w,
                       int B, int S, int M, int D, int L, int Lq, int P,
+                      const int64_t *shapes_host, const int64_t *level_start_host,
                       void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus

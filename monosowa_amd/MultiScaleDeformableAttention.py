@@ -117,7 +117,31 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
-def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
+def host_geometry(spatial_shapes, level_start_index):
+    """Host copies of the (tiny) pyramid tensors for the backward's launch plan.  A caller that
+    built the pyramid can pre-attach them (``attach_host_geometry``) and avoid the device->host sync."""
+    cached = getattr(spatial_shapes, "_msda_host_geometry", None)
+    if cached is not None:
+        return cached
+    return attach_host_geometry(spatial_shapes, level_start_index,
+                                spatial_shapes.tolist(), level_start_index.tolist())
+
+
+def attach_host_geometry(spatial_shapes, level_start_index, shapes_list, lsi_list):
+    import ctypes
+    L = len(shapes_list)
+    sh = (ctypes.c_int64 * (2 * L))(*[int(x) for hw in shapes_list for x in hw])
+    ls = (ctypes.c_int64 * L)(*[int(x) for x in lsi_list])
+    geom = (sh, ls)
+    try:
+        spatial_shapes._msda_host_geometry = geom
+    except Exception:
+        pass
+    return geom
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step,
+                            host_geom=None):
     """-> [grad_value, grad_sampling_loc, grad_attn_weight]   (reference: cu:83-153)"""
     _check_common([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
                    ("sampling_loc", sampling_loc), ("attn_weight", attn_weight), ("grad_output", grad_output)], im2col_step)
@@ -130,6 +154,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     ws_bytes = lib.msda_backward_workspace_bytes(B, S, M, D, L, Lq, P, value.element_size())
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device) if ws_bytes else None
     fn = lib.msda_backward_f32 if value.dtype == torch.float32 else lib.msda_backward_f64
+    if host_geom is None:
+        host_geom = host_geometry(spatial_shapes, level_start_index) if ws_bytes else (None, None)
     timer = LaunchTimer.active
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream()
@@ -139,8 +165,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         code = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                   sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
                   grad_value.data_ptr(), grad_loc.data_ptr(), grad_w.data_ptr(),
-                  B, S, M, D, L, Lq, P, ws.data_ptr() if ws is not None else None, ws_bytes,
-                  stream.cuda_stream)
+                  B, S, M, D, L, Lq, P, host_geom[0], host_geom[1],
+                  ws.data_ptr() if ws is not None else None, ws_bytes, stream.cuda_stream)
         if timer is not None:
             e1.record(stream)
     _lib.check(code, "ms_deform_attn_backward")

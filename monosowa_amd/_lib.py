@@ -11,6 +11,7 @@ SYMBOLS = ("msda_abi_version", "msda_strerror", "msda_backward_workspace_bytes",
            "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64")
 
 _lib = None
+ABI_VERSION = 2
 
 
 class MSDALibraryError(RuntimeError):
@@ -38,8 +39,8 @@ def load():
         f.argtypes = [P] * 6 + [I] * 7 + [P]
         b = getattr(lib, "msda_backward_" + suf)
         b.restype = I
-        b.argtypes = [P] * 9 + [I] * 7 + [P, Z, P]
-    if lib.msda_abi_version() != 1:
+        b.argtypes = [P] * 9 + [I] * 7 + [P, P, P, Z, P]
+    if lib.msda_abi_version() != ABI_VERSION:
         raise MSDALibraryError("ABI version mismatch in %s" % LIB_PATH)
     _lib = lib
     return lib

@@ -14,10 +14,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 ARCH = "gfx950"
 
-# library name -> (translation unit, extra dependencies that trigger a rebuild)
+# library name -> (translation unit, extra dependencies that trigger a rebuild); every file under
+# csrc/ counts as a dependency as well
 LIBS = {
-    "libmonosowa_msda.so": ("msda_capi.hip", ["msda_kernels.hip", "msda_common.h",
-                                               os.path.join("..", "..", "include", "monosowa_msda.h")]),
+    "libmonosowa_msda.so": ("msda_capi.hip", [os.path.join("..", "..", "include", "monosowa_msda.h")]),
 }
 
 FLAGS = ["-O3", "--offload-arch=" + ARCH, "-munsafe-fp-atomics", "-fPIC", "-shared", "-std=c++17",
@@ -44,7 +44,8 @@ def build_all(force=False, verbose=False):
     for name, (tu, deps) in LIBS.items():
         out = os.path.join(LIBDIR, name)
         src = os.path.join(CSRC, tu)
-        alldeps = [src] + [os.path.normpath(os.path.join(CSRC, d)) for d in deps]
+        alldeps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + \
+                  [os.path.normpath(os.path.join(CSRC, d)) for d in deps]
         if force or _stale(out, alldeps):
             cmd = [hipcc()] + FLAGS + ["-o", out, src]
             if verbose:

@@ -5,6 +5,9 @@
 // launch covers the whole batch and the chunking precondition lives in the Python shim.
 #include "../../include/monosowa_msda.h"
 #include "msda_kernels.hip"
+#include "msda_backward_tiled.hip"
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -43,15 +46,104 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
   return (int)hipGetLastError();
 }
 
+inline bool tiled_backward_applies(int elem_bytes, int D, int L, int P) {
+  return elem_bytes == 4 && D == 32 && L == 4 && P == 4 && L <= msda::kMaxLevels;
+}
+
+inline size_t tiled_workspace_bytes(int B, int M, int L, int Lq, int P) {
+  return (size_t)B * M * L * Lq * P * 12;      // {h_im, w_im} + {attn_w} per sampling point
+}
+
+// Tiling of every level for the tile-owner scatter (msda_backward_tiled.hip, K2).
+msda::BwdPlan make_plan(const int64_t *shapes_host, const int64_t *lsi_host, int L, int Lq, int P) {
+  msda::BwdPlan plan{};
+  plan.n_levels = L;
+  const long long n_pts = (long long)Lq * P;
+  const long long target = 8192;                 // sampling points scanned per workgroup, roughly
+  double work[msda::kMaxLevels];
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)shapes_host[2 * l], W = (int)shapes_host[2 * l + 1];
+    plan.H[l] = H;
+    plan.W[l] = W;
+    plan.start[l] = (int)lsi_host[l];
+    if ((long long)H * W <= msda::kTileRows) {
+      plan.th[l] = H; plan.tw[l] = W; plan.n_ty[l] = 1; plan.n_tx[l] = 1;
+    } else {
+      // balanced tiles of at most 16 x 32 (or 512 / W rows when the level is narrow)
+      const int max_tw = std::min(W, 32), max_th = std::max(1, std::min(H, msda::kTileRows / max_tw));
+      plan.n_tx[l] = (W + max_tw - 1) / max_tw;
+      plan.tw[l] = (W + plan.n_tx[l] - 1) / plan.n_tx[l];
+      plan.n_ty[l] = (H + max_th - 1) / max_th;
+      plan.th[l] = (H + plan.n_ty[l] - 1) / plan.n_ty[l];
+    }
+    const long long tiles = (long long)plan.n_ty[l] * plan.n_tx[l];
+    const long long per_tile = (n_pts + tiles - 1) / tiles;
+    plan.n_chunks[l] = (int)std::max(1LL, std::min(8LL, (per_tile + target / 2) / target));
+    work[l] = (double)per_tile / plan.n_chunks[l];
+    plan.order[l] = l;
+  }
+  std::sort(plan.order, plan.order + L, [&](int a, int b) { return work[a] > work[b]; });
+  plan.first_item[0] = 0;
+  for (int i = 0; i < L; ++i) {
+    const int l = plan.order[i];
+    plan.first_item[i + 1] = plan.first_item[i] + plan.n_ty[l] * plan.n_tx[l] * plan.n_chunks[l];
+  }
+  plan.n_items = plan.first_item[L];
+  return plan;
+}
+
 template <typename T>
 int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc,
                   const T *attw, const T *grad_out, T *grad_value, T *grad_loc, T *grad_attw,
-                  int B, int S, int M, int D, int L, int Lq, int P, void *, size_t, void *stream_) {
+                  int B, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
+                  const int64_t *lsi_host, void *workspace, size_t workspace_bytes, void *stream_) {
   if (!value || !shapes || !lsi || !loc || !attw || !grad_out || !grad_value || !grad_loc || !grad_attw)
     return MSDA_E_NULLPTR;
   if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
   hipStream_t stream = (hipStream_t)stream_;
   const long long n_pairs = (long long)B * Lq * M;
+
+  if constexpr (sizeof(T) == 4) {
+    if (tiled_backward_applies(4, D, L, P)) {
+      const size_t need = tiled_workspace_bytes(B, M, L, Lq, P);
+      if (!workspace || workspace_bytes < need) return MSDA_E_WORKSPACE;
+      int64_t host_geom[3 * msda::kMaxLevels];
+      if (!shapes_host || !lsi_host) {          // blocking fetch of the pyramid (see header)
+        hipError_t e = hipMemcpyAsync(host_geom, shapes, sizeof(int64_t) * 2 * L, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess)
+          e = hipMemcpyAsync(host_geom + 2 * L, lsi, sizeof(int64_t) * L, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return (int)e;
+        shapes_host = host_geom;
+        lsi_host = host_geom + 2 * L;
+      }
+      long long tokens = 0;
+      for (int l = 0; l < L; ++l) {
+        if (shapes_host[2 * l] <= 0 || shapes_host[2 * l + 1] <= 0) return MSDA_E_SHAPE;
+        tokens += shapes_host[2 * l] * shapes_host[2 * l + 1];
+      }
+      if (tokens != S) return MSDA_E_SHAPE;
+      const msda::BwdPlan plan = make_plan(shapes_host, lsi_host, L, Lq, P);
+      float2 *rec_hw = reinterpret_cast<float2 *>(workspace);
+      float *rec_aw = reinterpret_cast<float *>(rec_hw + (size_t)B * M * L * Lq * P);
+      const long long n_rec = (long long)B * M * L * Lq * P;
+      msda::bwd_prep_kernel<<<grid_for(n_rec, 256), 256, 0, stream>>>(loc, attw, shapes, rec_hw, rec_aw, M, L,
+                                                                        Lq, P, n_rec);
+      // levels shared by several workgroups are accumulated with atomics: zero exactly those rows
+      for (int l = 0; l < L; ++l) {
+        if (plan.n_chunks[l] == 1) continue;
+        hipError_t e = hipMemset2DAsync(grad_value + (size_t)plan.start[l] * M * 32, sizeof(float) * (size_t)S * M * 32,
+                                        0, sizeof(float) * (size_t)plan.H[l] * plan.W[l] * M * 32, B, stream);
+        if (e != hipSuccess) return (int)e;
+      }
+      const int bm_groups = (B * M + 7) / 8;
+      msda::bwd_scatter_kernel<<<8 * plan.n_items * bm_groups, 256, 0, stream>>>(
+          rec_hw, rec_aw, grad_out, grad_value, plan, B, S, M, Lq, P);
+      msda::bwd_gather_kernel<4, 4><<<grid_for(n_pairs, 32), 256, 0, stream>>>(
+          value, shapes, lsi, loc, attw, grad_out, grad_loc, grad_attw, S, M, Lq, n_pairs);
+      return (int)hipGetLastError();
+    }
+  }
   hipError_t err = hipMemsetAsync(grad_value, 0, sizeof(T) * (size_t)B * S * M * D, stream);
   if (err != hipSuccess) return (int)err;
   msda::bwd_generic_kernel<T><<<grid_for(n_pairs, 8), 256, 0, stream>>>(
@@ -72,11 +164,16 @@ const char *msda_strerror(int code) {
     case MSDA_E_NULLPTR: return "msda: a required pointer is NULL";
     case MSDA_E_SHAPE: return "msda: a dimension is <= 0 or exceeds the indexing range";
     case MSDA_E_UNSUPPORTED: return "msda: unsupported configuration";
+    case MSDA_E_WORKSPACE: return "msda: workspace is NULL or smaller than msda_backward_workspace_bytes()";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "msda: unknown error";
   }
 }
 
-size_t msda_backward_workspace_bytes(int, int, int, int, int, int, int, int) { return 0; }
+size_t msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int Lq, int P, int elem_bytes) {
+  (void)S;
+  if (B <= 0 || M <= 0 || L <= 0 || Lq <= 0 || P <= 0) return 0;
+  return tiled_backward_applies(elem_bytes, D, L, P) ? tiled_workspace_bytes(B, M, L, Lq, P) : 0;
+}
 
 int msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
                      const float *loc, const float *attn_w, float *out, int B, int S, int M, int D,
@@ -93,18 +190,22 @@ int msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *
 int msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
                       const float *loc, const float *attn_w, const float *grad_out, float *grad_value,
                       float *grad_loc, float *grad_attn_w, int B, int S, int M, int D, int L, int Lq,
-                      int P, void *workspace, size_t workspace_bytes, void *stream) {
+                      int P, const int64_t *shapes_host, const int64_t *level_start_host, void *workspace,
+                      size_t workspace_bytes, void *stream) {
   return backward_impl<float>(value, shapes, level_start, loc, attn_w, grad_out, grad_value, grad_loc,
-                              grad_attn_w, B, S, M, D, L, Lq, P, workspace, workspace_bytes, stream);
+                              grad_attn_w, B, S, M, D, L, Lq, P, shapes_host, level_start_host, workspace,
+                              workspace_bytes, stream);
 }
 
 int msda_backward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,
                       const double *loc, const double *attn_w, const double *grad_out,
                       double *grad_value, double *grad_loc, double *grad_attn_w, int B, int S, int M,
-                      int D, int L, int Lq, int P, void *workspace, size_t workspace_bytes,
+                      int D, int L, int Lq, int P, const int64_t *shapes_host,
+                      const int64_t *level_start_host, void *workspace, size_t workspace_bytes,
                       void *stream) {
   return backward_impl<double>(value, shapes, level_start, loc, attn_w, grad_out, grad_value, grad_loc,
-                               grad_attn_w, B, S, M, D, L, Lq, P, workspace, workspace_bytes, stream);
+                               grad_attn_w, B, S, M, D, L, Lq, P, shapes_host, level_start_host, workspace,
+                               workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -66,3 +66,49 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
 }  // namespace msda
+
+namespace msda {
+
+// Tap from already-scaled image coordinates of a point known to pass the cuh:274 test.
+__device__ __forceinline__ Tap<float> make_tap_im(float h_im, float w_im, int H, int W) {
+  Tap<float> tp;
+  tp.valid = true;
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  const int h_low = (int)hf, w_low = (int)wf;
+  tp.lh = h_im - hf;
+  tp.lw = w_im - wf;
+  tp.hh = 1.f - tp.lh;
+  tp.hw = 1.f - tp.lw;
+  tp.t = (h_low >= 0);
+  tp.b = (h_low + 1 <= H - 1);
+  tp.l = (w_low >= 0);
+  tp.r = (w_low + 1 <= W - 1);
+  tp.w1 = (tp.t && tp.l) ? tp.hh * tp.hw : 0.f;
+  tp.w2 = (tp.t && tp.r) ? tp.hh * tp.lw : 0.f;
+  tp.w3 = (tp.b && tp.l) ? tp.lh * tp.hw : 0.f;
+  tp.w4 = (tp.b && tp.r) ? tp.lh * tp.lw : 0.f;
+  tp.y0 = max(h_low, 0);
+  tp.y1 = min(h_low + 1, H - 1);
+  tp.x0 = max(w_low, 0);
+  tp.x1 = min(w_low + 1, W - 1);
+  return tp;
+}
+
+// ---- host/device shared plan of the tile-owner backward (passed to the kernel by value) -------
+// Work items are never materialised: item -> (level, tile, query chunk) is derived on the device
+// from per-level tilings, so any image size fits the kernel argument.
+constexpr int kMaxLevels = 8;
+constexpr int kTileRows = 512;        // LDS accumulator rows (x 128 B) per workgroup
+
+struct BwdPlan {
+  int n_items;                 // sum over levels of n_ty * n_tx * n_chunks
+  int n_levels;
+  int H[kMaxLevels], W[kMaxLevels], start[kMaxLevels];
+  int th[kMaxLevels], tw[kMaxLevels];        // nominal tile extent (th * tw <= kTileRows)
+  int n_ty[kMaxLevels], n_tx[kMaxLevels];
+  int n_chunks[kMaxLevels];                  // workgroups sharing one tile (split by query range)
+  int order[kMaxLevels];                     // levels sorted by work per item, heaviest first
+  int first_item[kMaxLevels + 1];            // prefix over `order`
+};
+
+}  // namespace msda

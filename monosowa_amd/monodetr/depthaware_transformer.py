@@ -17,6 +17,7 @@ from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from .misc import inverse_sigmoid
+from .. import MultiScaleDeformableAttention as _MSDA
 from ..ms_deform_attn import MSDeformAttn
 
 
@@ -274,6 +275,11 @@ class DepthAwareTransformer(nn.Module):
         pos_flat = torch.cat(pos_flat, 1)
         spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src_flat.device)
         level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        if spatial_shapes.is_cuda:    # the HIP backward plans its launch from the pyramid: hand it the host copy
+            starts = [0]
+            for h, w in shapes[:-1]:
+                starts.append(starts[-1] + h * w)
+            _MSDA.attach_host_geometry(spatial_shapes, level_start_index, shapes, starts)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
 
         memory = self.encoder(src_flat, spatial_shapes, level_start_index, valid_ratios, pos_flat, mask_flat,

@@ -16,6 +16,9 @@ class MSDeformAttnFunction(Function):
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
                 attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
+        # host copy of the pyramid for the backward's launch plan (attached by the transformer that
+        # built the tensors; otherwise one tiny device->host read here, not in backward)
+        ctx.host_geom = MSDA.host_geometry(value_spatial_shapes, value_level_start_index) if value.is_cuda else None
         output = MSDA.ms_deform_attn_forward(
             value, value_spatial_shapes, value_level_start_index, sampling_locations,
             attention_weights, ctx.im2col_step)
@@ -28,5 +31,5 @@ class MSDeformAttnFunction(Function):
     def backward(ctx, grad_output):
         value, shapes, lsi, loc, attw = ctx.saved_tensors
         grad_value, grad_loc, grad_attw = MSDA.ms_deform_attn_backward(
-            value, shapes, lsi, loc, attw, grad_output.contiguous(), ctx.im2col_step)
+            value, shapes, lsi, loc, attw, grad_output.contiguous(), ctx.im2col_step, host_geom=ctx.host_geom)
         return grad_value, None, None, grad_loc, grad_attw, None

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.load().msda_abi_version() == 1
+    assert _lib.load().msda_abi_version() == _lib.ABI_VERSION
     assert b"NULL" in _lib.load().msda_strerror(-1)
 
 
