@@ -9,11 +9,11 @@
 //                           lists {h_im, w_im} / {attn_w} (12 B per point, coalesced for the
 //                           scans below); points failing the cuh:274 test get a sentinel.
 //   K2 bwd_scatter_kernel   "tile owner": one workgroup owns a tile of one level of one
-//                           (batch, head) -- 512 value rows x 128 B of LDS accumulators.  It scans
-//                           the level's record list, queues the points with a corner inside its
-//                           tile, and adds w_corner * attn_w * grad_out[b,q,m,:] into LDS with
-//                           ds_add_f32 (8 lanes x 4 channels per point, channel order rotated per
-//                           lane group so the 32 lanes of an LDS pass hit 32 different banks).
+//                           (batch, head) -- 256 value rows x 32 double accumulators in LDS.  It
+//                           scans the level's record list, queues the points with a corner inside
+//                           its tile, and adds w_corner * attn_w * grad_out[b,q,m,:] into LDS with
+//                           ds_add_f64 (8 lanes x 4 channels per point, channel order rotated per
+//                           lane group to spread the LDS banks).
 //                           Tiles owned by a single workgroup are written back with plain stores
 //                           (no zero-fill, no atomics); coarse levels, whose few rows receive a
 //                           quarter of all points each, are split over several workgroups by
@@ -52,18 +52,24 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(
 }
 
 // ------------------------------------------------------------------------------------------ K2
+// LDS float atomics (ds_add_f32) are serialised per lane on gfx950 (0.33 lane-adds/clk/CU measured,
+// tools/ubench/lds_atomic*.hip) while ds_add_f64 runs at 3.9 and ds_add_u32 at 11-13: the tile is
+// accumulated in double, which is also more accurate than the reference's float atomics.
 constexpr int kQueue = 128;              // hit queue slots per wave (ring)
+constexpr int kScatterThreads = 512;
+constexpr int kScatterWaves = kScatterThreads / 64;
+constexpr int kDrainBatches = 4;         // 8-hit batches whose grad_out rows are fetched together
 
 __device__ __forceinline__ float pick(const float4 &v, int i) {
   return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
-__global__ __launch_bounds__(256, 2) void bwd_scatter_kernel(
+__global__ __launch_bounds__(kScatterThreads, 4) void bwd_scatter_kernel(
     const float2 *__restrict__ rec_hw, const float *__restrict__ rec_aw,
     const float *__restrict__ grad_out, float *__restrict__ grad_value, const BwdPlan plan, int B, int S,
     int M, int Lq, int P) {
-  __shared__ float acc[kTileRows * 32];
-  __shared__ float4 queue[4][kQueue];
+  __shared__ double acc[kTileRows * 32];                 // 64 KB
+  __shared__ float4 queue[kScatterWaves][kQueue];        // 16 KB
 
   // blockIdx -> (batch*head, item); all items of one (batch, head) share blockIdx % 8, i.e. one XCD
   // (speed only: they re-scan the same record lists out of that XCD's L2).
@@ -87,45 +93,52 @@ __global__ __launch_bounds__(256, 2) void bwd_scatter_kernel(
   const int pt_begin = (int)(n_pts * chunk / n_chunks), pt_end = (int)(n_pts * (chunk + 1) / n_chunks);
   const bool exclusive = n_chunks == 1;
 
-  for (int i = threadIdx.x; i < n_rows * 32; i += 256) acc[i] = 0.f;
+  for (int i = threadIdx.x; i < n_rows * 32; i += kScatterThreads) acc[i] = 0.0;
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane >> 3, sub = lane & 7;
-  const long long list = ((long long)bm * plan.n_levels + l) * (long long)Lq * P;   // this level's record list
+  const long long list = ((long long)bm * plan.n_levels + l) * n_pts;        // this level's record list
   const float2 *hw_list = rec_hw + list;
   const float *aw_list = rec_aw + list;
   const float *go_base = grad_out + ((long long)b * Lq * M + m) * 32 + sub * 4;     // + q * M*32
   float4 *myq = queue[wave];
   int qhead = 0, qtail = 0;
+  // rotate the channel order by the group index: in an LDS pass the groups of a 32-lane half then
+  // touch different banks of every 4-bank quad
+  const int r0 = grp & 3;
+  const int c0 = sub * 4 + r0, c1 = sub * 4 + ((r0 + 1) & 3), c2 = sub * 4 + ((r0 + 2) & 3),
+            c3 = sub * 4 + ((r0 + 3) & 3);
 
-  // Adds the queued hits [qhead, min(qhead+8, qtail)) into the LDS tile, one hit per 8-lane group.
-  auto drain8 = [&]() {
-    const bool active = (qhead + grp) < qtail;
-    const float4 rec = myq[(qhead + grp) & (kQueue - 1)];
-    qhead += 8;
-    if (active) {
-      const Tap<float> tp = make_tap_im(rec.x, rec.y, H, W);
-      const int idx = __float_as_int(rec.w);
-      const int q = idx / P;
-      const float4 g = ld4(go_base + (long long)q * M * 32);
-      const float aw = rec.z;
-      // rotate the channel order by the group index: in an LDS pass the 4 groups of a 32-lane
-      // half then touch 4 different banks of every 4-bank quad
-      const int r0 = grp & 3;
-      const float t0 = pick(g, r0) * aw, t1 = pick(g, (r0 + 1) & 3) * aw;
-      const float t2 = pick(g, (r0 + 2) & 3) * aw, t3 = pick(g, (r0 + 3) & 3) * aw;
-      const int c0 = sub * 4 + r0, c1 = sub * 4 + ((r0 + 1) & 3), c2 = sub * 4 + ((r0 + 2) & 3),
-                c3 = sub * 4 + ((r0 + 3) & 3);
+  // Adds up to NB x 8 queued hits into the LDS tile, one hit per 8-lane group and batch; the
+  // grad_out rows of all batches are requested before the first is consumed.
+  auto drain = [&](const int nb) {
+    float4 rec[kDrainBatches], g[kDrainBatches];
+    bool active[kDrainBatches];
+#pragma unroll
+    for (int k = 0; k < kDrainBatches; ++k) {
+      active[k] = (k < nb) && (qhead + 8 * k + grp) < qtail;
+      rec[k] = myq[(qhead + 8 * k + grp) & (kQueue - 1)];
+      const int q = __float_as_int(rec[k].w) / P;
+      g[k] = active[k] ? ld4(go_base + (long long)q * M * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    qhead += 8 * nb;
+#pragma unroll
+    for (int k = 0; k < kDrainBatches; ++k) {
+      if (!active[k]) continue;
+      const Tap<float> tp = make_tap_im(rec[k].x, rec[k].y, H, W);
+      const float aw = rec[k].z;
+      const float t0 = pick(g[k], r0) * aw, t1 = pick(g[k], (r0 + 1) & 3) * aw;
+      const float t2 = pick(g[k], (r0 + 2) & 3) * aw, t3 = pick(g[k], (r0 + 3) & 3) * aw;
       const int ry0 = tp.y0 - y0, ry1 = tp.y1 - y0, rx0 = tp.x0 - x0, rx1 = tp.x1 - x0;
       const bool iy0 = tp.t && (unsigned)ry0 < (unsigned)th, iy1 = tp.b && (unsigned)ry1 < (unsigned)th;
       const bool ix0 = tp.l && (unsigned)rx0 < (unsigned)tw, ix1 = tp.r && (unsigned)rx1 < (unsigned)tw;
       auto add_row = [&](int ry, int rx, float w) {
-        float *row = acc + (ry * tw + rx) * 32;
-        atomicAdd(row + c0, w * t0);
-        atomicAdd(row + c1, w * t1);
-        atomicAdd(row + c2, w * t2);
-        atomicAdd(row + c3, w * t3);
+        double *row = acc + (ry * tw + rx) * 32;
+        atomicAdd(row + c0, (double)(w * t0));
+        atomicAdd(row + c1, (double)(w * t1));
+        atomicAdd(row + c2, (double)(w * t2));
+        atomicAdd(row + c3, (double)(w * t3));
       };
       if (iy0 && ix0) add_row(ry0, rx0, tp.w1);
       if (iy0 && ix1) add_row(ry0, rx1, tp.w2);
@@ -134,10 +147,15 @@ __global__ __launch_bounds__(256, 2) void bwd_scatter_kernel(
     }
   };
 
-  for (int base = pt_begin + wave * 64; base < pt_end; base += 4 * 64) {
+  const int step = kScatterWaves * 64;
+  int base = pt_begin + wave * 64;
+  float2 hw_next = make_float2(kInvalidCoord, kInvalidCoord);
+  if (base + lane < pt_end) hw_next = hw_list[base + lane];
+  for (; base < pt_end; base += step) {
     const int idx = base + lane;
-    float2 hw = make_float2(kInvalidCoord, kInvalidCoord);
-    if (idx < pt_end) hw = hw_list[idx];
+    const float2 hw = hw_next;
+    hw_next = make_float2(kInvalidCoord, kInvalidCoord);
+    if (idx + step < pt_end) hw_next = hw_list[idx + step];          // prefetch the next slice
     const int h_low = (int)floorf(hw.x), w_low = (int)floorf(hw.y);
     // a corner row/col counts if it lies inside the tile (tiles lie inside the level, so this also
     // implies the cuh:56-79 bounds checks)
@@ -151,23 +169,24 @@ __global__ __launch_bounds__(256, 2) void bwd_scatter_kernel(
     }
     __builtin_amdgcn_wave_barrier();      // queue writes above are read by other lanes of this wave below
     qtail += __popcll(mask);
-    while (qtail - qhead >= 8) drain8();
+    while (qtail - qhead >= 8 * kDrainBatches) drain(kDrainBatches);
   }
-  while (qhead < qtail) drain8();
+  while (qhead < qtail) drain(min(kDrainBatches, (qtail - qhead + 7) / 8));
   __syncthreads();
 
-  // write the tile back
+  // write the tile back (rounded to float once)
   const long long tok0 = (long long)b * S + plan.start[l];
   if (exclusive) {
-    for (int r = threadIdx.x >> 3; r < n_rows; r += 32) {
+    for (int r = threadIdx.x >> 3; r < n_rows; r += kScatterThreads / 8) {
       const int ry = r / tw, rx = r - ry * tw;
       float *dst = grad_value + ((tok0 + (long long)(y0 + ry) * W + (x0 + rx)) * M + m) * 32 + sub * 4;
-      st4(dst, *reinterpret_cast<const float4 *>(acc + r * 32 + sub * 4));
+      const double *a = acc + r * 32 + sub * 4;
+      st4(dst, make_float4((float)a[0], (float)a[1], (float)a[2], (float)a[3]));
     }
   } else {
     const int ch = threadIdx.x & 31;
-    for (int r = threadIdx.x >> 5; r < n_rows; r += 8) {
-      const float v = acc[r * 32 + ch];
+    for (int r = threadIdx.x >> 5; r < n_rows; r += kScatterThreads / 32) {
+      const float v = (float)acc[r * 32 + ch];
       const int ry = r / tw, rx = r - ry * tw;
       if (v != 0.f)
         atomicAdd(grad_value + ((tok0 + (long long)(y0 + ry) * W + (x0 + rx)) * M + m) * 32 + ch, v);

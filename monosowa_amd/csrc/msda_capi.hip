@@ -69,8 +69,8 @@ msda::BwdPlan make_plan(const int64_t *shapes_host, const int64_t *lsi_host, int
     if ((long long)H * W <= msda::kTileRows) {
       plan.th[l] = H; plan.tw[l] = W; plan.n_ty[l] = 1; plan.n_tx[l] = 1;
     } else {
-      // balanced tiles of at most 16 x 32 (or 512 / W rows when the level is narrow)
-      const int max_tw = std::min(W, 32), max_th = std::max(1, std::min(H, msda::kTileRows / max_tw));
+      // balanced tiles of at most 16 x 16 (or kTileRows / W rows when the level is narrow)
+      const int max_tw = std::min(W, 16), max_th = std::max(1, std::min(H, msda::kTileRows / max_tw));
       plan.n_tx[l] = (W + max_tw - 1) / max_tw;
       plan.tw[l] = (W + plan.n_tx[l] - 1) / plan.n_tx[l];
       plan.n_ty[l] = (H + max_th - 1) / max_th;
@@ -137,7 +137,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         if (e != hipSuccess) return (int)e;
       }
       const int bm_groups = (B * M + 7) / 8;
-      msda::bwd_scatter_kernel<<<8 * plan.n_items * bm_groups, 256, 0, stream>>>(
+      msda::bwd_scatter_kernel<<<8 * plan.n_items * bm_groups, msda::kScatterThreads, 0, stream>>>(
           rec_hw, rec_aw, grad_out, grad_value, plan, B, S, M, Lq, P);
       msda::bwd_gather_kernel<4, 4><<<grid_for(n_pairs, 32), 256, 0, stream>>>(
           value, shapes, lsi, loc, attw, grad_out, grad_loc, grad_attw, S, M, Lq, n_pairs);

@@ -98,7 +98,7 @@ __device__ __forceinline__ Tap<float> make_tap_im(float h_im, float w_im, int H,
 // Work items are never materialised: item -> (level, tile, query chunk) is derived on the device
 // from per-level tilings, so any image size fits the kernel argument.
 constexpr int kMaxLevels = 8;
-constexpr int kTileRows = 512;        // LDS accumulator rows (x 128 B) per workgroup
+constexpr int kTileRows = 256;        // LDS accumulator rows (x 32 doubles = 256 B) per workgroup
 
 struct BwdPlan {
   int n_items;                 // sum over levels of n_ty * n_tx * n_chunks
