@@ -1,0 +1,233 @@
+"""Host-side helpers: the AdamW variant (bit-for-bit against a literal per-parameter restatement of
+lib/helpers/optimizer_helper.py:69-129), checkpoint dictionary, LR schedule, detection bookkeeping
+(decode_helper.py:58-111 -- top-k / // / % / gather must be exact), KITTI result writer, synthetic data
+contract, the end-to-end CPU plumbing step (BASELINE configs[0], reduced resolution)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg():
+    return yaml.safe_load(open(os.path.join(ROOT, "configs", "monodetr.yaml")))
+
+
+def _reference_adamw_step(params, grads, state, lr, wd, step, betas=(0.9, 0.999), eps=1e-8):
+    """Literal per-parameter loop of the reference update."""
+    b1, b2 = betas
+    for p, g, st in zip(params, grads, state):
+        st["m"].mul_(b1).add_(g, alpha=1 - b1)
+        st["v"].mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = st["v"].sqrt().add_(eps)
+        step_size = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        p.add_(torch.mul(p, wd).addcdiv_(st["m"], denom, value=1), alpha=-step_size)
+
+
+def test_adamw_matches_reference_update_bitwise():
+    from monosowa_amd.helpers.optimizer_helper import AdamW
+    torch.manual_seed(0)
+    shapes = [(7, 5), (5,), (3, 4, 2), (1,)]
+    ps = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    ref = [p.detach().clone() for p in ps]
+    st = [{"m": torch.zeros_like(p), "v": torch.zeros_like(p)} for p in ref]
+    opt = AdamW([{"params": ps[:2], "weight_decay": 0}, {"params": ps[2:], "weight_decay": 1e-4}], lr=2e-4)
+    for step in range(1, 6):
+        gs = [torch.randn_like(p) for p in ps]
+        for p, g in zip(ps, gs):
+            p.grad = g.clone()
+        opt.step()
+        _reference_adamw_step(ref[:2], gs[:2], st[:2], 2e-4, 0, step)
+        _reference_adamw_step(ref[2:], gs[2:], st[2:], 2e-4, 1e-4, step)
+        for p, r in zip(ps, ref):
+            assert torch.equal(p.detach(), r)
+    sd = opt.state_dict()["state"][0]
+    assert set(sd.keys()) == {"step", "exp_avg", "exp_avg_sq"}          # reference state keys
+
+
+def test_build_optimizer_groups_biases_without_decay():
+    from monosowa_amd.helpers.optimizer_helper import build_optimizer
+    m = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.LayerNorm(4))
+    opt = build_optimizer({"type": "adamw", "lr": 1e-3, "weight_decay": 0.1}, m)
+    assert opt.param_groups[0]["weight_decay"] == 0 and len(opt.param_groups[0]["params"]) == 2
+    assert opt.param_groups[1]["weight_decay"] == 0.1 and len(opt.param_groups[1]["params"]) == 2
+    with pytest.raises(NotImplementedError):
+        build_optimizer({"type": "lion", "lr": 1e-3, "weight_decay": 0.1}, m)
+
+
+def test_lr_schedule_and_checkpoint_roundtrip(tmp_path):
+    from monosowa_amd.helpers.optimizer_helper import build_optimizer
+    from monosowa_amd.helpers.save_helper import get_checkpoint_state, load_checkpoint, save_checkpoint
+    from monosowa_amd.helpers.scheduler_helper import build_lr_scheduler
+    m = torch.nn.Linear(3, 2)
+    opt = build_optimizer({"type": "adamw", "lr": 2e-4, "weight_decay": 1e-4}, m)
+    sched, warm = build_lr_scheduler({"warmup": False, "decay_rate": 0.1, "decay_list": [2, 4]}, opt, last_epoch=-1)
+    assert warm is None
+    lrs = []
+    for _ in range(5):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sched.step()
+    assert np.allclose(lrs, [2e-4, 2e-4, 2e-5, 2e-5, 2e-6])
+    _, warm = build_lr_scheduler({"warmup": True, "decay_rate": 0.1, "decay_list": [2]}, opt, last_epoch=-1)
+    assert warm is not None
+    m(torch.randn(1, 3)).sum().backward()
+    opt.step()
+    state = get_checkpoint_state(m, opt, epoch=3, best_result=1.5, best_epoch=2)
+    assert set(state) == {"epoch", "model_state", "optimizer_state", "best_result", "best_epoch"}
+    save_checkpoint(state, str(tmp_path / "checkpoint_epoch_3"))
+    m2 = torch.nn.Linear(3, 2)
+    opt2 = build_optimizer({"type": "adamw", "lr": 2e-4, "weight_decay": 1e-4}, m2)
+    ep, best, best_ep = load_checkpoint(m2, opt2, str(tmp_path / "checkpoint_epoch_3.pth"), "cpu")
+    assert (ep, best, best_ep) == (3, 1.5, 2)
+    assert torch.equal(m2.weight, m.weight)
+    with pytest.raises(FileNotFoundError):
+        load_checkpoint(m2, None, str(tmp_path / "nope.pth"), "cpu")
+
+
+def test_extract_dets_bookkeeping_is_exact():
+    from monosowa_amd.helpers.decode_helper import extract_dets_from_outputs
+    torch.manual_seed(1)
+    B, Q, C = 3, 50, 3
+    out = {"pred_logits": torch.randn(B, Q, C), "pred_boxes": torch.rand(B, Q, 6) * 0.2 + 0.3,
+           "pred_angle": torch.randn(B, Q, 24), "pred_3d_dim": torch.randn(B, Q, 3), "pred_depth": torch.randn(B, Q, 2)}
+    dets = extract_dets_from_outputs(out, K=50, topk=50)
+    assert dets.shape == (B, 50, 37)
+    prob = out["pred_logits"].sigmoid().numpy().reshape(B, -1)
+    for b in range(B):
+        order = np.argsort(-prob[b], kind="stable")[:50]
+        assert np.array_equal(dets[b, :, 0].numpy().astype(np.int64), order % C)             # labels
+        assert np.array_equal(dets[b, :, 1].numpy(), prob[b][order])                         # scores, exact
+        qi = order // C
+        assert np.array_equal(dets[b, :, 6].numpy(), out["pred_depth"][b, qi, 0].numpy())    # gathered depth
+        assert np.array_equal(dets[b, :, 7:31].numpy(), out["pred_angle"][b, qi].numpy())
+        assert np.array_equal(dets[b, :, 34].numpy(), out["pred_boxes"][b, qi, 0].numpy())   # x3d
+        assert np.allclose(dets[b, :, 36].numpy(), np.exp(-out["pred_depth"][b, qi, 1].numpy()))
+
+
+def test_decode_and_kitti_writer(tmp_path):
+    from monosowa_amd.helpers.decode_helper import PinholeCalib, class2angle, decode_detections, get_heading_angle
+    assert class2angle(0, 0.1) == pytest.approx(0.1)
+    assert class2angle(11, 0.2, to_label_format=True) == pytest.approx(11 * math.pi / 6 + 0.2 - 2 * math.pi)
+    heading = np.zeros(24, np.float32)
+    heading[3] = 5.0
+    heading[15] = 0.25
+    assert get_heading_angle(heading) == pytest.approx(3 * math.pi / 6 + 0.25)
+    P2 = np.array([[700., 0, 600., 40.], [0, 700., 180., 2.], [0, 0, 1, 0.003]])
+    cal = PinholeCalib(P2)
+    xyz = cal.img_to_rect(np.array([650.]), np.array([200.]), np.array([10.]))
+    assert np.allclose(xyz, [[(650 - 600) * 10 / 700 + 40 / -700, (200 - 180) * 10 / 700 + 2 / -700, 10.]])
+    dets = np.zeros((1, 2, 37), np.float32)
+    dets[0, 0, :7] = [1, 0.9, 0.5, 0.5, 0.1, 0.2, 20.0]
+    dets[0, 0, 31:34] = [1.5, 1.6, 3.9]
+    dets[0, 0, 34:37] = [0.5, 0.5, 0.8]
+    dets[0, 1, 1] = 0.1                                   # below threshold
+    info = {"img_size": np.array([[1242, 375]]), "height_crop": np.array([1.0]), "canonical_scale": np.array([0.5]),
+            "img_id": np.array([7])}
+    res = decode_detections(dets, info, [cal], np.zeros((3, 3), np.float32), threshold=0.2)
+    assert list(res) == [7] and len(res[7]) == 1
+    p = res[7][0]
+    assert p[0] == 1 and p[-1] == pytest.approx(0.9 * 0.8) and len(p) == 14
+    assert p[2:6] == pytest.approx([0.5 * 1242 - 62.1, 0.5 * 375 - 37.5, 0.5 * 1242 + 62.1, 0.5 * 375 + 37.5], rel=1e-5)
+    assert p[11] == pytest.approx(40.0)                   # depth leaves Canonical Object Space: 20 / 0.5
+
+    from monosowa_amd.helpers.tester_helper import Tester
+
+    class _DS:
+        max_objs, class_name, cls_mean_size = 50, ["Pedestrian", "Car", "Cyclist"], np.zeros((3, 3))
+
+    class _DL:
+        dataset = _DS()
+
+    import logging
+    t = Tester({"type": "KITTI", "topk": 50}, None, _DL(), logging.getLogger("t"), {"save_path": str(tmp_path) + "/"}, "m")
+    t.output_dir = str(tmp_path)
+    t.save_results(res)
+    line = open(tmp_path / "outputs" / "data" / "000007.txt").read().strip().split(" ")
+    assert line[0] == "Car" and line[1:3] == ["0.0", "0"] and len(line) == 16 and line[-1] == "0.72"
+    assert all(len(x.split(".")[1]) == 2 for x in line[3:])                         # '{:.2f}' everywhere
+
+
+def test_synthetic_batch_contract():
+    from monosowa_amd.synthetic import SyntheticKITTI, make_batch, prepare_targets
+    inputs, calibs, targets, info = make_batch(3, "cpu", seed=1, resolution=(320, 96))
+    assert inputs.shape == (3, 3, 96, 320) and inputs.dtype == torch.float32 and calibs.shape == (3, 3, 4)
+    assert set(targets) == {"calibs", "indices", "img_size", "labels", "boxes", "boxes_3d", "depth", "size_2d", "size_3d",
+                            "src_size_3d", "heading_bin", "heading_res", "mask_2d"}
+    assert targets["labels"].dtype == torch.int8 and targets["heading_bin"].dtype == torch.int64
+    assert targets["mask_2d"].dtype == torch.bool and targets["boxes_3d"].shape == (3, 50, 6)
+    tl = prepare_targets(targets, 3)
+    for b, t in enumerate(tl):
+        n = int(targets["mask_2d"][b].sum())
+        assert 1 <= n <= 10 and t["boxes_3d"].shape == (n, 6) and t["calibs"].shape == (n, 3, 4)
+        x0 = t["boxes_3d"][:, 0] - t["boxes_3d"][:, 2]
+        assert torch.allclose(t["boxes"][:, 0] - t["boxes"][:, 2] / 2, x0, atol=1e-6)
+    ds = SyntheticKITTI("train", {"resolution": (320, 96), "num_samples": 4})
+    a, b = ds[1], ds[1]
+    assert len(ds) == 4 and np.array_equal(a[0], b[0]) and a[3]["img_id"] == 1
+
+
+def test_cpu_plumbing_train_and_eval_step(monkeypatch):
+    """BASELINE configs[0] (CPU-only path, random images) at reduced resolution: dict keys / shapes /
+    finite loss, one optimizer step, then eval mode with 50 queries.  MSDA goes through the oracle port
+    (tests only)."""
+    import monosowa_amd.ms_deform_attn_func as F
+    from oracle import msda_oracle as O
+    from monosowa_amd.helpers.model_helper import build_model
+    from monosowa_amd.helpers.optimizer_helper import build_optimizer
+    from monosowa_amd.helpers.decode_helper import extract_dets_from_outputs
+    from monosowa_amd.synthetic import make_batch, prepare_targets
+
+    class _Fn:
+        @staticmethod
+        def apply(value, shapes, lsi, loc, w, step):
+            return O.msda_core_torch(value, shapes, loc, w)
+    monkeypatch.setattr(F, "MSDeformAttnFunction", _Fn)
+    cfg = _cfg()
+    torch.manual_seed(cfg["random_seed"])
+    mcfg = dict(cfg["model"], device="cpu", depth_map_size=(20, 6))
+    model, crit = build_model(mcfg)
+    opt = build_optimizer(cfg["optimizer"], model)
+    inputs, calibs, targets, info = make_batch(2, "cpu", resolution=(320, 96))
+    tl = prepare_targets(targets, 2)
+    model.train()
+    crit.train()
+    out = model(inputs, calibs, tl, targets["img_size"])
+    assert out["pred_logits"].shape == (2, 550, 3) and out["pred_boxes"].shape == (2, 550, 6)
+    assert out["pred_3d_dim"].shape == (2, 550, 3) and out["pred_depth"].shape == (2, 550, 2)
+    assert out["pred_angle"].shape == (2, 550, 24) and out["pred_depth_map_logits"].shape == (2, 81, 6, 20)
+    assert len(out["aux_outputs"]) == 2
+    losses = crit(out, tl)
+    wd = crit.weight_dict
+    expected = {"loss_ce", "loss_bbox", "loss_giou", "loss_center", "loss_depth", "loss_dim", "loss_angle", "loss_depth_map",
+                "loss_tfl", "loss_mask"}
+    assert expected <= set(losses) and {k + "_0" for k in expected - {"loss_depth_map"}} <= set(losses)
+    total = sum(losses[k] * wd[k] for k in losses if k in wd)
+    assert torch.isfinite(total)
+    before = model.class_embed[0].weight.detach().clone()
+    total.backward()
+    opt.step()
+    assert not torch.equal(before, model.class_embed[0].weight)
+    no_grad = sorted(n for n, p in model.named_parameters() if p.requires_grad and p.grad is None)
+    assert no_grad == sorted(model.unused_parameter_names())
+    model.eval()
+    crit.eval()
+    with torch.no_grad():
+        out = model(inputs, calibs, None, targets["img_size"])
+    assert out["pred_logits"].shape == (2, 50, 3)
+    assert extract_dets_from_outputs(out, K=50, topk=50).shape == (2, 50, 37)
+    assert len(crit(out, tl)) > 0
+
+
+def test_unshipped_switches_fail_loudly():
+    from monosowa_amd.helpers.model_helper import build_model
+    cfg = _cfg()["model"]
+    for key in ("two_stage", "use_dab", "two_stage_dino", "use_dn", "use_tfl", "pretrained"):
+        bad = dict(cfg, device="cpu")
+        bad[key] = True
+        with pytest.raises((NotImplementedError, RuntimeError)):
+            build_model(bad)
