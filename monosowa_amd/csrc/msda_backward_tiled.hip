@@ -214,8 +214,9 @@ __global__ __launch_bounds__(256, 4) void bwd_gather_kernel(
   const int grp = lane & ~7;
   const bool odd = sub & 1;
   const int tok = M * 32;
-  const long long stride = (long long)gridDim.x * 32;
-  for (long long pair = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); pair < n_pairs; pair += stride) {
+  // exact grid (padded to a multiple of 8 workgroups), XCD x takes the x-th contiguous eighth of the pairs
+  const long long pair = xcd_chunked_block(gridDim.x) * 32 + (threadIdx.x >> 3);
+  if (pair < n_pairs) {
     const int m = (int)(pair % M);
     const int b = (int)(pair / ((long long)M * Lq));
     const float *vb = value + ((long long)b * S * M + m) * 32 + sub * 4;

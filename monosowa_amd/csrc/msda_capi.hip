@@ -19,10 +19,14 @@ inline int grid_for(long long work_items, int items_per_block) {
   return (int)g;
 }
 
+// exact grid for the 8-lanes-per-pair kernels: 32 pairs per workgroup, padded to a multiple of 8 workgroups
+inline int grid_pairs(long long n_pairs) { return (int)(((n_pairs + 31) / 32 + 7) / 8 * 8); }
+
 inline int check_dims(int B, int S, int M, int D, int L, int Lq, int P) {
   if (B <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0) return MSDA_E_SHAPE;
   // per-sample offsets are kept in 32 bits inside the d32 kernel
   if ((long long)S * M * D >= (1LL << 31)) return MSDA_E_SHAPE;
+  if ((long long)B * Lq * M >= (1LL << 35)) return MSDA_E_SHAPE;      // exact grids: (pairs / 32) workgroups
   return 0;
 }
 
@@ -36,7 +40,7 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
   const long long n_pairs = (long long)B * Lq * M;
   if constexpr (sizeof(T) == 4) {
     if (D == 32 && L == 4 && P == 4) {
-      msda::fwd_d32_kernel<4, 4><<<grid_for(n_pairs, 32), 256, 0, stream>>>(
+      msda::fwd_d32_kernel<4, 4><<<grid_pairs(n_pairs), 256, 0, stream>>>(
           value, shapes, lsi, loc, attw, out, S, M, Lq, n_pairs);
       return (int)hipGetLastError();
     }
@@ -139,7 +143,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       const int bm_groups = (B * M + 7) / 8;
       msda::bwd_scatter_kernel<<<8 * plan.n_items * bm_groups, msda::kScatterThreads, 0, stream>>>(
           rec_hw, rec_aw, grad_out, grad_value, plan, B, S, M, Lq, P);
-      msda::bwd_gather_kernel<4, 4><<<grid_for(n_pairs, 32), 256, 0, stream>>>(
+      msda::bwd_gather_kernel<4, 4><<<grid_pairs(n_pairs), 256, 0, stream>>>(
           value, shapes, lsi, loc, attw, grad_out, grad_loc, grad_attw, S, M, Lq, n_pairs);
       return (int)hipGetLastError();
     }

@@ -62,6 +62,14 @@ __device__ __forceinline__ Tap<T> make_tap(T loc_x, T loc_y, int H, int W) {
   return tp;
 }
 
+// XCD-aware work mapping (speed only, never correctness): workgroups are dealt round-robin over the 8
+// XCDs, so workgroup b and b+8 share an L2.  Giving XCD x the x-th contiguous eighth of the work keeps
+// each L2's working set to the value rows around one stretch of queries instead of the whole tensor.
+__device__ __forceinline__ long long xcd_chunked_block(long long n_blocks_padded8) {
+  const long long per_xcd = n_blocks_padded8 >> 3;
+  return (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+}
+
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 

@@ -39,8 +39,9 @@ __global__ __launch_bounds__(256) void fwd_d32_kernel(
     st[l] = (int)lsi[l];
   }
   const int tok = M * 32;              // floats between consecutive tokens
-  const long long stride = (long long)gridDim.x * 32;
-  for (long long pair = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); pair < n_pairs; pair += stride) {
+  // exact grid (padded to a multiple of 8 workgroups), XCD x takes the x-th contiguous eighth of the pairs
+  const long long pair = xcd_chunked_block(gridDim.x) * 32 + (threadIdx.x >> 3);
+  if (pair < n_pairs) {
     const int m = (int)(pair % M);
     const int b = (int)(pair / ((long long)M * Lq));
     const float *vb = value + ((long long)b * S * M + m) * 32 + sub * 4;

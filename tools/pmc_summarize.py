@@ -1,0 +1,70 @@
+"""Turns the rocprofv3 --pmc CSVs of tools/collect_pmc.sh into per-launch HBM bytes for the MSDA kernels,
+corrected with the calibration kernels (known byte counts), and writes <dir>/msda_traffic.json."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+d = sys.argv[1]
+
+
+def counters(pattern):
+    out = defaultdict(list)
+    for f in glob.glob(os.path.join(d, pattern, "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            out[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), r))
+    return out
+
+
+calib = {}
+for C in ("FETCH_SIZE", "WRITE_SIZE"):
+    for (k, c), v in counters("calib_" + C).items():
+        calib[(k, c)] = sum(x[1] for x in v) / len(v)
+known = {"calib_stream_f4": {"FETCH_SIZE": (64 << 20) * 16 + (64 << 20) * 4, "WRITE_SIZE": (64 << 20) * 4},
+         "calib_rowgather": {"FETCH_SIZE": (2 << 20) * 128 + (2 << 20) * 4}}
+factor = {}
+for k, cs in known.items():
+    for c, nbytes in cs.items():
+        raw = calib.get((k, c))
+        if raw:
+            factor[(k, c)] = nbytes / (raw * 1024.0)     # counter unit: KiB
+print("calibration: true bytes / (counter * 1024):", {"%s/%s" % k: round(v, 3) for k, v in factor.items()})
+
+res = {"calibration": {"%s/%s" % k: v for k, v in factor.items()}, "unit": "bytes per launch", "kernels": {}}
+msda = {}
+for C in ("FETCH_SIZE", "WRITE_SIZE"):
+    for (k, c), v in counters("msda_" + C).items():
+        if "msda::" not in k:
+            continue
+        grids = defaultdict(list)
+        for _, val, r in v:
+            grids[(r["Grid_Size"], r.get("LDS_Block_Size", ""))].append(val)
+        for g, vals in grids.items():
+            msda.setdefault((k, g[0]), {})[c] = sum(vals) / len(vals) * 1024.0
+f_gather = factor.get(("calib_rowgather", "FETCH_SIZE"), 1.0)
+f_write = factor.get(("calib_stream_f4", "WRITE_SIZE"), 1.0)
+for (k, grid), cs in sorted(msda.items()):
+    fetch = cs.get("FETCH_SIZE", 0.0) * f_gather
+    write = cs.get("WRITE_SIZE", 0.0) * f_write
+    res["kernels"]["%s grid=%s" % (k, grid)] = {"fetch_bytes": fetch, "write_bytes": write, "hbm_bytes": fetch + write,
+                                                "raw_fetch_counter_bytes": cs.get("FETCH_SIZE", 0.0),
+                                                "raw_write_counter_bytes": cs.get("WRITE_SIZE", 0.0)}
+    print("%-70s fetch %8.1f MB  write %8.1f MB" % (k + " grid=" + grid, fetch / 1e6, write / 1e6))
+# op-level sums in the keys bench.py looks up: the micro-benchmark runs the encoder shape (larger grids)
+# and the decoder-train shape (smaller grids) at B=16
+by_kernel = defaultdict(list)
+for (k, grid), cs in msda.items():
+    by_kernel[k].append((int(grid), k, grid))
+ops = {"msda_fwd": ["fwd_d32_kernel"], "msda_bwd": ["bwd_prep_kernel", "bwd_scatter_kernel", "bwd_gather_kernel"]}
+for shape_i, tag in ((-1, "Lq10200_B16"), (0, "Lq550_B16")):
+    for op, names in ops.items():
+        tot = 0.0
+        for k, lst in by_kernel.items():
+            if any(n in k for n in names):
+                _, kk, grid = sorted(lst)[shape_i]
+                tot += res["kernels"]["%s grid=%s" % (kk, grid)]["hbm_bytes"]
+        res["%s_%s" % (op, tag)] = tot
+        print("%-28s %8.1f MB per launch (fetch x%.2f + write x%.2f corrected)" % (op + "_" + tag, tot / 1e6, f_gather, f_write))
+json.dump(res, open(os.path.join(d, "msda_traffic.json"), "w"), indent=1)
