@@ -12,7 +12,8 @@ d = sys.argv[1]
 
 def counters(pattern):
     out = defaultdict(list)
-    for f in glob.glob(os.path.join(d, pattern, "*", "*counter_collection.csv")):
+    files = sorted(glob.glob(os.path.join(d, pattern, "*", "*counter_collection.csv")), key=os.path.getmtime)
+    for f in files[-1:]:          # newest run only (gpurun merges successive runs into the same directory)
         for r in csv.DictReader(open(f)):
             out[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), r))
     return out
