@@ -38,9 +38,21 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def build_host_libs(force=False, verbose=False):
+    """Host-side native helpers (plain g++, no GPU code)."""
+    out = os.path.join(LIBDIR, "libmonosowa_lsap.so")
+    src = os.path.join(CSRC, "lsap.cpp")
+    if force or _stale(out, [src]):
+        cmd = [shutil.which("g++") or "g++", "-O3", "-fPIC", "-shared", "-std=c++17", "-Wall", "-o", out, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return [out]
+
+
 def build_all(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
-    built = []
+    built = build_host_libs(force, verbose)
     for name, (tu, deps) in LIBS.items():
         out = os.path.join(LIBDIR, name)
         src = os.path.join(CSRC, tu)

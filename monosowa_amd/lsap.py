@@ -1,0 +1,66 @@
+"""ctypes face of the native assignment solver (csrc/lsap.cpp)."""
+import ctypes
+import os
+
+import numpy as np
+
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_lsap.so")
+_lib = None
+
+
+def available():
+    return os.path.exists(_PATH)
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        lib = ctypes.CDLL(_PATH)
+        P, I = ctypes.c_void_p, ctypes.c_int64
+        lib.lsap_solve_f64.restype = I
+        lib.lsap_solve_f64.argtypes = [P, I, I, P, P]
+        lib.lsap_match_groups_f32.restype = I
+        lib.lsap_match_groups_f32.argtypes = [P, I, I, I, I, P, I, I, P, P, P]
+        assert lib.lsap_abi_version() == 1
+        _lib = lib
+    return _lib
+
+
+def linear_sum_assignment(cost):
+    """Same contract as scipy.optimize.linear_sum_assignment (minimisation)."""
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
+    nr, nc = cost.shape
+    k = min(nr, nc)
+    rows, cols = np.empty(k, np.int64), np.empty(k, np.int64)
+    got = _load().lsap_solve_f64(cost.ctypes.data, nr, nc, rows.ctypes.data, cols.ctypes.data)
+    if got < 0:
+        raise ValueError("cost matrix is infeasible")
+    return rows, cols
+
+
+def match_groups(cost, sizes, group_num, padded=False):
+    """cost [NL,B,Q,T] float32 (host) -> per layer, per image (src int64, tgt int64) numpy arrays.
+    padded=False: T = sum(sizes), image b's targets at columns [off_b, off_b + sizes[b]);
+    padded=True : T >= max(sizes), image b's targets at columns [0, sizes[b])."""
+    cost = np.ascontiguousarray(cost, dtype=np.float32)
+    NL, B, Q, T = cost.shape
+    sizes = np.ascontiguousarray(sizes, dtype=np.int64)
+    assert sizes.shape == (B,) and Q % group_num == 0
+    assert (int(sizes.max(initial=0)) <= T) if padded else (int(sizes.sum()) == T)
+    gq = Q // group_num
+    per_layer = int(sum(group_num * min(gq, int(n)) for n in sizes))
+    src, tgt = np.empty(NL * per_layer, np.int64), np.empty(NL * per_layer, np.int64)
+    count = np.empty(NL * B, np.int64)
+    got = _load().lsap_match_groups_f32(cost.ctypes.data, NL, B, Q, T, sizes.ctypes.data, group_num, int(padded),
+                                        src.ctypes.data, tgt.ctypes.data, count.ctypes.data)
+    if got < 0:
+        raise ValueError("cost matrix is infeasible")
+    out, pos = [], 0
+    for l in range(NL):
+        layer = []
+        for b in range(B):
+            c = int(count[l * B + b])
+            layer.append((src[pos:pos + c], tgt[pos:pos + c]))
+            pos += c
+        out.append(layer)
+    return out

@@ -12,6 +12,7 @@ placeholders here and raise if switched on.
 ``num_boxes`` is all-reduced over the data-parallel group (:1202-1206) so that N GPUs at
 per-GPU batch b compute the same loss as one GPU at batch N*b.
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -21,9 +22,21 @@ from .losses import DDNLoss, sigmoid_focal_loss
 from .misc import accuracy, get_world_size, is_dist_avail_and_initialized
 
 
+def _paired_giou(a, b):
+    """GIoU of matched xyxy boxes a[..., 4], b[..., 4] (the diagonal of box_ops.generalized_box_iou)."""
+    area_a = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1])
+    area_b = (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
+    wh = (torch.min(a[..., 2:], b[..., 2:]) - torch.max(a[..., :2], b[..., :2])).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    union = area_a + area_b - inter
+    wh_c = (torch.max(a[..., 2:], b[..., 2:]) - torch.min(a[..., :2], b[..., :2])).clamp(min=0)
+    area_c = wh_c[..., 0] * wh_c[..., 1]
+    return inter / union - (area_c - union) / area_c
+
+
 class SetCriterion(nn.Module):
     def __init__(self, num_classes, matcher, weight_dict, focal_alpha, losses, group_num=11, cfg=None,
-                 depth_map_size=(80, 24)):
+                 depth_map_size=(80, 24), fast=True):
         super().__init__()
         self.num_classes = num_classes
         self.matcher = matcher
@@ -34,6 +47,9 @@ class SetCriterion(nn.Module):
         self.group_num = group_num
         # width, height of the stride-16 depth map; the reference hard-codes [80, 24, 80, 24] (:528)
         self.depth_map_size = tuple(depth_map_size)
+        # fast=True: all decoder layers matched and scored together with flat indices (one device->host
+        # copy per step); fast=False: the layer-by-layer, image-by-image formulation of the reference.
+        self.fast = fast
         self.use_tfl = bool(cfg["use_tfl"]) if cfg is not None else False
         self.use_mask_loss = bool(cfg["use_mask_loss"]) if cfg is not None else False
         self.mask_loss = cfg["mask_loss"] if cfg is not None else "DICE"
@@ -152,6 +168,126 @@ class SetCriterion(nn.Module):
         return loss_map[loss](outputs, targets, indices, num_boxes, **kwargs)
 
     def forward(self, outputs, targets, mask_dict=None, info=None):
+        if self.fast:
+            return self.forward_fast(outputs, targets)
+        return self.forward_layerwise(outputs, targets, mask_dict, info)
+
+    # ------------------------------------------------------------------ batched formulation
+    def _num_boxes(self, targets, group_num, device):
+        n = float(sum(len(t["labels"]) for t in targets) * group_num)
+        if is_dist_avail_and_initialized():       # stays on the device: dividing by a tensor needs no sync
+            t = torch.as_tensor([n], dtype=torch.float, device=device)
+            torch.distributed.all_reduce(t)
+            return torch.clamp(t / get_world_size(), min=1)[0]
+        return max(n / get_world_size(), 1.0)
+
+    def forward_fast(self, outputs, targets):
+        """Same losses as ``forward_layerwise`` (same keys, same normalisation); the matching of all decoder
+        layers is one cost pass + one host copy + one native call, and every loss is evaluated for all layers
+        at once through flat (layer, batch, query) / target index tensors."""
+        layers = [{k: v for k, v in outputs.items() if k != "aux_outputs"}] + list(outputs.get("aux_outputs", []))
+        NL = len(layers)
+        group_num = self.group_num if self.training else 1
+        logits = torch.stack([o["pred_logits"] for o in layers])          # [NL,B,Q,C]
+        boxes = torch.stack([o["pred_boxes"] for o in layers])            # [NL,B,Q,6]
+        dims = torch.stack([o["pred_3d_dim"] for o in layers])
+        depth = torch.stack([o["pred_depth"] for o in layers])
+        angle = torch.stack([o["pred_angle"] for o in layers])
+        _, B, Q, C = logits.shape
+        dev = logits.device
+        sizes = [len(t["labels"]) for t in targets]
+        T = sum(sizes)
+        flat = {k: torch.cat([t[k] for t in targets], dim=0)
+                for k in ("labels", "boxes_3d", "boxes", "depth", "size_3d", "heading_bin", "heading_res")}
+        num_boxes = self._num_boxes(targets, group_num, dev)
+
+        matches = self.matcher.match_layers(logits, boxes, flat, sizes, group_num)
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        b_idx = np.stack([np.concatenate([np.full(len(s), b, np.int64) for b, (s, _) in enumerate(layer)]) for layer in matches])
+        q_idx = np.stack([np.concatenate([s for s, _ in layer]) for layer in matches])
+        t_idx = np.stack([np.concatenate([t + offs[b] for b, (_, t) in enumerate(layer)]) for layer in matches])
+        K = b_idx.shape[1]
+        idx = torch.as_tensor(np.stack([b_idx, q_idx, t_idx]), dtype=torch.int64).to(dev, non_blocking=True)   # [3,NL,K]
+        b_idx, q_idx, t_idx = idx[0], idx[1], idx[2]
+        l_idx = torch.arange(NL, device=dev).view(NL, 1).expand(NL, K)
+        take = lambda t: t[l_idx, b_idx, q_idx]                             # [NL,K,...] matched predictions
+        per_layer = {}
+
+        # labels (focal), class error, cardinality
+        tgt_cls = flat["labels"].long()[t_idx] if T else torch.zeros((NL, 0), dtype=torch.int64, device=dev)
+        target_classes = torch.full((NL, B, Q), self.num_classes, dtype=torch.int64, device=dev)
+        target_classes[l_idx, b_idx, q_idx] = tgt_cls
+        onehot = torch.zeros((NL, B, Q, C + 1), dtype=logits.dtype, device=dev).scatter_(3, target_classes.unsqueeze(-1), 1)[..., :-1]
+        prob = logits.sigmoid()
+        ce = F.binary_cross_entropy_with_logits(logits, onehot, reduction="none")
+        p_t = prob * onehot + (1 - prob) * (1 - onehot)
+        focal = ce * ((1 - p_t) ** 2)
+        if self.focal_alpha >= 0:
+            focal = (self.focal_alpha * onehot + (1 - self.focal_alpha) * (1 - onehot)) * focal
+        per_layer["loss_ce"] = focal.mean(2).sum((1, 2)) / num_boxes * Q
+        matched_logits = take(logits)
+        if K:
+            correct = matched_logits.argmax(-1).eq(tgt_cls).float().sum(1) * (100.0 / K)
+        else:
+            correct = torch.zeros(NL, device=dev)
+        per_layer["class_error"] = 100 - correct
+        tgt_lengths = torch.as_tensor(sizes, dtype=torch.float, device=dev)
+        card_pred = (logits.argmax(-1) != C - 1).sum(2).float()
+        per_layer["cardinality_error"] = (card_pred - tgt_lengths).abs().mean(1)
+
+        # boxes: 3D-centre L1, l/r/t/b L1, GIoU of matched pairs
+        src_box, tgt_box = take(boxes), flat["boxes_3d"][t_idx]
+        per_layer["loss_center"] = (src_box[..., 0:2] - tgt_box[..., 0:2]).abs().sum((1, 2)) / num_boxes
+        per_layer["loss_bbox"] = (src_box[..., 2:6] - tgt_box[..., 2:6]).abs().sum((1, 2)) / num_boxes
+        giou = _paired_giou(box_ops.box_cxcylrtb_to_xyxy(src_box), box_ops.box_cxcylrtb_to_xyxy(tgt_box))
+        per_layer["loss_giou"] = (1 - giou).sum(1) / num_boxes
+        # depth (Laplacian aleatoric uncertainty)
+        src_d, tgt_d = take(depth), flat["depth"][t_idx].squeeze(-1)
+        per_layer["loss_depth"] = (1.4142 * torch.exp(-src_d[..., 1]) * (src_d[..., 0] - tgt_d).abs() + src_d[..., 1]).sum(1) / num_boxes
+        # 3D size (dimension-aware L1 with the per-layer compensation weight)
+        src_s, tgt_s = take(dims), flat["size_3d"][t_idx]
+        l1 = (src_s - tgt_s).abs()
+        dim_loss = l1 / tgt_s.detach()
+        with torch.no_grad():
+            comp = l1.mean((1, 2)) / dim_loss.mean((1, 2))
+        per_layer["loss_dim"] = (dim_loss * comp.view(NL, 1, 1)).sum((1, 2)) / num_boxes
+        # heading: 12-bin classification + residual of the target bin
+        heading = take(angle)
+        cls_t = flat["heading_bin"][t_idx].view(NL, K).long()
+        res_t = flat["heading_res"][t_idx].view(NL, K)
+        cls_loss = F.cross_entropy(heading[..., 0:12].reshape(NL * K, 12), cls_t.reshape(-1), reduction="none").view(NL, K)
+        res_pred = torch.gather(heading[..., 12:24], 2, cls_t.unsqueeze(-1)).squeeze(-1)
+        per_layer["loss_angle"] = (cls_loss + (res_pred - res_t).abs()).sum(1) / num_boxes
+
+        losses = {}
+        zero = lambda: torch.zeros((), device=dev, dtype=torch.float32, requires_grad=True)
+        for l in range(NL):
+            suffix = "" if l == 0 else "_%d" % (l - 1)
+            for k, v in per_layer.items():
+                losses[k + suffix] = v[l]
+            losses["loss_tfl" + suffix] = zero()
+            losses["loss_mask" + suffix] = zero()
+
+        # depth map (final layer only): padded per-image boxes, rasterised on the device
+        maxn = max(sizes) if sizes else 0
+        w, h = self.depth_map_size
+        if maxn:
+            slot = np.minimum(offs[:, None] + np.arange(maxn)[None, :], max(T - 1, 0))
+            valid = np.arange(maxn)[None, :] < np.asarray(sizes)[:, None]
+            slot_t = torch.as_tensor(slot, dtype=torch.int64).to(dev, non_blocking=True)
+            valid_t = torch.as_tensor(valid).to(dev, non_blocking=True)
+            scale = torch.tensor([w, h, w, h], device=dev, dtype=logits.dtype)
+            boxes2d = box_ops.box_cxcywh_to_xyxy(flat["boxes"] * scale)[slot_t]
+            depth2d = flat["depth"].squeeze(1)[slot_t]
+        else:
+            valid_t = torch.zeros((B, 1), dtype=torch.bool, device=dev)
+            boxes2d = torch.zeros((B, 1, 4), device=dev, dtype=logits.dtype)
+            depth2d = torch.zeros((B, 1), device=dev, dtype=logits.dtype)
+        losses["loss_depth_map"] = self.ddn_loss.forward_padded(outputs["pred_depth_map_logits"], boxes2d, depth2d, valid_t)
+        return losses
+
+    # ------------------------------------------------------------------ reference formulation
+    def forward_layerwise(self, outputs, targets, mask_dict=None, info=None):
         outputs_without_aux = {k: v for k, v in outputs.items() if k != "aux_outputs"}
         group_num = self.group_num if self.training else 1
         indices = self.matcher(outputs_without_aux, targets, group_num=group_num)

@@ -83,6 +83,21 @@ class DDNLoss(nn.Module):
             start += n
         return canvas
 
+    def forward_padded(self, depth_logits, boxes_padded, depth_padded, valid):
+        """Same loss from padded per-image targets ([B,N,4] xyxy in depth-map pixels, [B,N], [B,N] bool) with no
+        host round trip.  Equal depths aside (where the painted value is the same anyway) it reproduces
+        ``forward`` exactly; downsample_factor must be 1 (the only value the reference uses)."""
+        assert self.downsample_factor == 1
+        B, _, H, W = depth_logits.shape
+        b = boxes_padded.clone()
+        b[..., :2] = torch.floor(b[..., :2])
+        b[..., 2:] = torch.ceil(b[..., 2:])
+        depth_maps, fg = rasterize_boxes(b.long(), depth_padded, valid, H, W)
+        target = lid_bin_indices(depth_maps, target=True)
+        loss = softmax_focal_loss(depth_logits, target, self.alpha, self.gamma)
+        loss = loss * (self.fg_weight * fg + self.bg_weight * (~fg))
+        return (loss * fg).sum() / fg.numel() + (loss * (~fg)).sum() / fg.numel()
+
     def forward(self, depth_logits, gt_boxes2d, num_gt_per_img, gt_center_depth):
         B, _, H, W = depth_logits.shape
         boxes_int = _int_boxes(gt_boxes2d)
@@ -98,6 +113,29 @@ class DDNLoss(nn.Module):
         num_pixels = fg.numel()
         loss = loss * weights
         return (loss * fg).sum() / num_pixels + (loss * (~fg)).sum() / num_pixels
+
+
+def _norm_slice(a, n):
+    """Start/stop of ``[a:b]`` normalised the way Python/torch slicing does: negative values count from
+    the end, everything is clamped into [0, n]."""
+    a = torch.where(a < 0, a + n, a)
+    return a.clamp(min=0, max=n)
+
+
+def rasterize_boxes(boxes_int, depths, valid, H, W):
+    """Loop-free equivalent of ``DDNLoss.paint_boxes`` for padded per-image boxes, fully on the device.
+    boxes_int [B,N,4] int64 (u1,v1,u2,v2), depths [B,N], valid [B,N] bool ->
+    depth_map [B,H,W] (painting far to near = the nearest covering box wins), fg_mask [B,H,W] bool."""
+    u1, v1, u2, v2 = boxes_int.unbind(-1)
+    ys = torch.arange(H, device=boxes_int.device).view(1, 1, H, 1)
+    xs = torch.arange(W, device=boxes_int.device).view(1, 1, 1, W)
+    y0, y1 = _norm_slice(v1, H)[..., None, None], _norm_slice(v2, H)[..., None, None]
+    x0, x1 = _norm_slice(u1, W)[..., None, None], _norm_slice(u2, W)[..., None, None]
+    cover = (ys >= y0) & (ys < y1) & (xs >= x0) & (xs < x1) & valid[..., None, None]          # [B,N,H,W]
+    inf = torch.full((), float("inf"), dtype=depths.dtype, device=depths.device)
+    nearest = torch.where(cover, depths[..., None, None], inf).amin(dim=1)
+    fg = cover.any(dim=1)
+    return torch.where(fg, nearest, torch.zeros((), dtype=depths.dtype, device=depths.device)), fg
 
 
 def _sl(a, b, n):

@@ -60,6 +60,44 @@ class HungarianMatcher(nn.Module):
         return [(torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)) for i, j in indices]
 
 
+    @torch.no_grad()
+    def match_layers(self, pred_logits, pred_boxes, flat_targets, sizes, group_num):
+        """All decoder layers at once: pred_logits [NL,B,Q,C], pred_boxes [NL,B,Q,6]; flat_targets holds the
+        concatenated 'labels' [T] and 'boxes_3d' [T,6]; sizes = targets per image (host ints).
+        One cost pass (same ops as ``cost_matrix``, so the same floats), one device->host copy of the
+        per-image diagonal blocks, one native call for every (layer, image, group) assignment.
+        -> list over layers of list over images of (query_idx, target_idx) int64 numpy arrays."""
+        from .. import lsap
+        NL, B, Q, _ = pred_logits.shape
+        T = int(sum(sizes))
+        if T == 0:
+            e = np.empty(0, np.int64)
+            return [[(e, e) for _ in range(B)] for _ in range(NL)]
+        C = self.cost_matrix({"pred_logits": pred_logits.flatten(0, 1), "pred_boxes": pred_boxes.flatten(0, 1)},
+                             [flat_targets]).view(NL, B, Q, T)
+        maxn = max(sizes)
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+        cols = np.minimum(offs[:, None] + np.arange(maxn)[None, :], T - 1)            # [B, maxn], clamped padding
+        cols = torch.as_tensor(cols, dtype=torch.int64).to(C.device, non_blocking=True)
+        blocks = torch.gather(C, 3, cols.view(1, B, 1, maxn).expand(NL, B, Q, maxn))
+        host = blocks.cpu().numpy()
+        if lsap.available():
+            return lsap.match_groups(host, np.asarray(sizes, np.int64), group_num, padded=True)
+        g_q = Q // group_num
+        out = []
+        for l in range(NL):
+            layer = []
+            for b in range(B):
+                src, tgt = [], []
+                for g in range(group_num):
+                    r, c = linear_sum_assignment(host[l, b, g * g_q:(g + 1) * g_q, :sizes[b]])
+                    src.append(r + g * g_q)
+                    tgt.append(c)
+                layer.append((np.concatenate(src), np.concatenate(tgt)))
+            out.append(layer)
+        return out
+
+
 def build_matcher(cfg):
     return HungarianMatcher(cost_class=cfg["set_cost_class"], cost_bbox=cfg["set_cost_bbox"],
                             cost_3dcenter=cfg["set_cost_3dcenter"], cost_giou=cfg["set_cost_giou"])

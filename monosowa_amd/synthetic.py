@@ -96,7 +96,12 @@ def make_batch(batch_size, device, seed=444, resolution=(1280, 384)):
 
 
 def prepare_targets(targets, batch_size):
-    """Padded [B,50,...] dict -> list of per-image dicts of the valid objects (trainer_helper.py:180-191)."""
+    """Padded [B,50,...] dict -> list of per-image dicts of the valid objects (trainer_helper.py:180-191).
+    The reference indexes every key of every image with a boolean mask (8 x B device->host syncs); here the
+    mask is resolved once and each key is gathered once for the whole batch, then split into views."""
     keys = ("labels", "boxes", "calibs", "depth", "size_3d", "heading_bin", "heading_res", "boxes_3d")
-    mask = targets["mask_2d"]
-    return [{k: v[b][mask[b]] for k, v in targets.items() if k in keys} for b in range(batch_size)]
+    mask = targets["mask_2d"][:batch_size]
+    b_idx, s_idx = mask.nonzero(as_tuple=True)                     # one sync; row-major = per image, slot order
+    counts = torch.bincount(b_idx, minlength=batch_size).tolist() if b_idx.numel() else [0] * batch_size
+    per_key = {k: v[b_idx, s_idx].split(counts) for k, v in targets.items() if k in keys}
+    return [{k: per_key[k][b] for k in per_key} for b in range(batch_size)]

@@ -231,3 +231,83 @@ def test_unshipped_switches_fail_loudly():
         bad[key] = True
         with pytest.raises((NotImplementedError, RuntimeError)):
             build_model(bad)
+
+
+def test_fast_criterion_equals_layerwise_formulation():
+    """The batched criterion (one matching pass, flat indices, device rasterisation) against the
+    layer-by-layer / image-by-image formulation restated from the reference, losses and gradients."""
+    from monosowa_amd.monodetr import build_weight_dict
+    from monosowa_amd.monodetr.criterion import SetCriterion
+    from monosowa_amd.monodetr.matcher import build_matcher
+    from monosowa_amd.synthetic import make_batch, prepare_targets
+    cfg = _cfg()["model"]
+    torch.manual_seed(5)
+    B, G, Qg = 3, 11, 50
+    _, _, targets, _ = make_batch(B, "cpu", seed=9, resolution=(320, 96))
+    tl = prepare_targets(targets, B)
+    tl[1] = {k: v[:0] for k, v in tl[1].items()}                       # an image without objects
+
+    def outputs(Q, seed):
+        g = torch.Generator().manual_seed(seed)
+        mk = lambda *s: torch.randn(*s, generator=g)
+        layer = lambda: {"pred_logits": mk(B, Q, 3).requires_grad_(), "pred_boxes": (torch.rand(B, Q, 6, generator=g) * 0.3 + 0.2).requires_grad_(),
+                         "pred_3d_dim": mk(B, Q, 3).requires_grad_(), "pred_depth": mk(B, Q, 2).requires_grad_(),
+                         "pred_angle": mk(B, Q, 24).requires_grad_()}
+        out = layer()
+        out["pred_depth_map_logits"] = mk(B, 81, 6, 20).requires_grad_()
+        out["aux_outputs"] = [layer(), layer()]
+        return out
+
+    for training in (True, False):
+        Q = G * Qg if training else Qg
+        res = {}
+        for fast in (False, True):
+            crit = SetCriterion(3, build_matcher(cfg), build_weight_dict(cfg), 0.25,
+                                ["labels", "boxes", "cardinality", "depths", "dims", "angles", "center", "depth_map", "tfl"],
+                                cfg=cfg, depth_map_size=(20, 6), fast=fast).train(training)
+            out = outputs(Q, 3)
+            ld = crit(out, tl)
+            total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+            total.backward()
+            res[fast] = (ld, out)
+        slow, fastd = res[False][0], res[True][0]
+        assert set(slow) == set(fastd), set(slow) ^ set(fastd)
+        for k in slow:
+            assert torch.allclose(slow[k], fastd[k], rtol=2e-5, atol=1e-6), (k, slow[k], fastd[k])
+        for key in ("pred_logits", "pred_boxes", "pred_depth", "pred_3d_dim", "pred_angle", "pred_depth_map_logits"):
+            assert torch.allclose(res[False][1][key].grad, res[True][1][key].grad, rtol=1e-4, atol=1e-7), key
+        for a, b in zip(res[False][1]["aux_outputs"], res[True][1]["aux_outputs"]):
+            assert torch.allclose(a["pred_boxes"].grad, b["pred_boxes"].grad, rtol=1e-4, atol=1e-7)
+
+
+def test_rasterize_boxes_matches_painting_loop(golden_dir=None):
+    from monosowa_amd.monodetr import losses as L
+    g = np.load(os.path.join(ROOT, "tests", "golden", "losses.npz"))
+    boxes, depth, num_gt = torch.from_numpy(g["boxes"]), torch.from_numpy(g["depth"]), [int(x) for x in g["num_gt"]]
+    pad = torch.zeros(2, 3, 4)
+    dpad = torch.zeros(2, 3)
+    valid = torch.zeros(2, 3, dtype=torch.bool)
+    pad[0, :3], pad[1, :2] = boxes[:3], boxes[3:]
+    dpad[0, :3], dpad[1, :2] = depth[:3], depth[3:]
+    valid[0, :3], valid[1, :2] = True, True
+    dm, fg = L.rasterize_boxes(L._int_boxes(pad.view(-1, 4)).view(2, 3, 4), dpad, valid, 24, 80)
+    assert torch.equal(dm, torch.from_numpy(g["depth_map"]))                  # incl. the box poking out on the left
+    loss = L.DDNLoss().forward_padded(torch.from_numpy(g["depth_logits"]), pad, dpad, valid)
+    assert torch.allclose(loss, torch.as_tensor(g["ddn_loss"]), rtol=1e-5)
+
+
+def test_native_lsap_equals_scipy_including_ties():
+    from scipy.optimize import linear_sum_assignment as ref
+    from monosowa_amd import lsap
+    assert lsap.available()
+    rng = np.random.default_rng(0)
+    for trial in range(400):
+        nr, nc = int(rng.integers(1, 12)), int(rng.integers(1, 60))
+        if trial % 2:
+            nr, nc = nc, nr
+        c = rng.integers(0, 4, (nr, nc)).astype(np.float64) if trial % 3 == 0 else rng.standard_normal((nr, nc))
+        a, b = ref(c)
+        x, y = lsap.linear_sum_assignment(c)
+        assert np.array_equal(a, x) and np.array_equal(b, y)
+    with pytest.raises(ValueError):
+        lsap.linear_sum_assignment(np.full((2, 2), np.nan))
