@@ -78,6 +78,9 @@ def build_everything(args, device):
     torch.manual_seed(cfg.get("random_seed", 444))
     model, criterion = build_model(mcfg)
     model.to(device)
+    if device.type == "cuda":
+        from monosowa_amd.helpers.model_helper import to_mi355x_layout
+        to_mi355x_layout(model)
     criterion.to(device)
     optimizer = build_optimizer(cfg["optimizer"], model)
     return cfg, model, criterion, optimizer, (W, H)
@@ -167,6 +170,7 @@ def main():
     criterion.train(train)
     model = wrap_ddp(model, device)
     batch = make_batch(args.batch, device, seed=444 + rank, resolution=(W, H))
+    batch = (batch[0].contiguous(memory_format=torch.channels_last),) + batch[1:]
 
     if train:
         step = train_step_fn(model, criterion, optimizer)

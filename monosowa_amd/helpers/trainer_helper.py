@@ -49,6 +49,9 @@ class Trainer(object):
             self.device = torch.device("cuda", torch.cuda.current_device())
         else:
             self.device = torch.device("cpu")
+        if self.device.type == "cuda":
+            from .model_helper import to_mi355x_layout
+            to_mi355x_layout(unwrap(model))
         self.model = wrap_ddp(model, self.device)
         self.detr_loss = loss
         self.model_name = model_name
@@ -126,6 +129,8 @@ class Trainer(object):
         bar = tqdm.tqdm(total=len(self.train_loader), leave=(self.epoch + 1 == self.cfg["max_epoch"]), desc="iters", disable=not main)
         for batch_idx, (inputs, calibs, targets, info) in enumerate(self.train_loader):
             inputs = inputs.to(self.device, non_blocking=True)
+            if inputs.is_cuda:
+                inputs = inputs.contiguous(memory_format=torch.channels_last)
             calibs = calibs.to(self.device, non_blocking=True)
             targets = {k: v.to(self.device, non_blocking=True) for k, v in targets.items()}
             total, loss_dict = self.train_step(inputs, calibs, targets, info)

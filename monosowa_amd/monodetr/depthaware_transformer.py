@@ -19,6 +19,7 @@ from torch.nn.init import constant_, normal_, xavier_uniform_
 from .misc import inverse_sigmoid
 from .. import MultiScaleDeformableAttention as _MSDA
 from ..ms_deform_attn import MSDeformAttn
+from ..token_linear import token_linear
 
 
 class MLP(nn.Module):
@@ -65,7 +66,7 @@ class VisualEncoderLayer(nn.Module):
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         attn = self.self_attn(_add_pos(src, pos), reference_points, src, spatial_shapes, level_start_index, padding_mask)
         src = self.norm1(src + self.dropout1(attn))
-        ff = self.linear2(self.dropout2(F.relu(self.linear1(src))))
+        ff = token_linear(self.dropout2(F.relu(token_linear(src, self.linear1))), self.linear2)
         return self.norm2(src + self.dropout3(ff))
 
 

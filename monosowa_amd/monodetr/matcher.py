@@ -14,6 +14,14 @@ from torch import nn
 from .box_ops import box_cxcylrtb_to_xyxy, generalized_box_iou
 
 
+def _pairwise_l1(a, b):
+    d = (a[:, None, :] - b[None, :, :]).abs()
+    out = d[..., 0]
+    for i in range(1, d.shape[-1]):
+        out = out + d[..., i]
+    return out
+
+
 class HungarianMatcher(nn.Module):
     def __init__(self, cost_class: float = 1, cost_3dcenter: float = 1, cost_bbox: float = 1, cost_giou: float = 1):
         super().__init__()
@@ -35,8 +43,10 @@ class HungarianMatcher(nn.Module):
 
         out_box = outputs["pred_boxes"].flatten(0, 1)
         tgt_box = torch.cat([v["boxes_3d"] for v in targets])
-        cost_3dcenter = torch.cdist(out_box[:, 0:2], tgt_box[:, 0:2], p=1)
-        cost_bbox = torch.cdist(out_box[:, 2:6], tgt_box[:, 2:6], p=1)
+        # pairwise L1 distances; the same left-to-right sum as the reference's torch.cdist(p=1) evaluates for 2 and
+        # 4 components, without cdist's ~1.5 ms kernel on a [B*Q, 2] x [T, 2] problem
+        cost_3dcenter = _pairwise_l1(out_box[:, 0:2], tgt_box[:, 0:2])
+        cost_bbox = _pairwise_l1(out_box[:, 2:6], tgt_box[:, 2:6])
         cost_giou = -generalized_box_iou(box_cxcylrtb_to_xyxy(out_box), box_cxcylrtb_to_xyxy(tgt_box), check=False)
         C = self.cost_bbox * cost_bbox + self.cost_3dcenter * cost_3dcenter + self.cost_class * cost_class \
             + self.cost_giou * cost_giou

@@ -13,6 +13,7 @@ from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
 from . import ms_deform_attn_func as _func
+from .token_linear import token_linear
 
 
 def _is_power_of_2(n):
@@ -67,13 +68,13 @@ class MSDeformAttn(nn.Module):
         N, Len_in, _ = input_flatten.shape
         assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
 
-        value = self.value_proj(input_flatten)
+        value = token_linear(input_flatten, self.value_proj)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
-        sampling_offsets = self.sampling_offsets(query).view(
+        sampling_offsets = token_linear(query, self.sampling_offsets).view(
             N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
-        attention_weights = self.attention_weights(query).view(
+        attention_weights = token_linear(query, self.attention_weights).view(
             N, Len_q, self.n_heads, self.n_levels * self.n_points)
         attention_weights = F.softmax(attention_weights, -1).view(
             N, Len_q, self.n_heads, self.n_levels, self.n_points)
@@ -91,4 +92,4 @@ class MSDeformAttn(nn.Module):
         output = _func.MSDeformAttnFunction.apply(
             value, input_spatial_shapes, input_level_start_index, sampling_locations,
             attention_weights, self.im2col_step)
-        return self.output_proj(output)
+        return token_linear(output, self.output_proj)

@@ -1,0 +1,54 @@
+"""Linear layer over very many tokens with a split-K weight gradient.
+
+In the visual encoder every projection runs over B*S = 163,200 tokens (B=16, 1280x384) with 256 (or 128)
+output features.  The forward and input-gradient GEMMs are tall and parallelise well, but the weight
+gradient  dW[256,256] = dY^T[256,T] @ X[T,256]  has a 256x256 output and K = T = 163,200: the library kernel
+runs it on 32 workgroups of a 256-CU chip (0.48 ms).  Splitting K into slices turns it into a batched
+GEMM with 64x more workgroups followed by a tiny reduction (0.18 ms, `tools/gemm_probe.py`).
+Same math as ``F.linear`` (fp32 summation order differs in the weight gradient: ~6e-6 relative).
+"""
+import torch
+import torch.nn.functional as F
+
+MIN_TOKENS = 32768
+
+
+def _slices(tokens):
+    for s in (64, 48, 32, 24, 16, 8):
+        if tokens % s == 0 and tokens // s >= 512:
+            return s
+    return 0
+
+
+class _TokenLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        g2 = grad_out.reshape(-1, grad_out.shape[-1])
+        if ctx.needs_input_grad[0]:
+            gx = (g2 @ weight).view_as(x)
+        if ctx.needs_input_grad[1]:
+            x2 = x.reshape(-1, x.shape[-1])
+            s = _slices(x2.shape[0])
+            if s:
+                gw = torch.bmm(g2.view(s, -1, g2.shape[1]).transpose(1, 2), x2.view(s, -1, x2.shape[1])).sum(0)
+            else:
+                gw = g2.t() @ x2
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return gx, gw, gb
+
+
+def token_linear(x, linear):
+    """``linear(x)`` for an ``nn.Linear``; routes through the split-K backward when there are enough tokens."""
+    tokens = x.numel() // x.shape[-1]
+    if x.is_cuda and tokens >= MIN_TOKENS and torch.is_grad_enabled() and linear.weight.requires_grad and _slices(tokens):
+        return _TokenLinear.apply(x, linear.weight, linear.bias)
+    return linear(x)

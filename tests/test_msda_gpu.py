@@ -216,3 +216,22 @@ def test_all_points_outside_and_nan_locations():
     out = MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, w, 64)
     gv, gl, gw = MSDA.ms_deform_attn_backward(v, shapes, lsi, loc, w, torch.ones(1, 5, 256).cuda(), 64)
     assert not out.any() and not gv.any() and not gl.any() and not gw.any()
+
+
+def test_token_linear_split_k_backward_matches_linear():
+    from monosowa_amd.token_linear import token_linear
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(256, 128).cuda()
+    x = torch.randn(4, 10200, 256, device="cuda", requires_grad=True)
+    go = torch.randn(4, 10200, 128, device="cuda")
+    y = token_linear(x, lin)
+    assert y.grad_fn is not None and "TokenLinear" in type(y.grad_fn).__name__
+    y.backward(go)
+    got = (x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x.grad = None
+    lin.zero_grad()
+    lin(x).backward(go)
+    for a, b in zip(got, (x.grad, lin.weight.grad, lin.bias.grad)):
+        assert (a - b).abs().max() <= 2e-5 * b.abs().max()
+    small = torch.randn(2, 50, 256, device="cuda", requires_grad=True)
+    assert "TokenLinear" not in type(token_linear(small, lin).grad_fn).__name__

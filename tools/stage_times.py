@@ -39,9 +39,13 @@ def main():
     cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "configs", "monodetr.yaml")))
     model, crit = build_model(cfg["model"])
     model.to(dev).train()
+    if "--cl" in sys.argv:
+        model.backbone.to(memory_format=torch.channels_last)
     crit.to(dev).train()
     opt = build_optimizer(cfg["optimizer"], model)
     inputs, calibs, targets, info = make_batch(B, dev)
+    if "--cl" in sys.argv:
+        inputs = inputs.contiguous(memory_format=torch.channels_last)
     tl = prepare_targets(targets, B)
     say("built; B =", B)
     with torch.no_grad():
