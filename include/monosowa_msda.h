@@ -30,10 +30,11 @@
  * allocation (`workspace` entry points below), so calls may be captured into a hipGraph.
  *
  * Level geometry on the host: `shapes_host` / `level_start_host` are optional HOST copies of
- * `shapes` / `level_start` (same values).  The backward's launch plan depends on H_l, W_l; when the
- * host copies are NULL the library fetches them from the device with a blocking copy on `stream`
- * (correct, but a host synchronisation and not graph-capturable) -- callers that know the pyramid
- * (they built it) should pass them.
+ * `shapes` / `level_start` (same values).  The launch plans of the fast kernels depend on H_l, W_l.
+ * Backward: when the host copies are NULL the library fetches them from the device with a blocking
+ * copy on `stream` (correct, but a host synchronisation and not graph-capturable).  Forward: NULL
+ * selects the kernel that needs no plan (no synchronisation, somewhat slower).  Callers that know the
+ * pyramid (they built it) should pass them.
  *
  * Errors: 0 on success; a positive value is a hipError_t from the launch (the reference only
  * printf's launch errors, cuh:948-952 -- this library returns them); negative values are
@@ -49,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 2
+#define MSDA_ABI_VERSION 3
 
 #define MSDA_E_NULLPTR (-1)   /* a required pointer is NULL                        */
 #define MSDA_E_SHAPE (-2)     /* a dimension is <= 0 or exceeds the indexing range */
@@ -66,11 +67,13 @@ size_t msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int Lq, 
 
 int msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
                      const float *loc, const float *attn_w, float *out,
-                     int B, int S, int M, int D, int L, int Lq, int P, void *stream);
+                     int B, int S, int M, int D, int L, int Lq, int P,
+                     const int64_t *shapes_host, const int64_t *level_start_host, void *stream);
 
 int msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,
                      const double *loc, const double *attn_w, double *out,
-                     int B, int S, int M, int D, int L, int Lq, int P, void *stream);
+                     int B, int S, int M, int D, int L, int Lq, int P,
+                     const int64_t *shapes_host, const int64_t *level_start_host, void *stream);
 
 int msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
                       const float *loc, const float *attn_w, const float *grad_out,

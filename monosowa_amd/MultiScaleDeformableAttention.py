@@ -92,7 +92,8 @@ def _dims(value, spatial_shapes, sampling_loc, attn_weight):
     return B, S, M, D, L, Lq, P
 
 
-def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step,
+                           host_geom=None):
     """-> Tensor [B, Lq, M*D]   (reference: ms_deform_attn_cuda_forward, cu:20-80)"""
     _check_common([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
                    ("sampling_loc", sampling_loc), ("attn_weight", attn_weight)], im2col_step)
@@ -102,6 +103,8 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     lib = _lib.load()
     out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
     fn = lib.msda_forward_f32 if value.dtype == torch.float32 else lib.msda_forward_f64
+    if host_geom is None:      # only a pre-attached copy is used here: the forward never synchronises for it
+        host_geom = getattr(spatial_shapes, "_msda_host_geometry", None) or (None, None)
     timer = LaunchTimer.active
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream()
@@ -110,7 +113,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
             e0.record(stream)
         code = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                   sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
-                  B, S, M, D, L, Lq, P, stream.cuda_stream)
+                  B, S, M, D, L, Lq, P, host_geom[0], host_geom[1], stream.cuda_stream)
         if timer is not None:
             e1.record(stream)
     _lib.check(code, "ms_deform_attn_forward")

@@ -11,7 +11,7 @@ SYMBOLS = ("msda_abi_version", "msda_strerror", "msda_backward_workspace_bytes",
            "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64")
 
 _lib = None
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MSDALibraryError(RuntimeError):
@@ -36,7 +36,7 @@ def load():
     for suf in ("f32", "f64"):
         f = getattr(lib, "msda_forward_" + suf)
         f.restype = I
-        f.argtypes = [P] * 6 + [I] * 7 + [P]
+        f.argtypes = [P] * 6 + [I] * 7 + [P, P, P]
         b = getattr(lib, "msda_backward_" + suf)
         b.restype = I
         b.argtypes = [P] * 9 + [I] * 7 + [P, P, P, Z, P]

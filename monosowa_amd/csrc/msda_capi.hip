@@ -6,6 +6,8 @@
 #include "../../include/monosowa_msda.h"
 #include "msda_kernels.hip"
 #include "msda_backward_tiled.hip"
+#include "msda_gather_rec.hip"
+#include <cstdlib>
 #include <algorithm>
 #include <vector>
 
@@ -30,16 +32,70 @@ inline int check_dims(int B, int S, int M, int D, int L, int Lq, int P) {
   return 0;
 }
 
+// Geometry of the LDS-resident gather kernels: stage the longest tail of levels that fits kLdsRows.
+// Returns false when nothing would be staged (the plain gather kernels are used instead).
+bool make_gather_geom(const int64_t *shapes_host, const int64_t *lsi_host, int B, int M, int Lq, int S,
+                      msda::GatherGeom &g) {
+  int first = 4;
+  long long rows = 0;
+  for (int l = 3; l >= 0; --l) {
+    const long long n = shapes_host[2 * l] * shapes_host[2 * l + 1];
+    if (lsi_host[l] + n != (l == 3 ? S : lsi_host[l + 1])) break;      // levels must tile the token axis in order
+    if (rows + n > msda::kLdsRows) break;
+    rows += n;
+    first = l;
+  }
+  for (int l = 0; l < 4; ++l) {
+    g.H[l] = (int)shapes_host[2 * l];
+    g.W[l] = (int)shapes_host[2 * l + 1];
+    g.start[l] = (int)lsi_host[l];
+  }
+  g.first_lds_level = first;
+  if (first == 4) { g.lds_token0 = 0; g.n_lds_rows = 0; g.n_chunks = 1; return false; }
+  g.lds_token0 = (int)lsi_host[first];
+  g.n_lds_rows = (int)rows;
+  // Query slices per (batch, head).  Workgroups of one (batch, head) run back to back on one XCD (32 CUs):
+  // with c slices an XCD has 32 / c value planes (1.2 MB of fine levels each at 1280x384) live in its 4 MB
+  // L2 -- measured L2 hit rate 31 % at c = 2.  8 slices keep ~4 planes live; each slice still gets >= 256
+  // queries so the 76 KB of staging stays amortised.
+  (void)B;
+  long long chunks = 8;
+  const long long max_chunks = std::max<long long>(1, Lq / 256);
+  g.n_chunks = (int)std::max<long long>(1, std::min(chunks, max_chunks));
+  return true;
+}
+
+// MSDA_GATHER = 0: first-generation gather kernels; 1: tap records; 2 (default): records + coarse levels in LDS.
+// A tuning / A-B switch only; every mode computes the same function.
+inline int gather_mode() {
+  static const int mode = [] { const char *e = std::getenv("MSDA_GATHER"); return e ? std::atoi(e) : 2; }();
+  return mode;
+}
+
 template <typename T>
 int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc,
                  const T *attw, T *out, int B, int S, int M, int D, int L, int Lq, int P,
-                 void *stream_) {
+                 const int64_t *shapes_host, const int64_t *lsi_host, void *stream_) {
   if (!value || !shapes || !lsi || !loc || !attw || !out) return MSDA_E_NULLPTR;
   if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
   hipStream_t stream = (hipStream_t)stream_;
   const long long n_pairs = (long long)B * Lq * M;
   if constexpr (sizeof(T) == 4) {
     if (D == 32 && L == 4 && P == 4) {
+      msda::GatherGeom geom;
+      if (shapes_host && lsi_host && gather_mode() > 0) {
+        const bool staged = make_gather_geom(shapes_host, lsi_host, B, M, Lq, S, geom) && gather_mode() > 1;
+        if (staged) {
+          const int bm_groups = (B * M + 7) / 8;
+          msda::gather_rec_kernel<false, true><<<8 * geom.n_chunks * bm_groups, msda::kStagedThreadsFwd, 0, stream>>>(
+              value, loc, attw, nullptr, out, nullptr, nullptr, geom, B, S, M, Lq, n_pairs);
+        } else {
+          geom.first_lds_level = 4;
+          msda::gather_rec_kernel<false, false><<<grid_pairs(n_pairs), msda::kPlainThreads, 0, stream>>>(
+              value, loc, attw, nullptr, out, nullptr, nullptr, geom, B, S, M, Lq, n_pairs);
+        }
+        return (int)hipGetLastError();
+      }
       msda::fwd_d32_kernel<4, 4><<<grid_pairs(n_pairs), 256, 0, stream>>>(
           value, shapes, lsi, loc, attw, out, S, M, Lq, n_pairs);
       return (int)hipGetLastError();
@@ -143,8 +199,19 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       const int bm_groups = (B * M + 7) / 8;
       msda::bwd_scatter_kernel<<<8 * plan.n_items * bm_groups, msda::kScatterThreads, 0, stream>>>(
           rec_hw, rec_aw, grad_out, grad_value, plan, B, S, M, Lq, P);
-      msda::bwd_gather_kernel<4, 4><<<grid_pairs(n_pairs), 256, 0, stream>>>(
-          value, shapes, lsi, loc, attw, grad_out, grad_loc, grad_attw, S, M, Lq, n_pairs);
+      msda::GatherGeom geom;
+      const bool can_stage = make_gather_geom(shapes_host, lsi_host, B, M, Lq, S, geom);
+      if (gather_mode() > 1 && can_stage) {
+        msda::gather_rec_kernel<true, true><<<8 * geom.n_chunks * bm_groups, msda::kStagedThreadsBwd, 0, stream>>>(
+            value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, geom, B, S, M, Lq, n_pairs);
+      } else if (gather_mode() > 0) {
+        geom.first_lds_level = 4;
+        msda::gather_rec_kernel<true, false><<<grid_pairs(n_pairs), msda::kPlainThreads, 0, stream>>>(
+            value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, geom, B, S, M, Lq, n_pairs);
+      } else {
+        msda::bwd_gather_kernel<4, 4><<<grid_pairs(n_pairs), 256, 0, stream>>>(
+            value, shapes, lsi, loc, attw, grad_out, grad_loc, grad_attw, S, M, Lq, n_pairs);
+      }
       return (int)hipGetLastError();
     }
   }
@@ -181,14 +248,18 @@ size_t msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int Lq, 
 
 int msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
                      const float *loc, const float *attn_w, float *out, int B, int S, int M, int D,
-                     int L, int Lq, int P, void *stream) {
-  return forward_impl<float>(value, shapes, level_start, loc, attn_w, out, B, S, M, D, L, Lq, P, stream);
+                     int L, int Lq, int P, const int64_t *shapes_host, const int64_t *level_start_host,
+                     void *stream) {
+  return forward_impl<float>(value, shapes, level_start, loc, attn_w, out, B, S, M, D, L, Lq, P, shapes_host,
+                             level_start_host, stream);
 }
 
 int msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,
                      const double *loc, const double *attn_w, double *out, int B, int S, int M, int D,
-                     int L, int Lq, int P, void *stream) {
-  return forward_impl<double>(value, shapes, level_start, loc, attn_w, out, B, S, M, D, L, Lq, P, stream);
+                     int L, int Lq, int P, const int64_t *shapes_host, const int64_t *level_start_host,
+                     void *stream) {
+  return forward_impl<double>(value, shapes, level_start, loc, attn_w, out, B, S, M, D, L, Lq, P, shapes_host,
+                              level_start_host, stream);
 }
 
 int msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,

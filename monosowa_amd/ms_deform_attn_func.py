@@ -21,7 +21,7 @@ class MSDeformAttnFunction(Function):
         ctx.host_geom = MSDA.host_geometry(value_spatial_shapes, value_level_start_index) if value.is_cuda else None
         output = MSDA.ms_deform_attn_forward(
             value, value_spatial_shapes, value_level_start_index, sampling_locations,
-            attention_weights, ctx.im2col_step)
+            attention_weights, ctx.im2col_step, host_geom=ctx.host_geom)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
                               sampling_locations, attention_weights)
         return output

@@ -20,6 +20,10 @@ def make(B, Lq_kind, dev, seed=0):
     g = torch.Generator(device=dev).manual_seed(seed)
     shapes = torch.tensor(LEVELS, dtype=torch.long, device=dev)
     lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    starts = [0]
+    for h, w in LEVELS[:-1]:
+        starts.append(starts[-1] + h * w)
+    MSDA.attach_host_geometry(shapes, lsi, LEVELS, starts)     # what the transformer does (no sync in forward)
     S, M, D, L, P = 10200, 8, 32, 4, 4
     value = torch.randn(B, S, M, D, device=dev, generator=g)
     if Lq_kind == "enc":
