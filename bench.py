@@ -141,8 +141,24 @@ def cpu_baseline(args):
         F.MSDeformAttnFunction = saved
 
 
+class _StdoutGuard:
+    """Third-party libraries (RCCL's version banner, MIOpen) write to fd 1; the contract is ONE JSON line on
+    stdout.  Everything goes to stderr until ``release()``."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def release(self):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     args = parse()
+    guard = _StdoutGuard()
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,7 +168,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the CPU path is only the cpu_baseline leg)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=device)
@@ -244,8 +260,9 @@ def main():
             log("cpu_baseline leg (bounded sample)")
             line["cpu_baseline"] = cpu_baseline(args)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        guard.release()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

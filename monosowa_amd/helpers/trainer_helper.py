@@ -20,7 +20,8 @@ from .save_helper import get_checkpoint_state, load_checkpoint, save_checkpoint,
 
 def wrap_ddp(model, device):
     """DDP with few large buckets (xGMI rings are per-link bound) and the never-used parameters frozen."""
-    if not (misc.is_dist_avail_and_initialized() and misc.get_world_size() > 1):
+    force = os.environ.get("MONOSOWA_FORCE_DDP") == "1"        # rehearse the DDP path on a 1-GPU box
+    if not (misc.is_dist_avail_and_initialized() and (misc.get_world_size() > 1 or force)):
         return model
     core = unwrap(model)
     unused = set(core.unused_parameter_names()) if hasattr(core, "unused_parameter_names") else set()
