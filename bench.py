@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-batch", type=int, default=2)
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--graph", action="store_true", help="infer mode: replay the forward from a captured hipGraph")
     ap.add_argument("--miopen-find", action="store_true", help="cudnn.benchmark=True: MIOpen searches per conv shape (slow start)")
     return ap.parse_args()
 
@@ -190,10 +191,16 @@ def main():
 
     if train:
         step = train_step_fn(model, criterion, optimizer)
-    else:
+    elif not args.graph:
         def step(b):
             with torch.no_grad():
                 return model(b[0], b[1], None, b[2]["img_size"])["pred_logits"]
+    else:
+        from monosowa_amd.helpers.tester_helper import GraphedForward
+        graphed = GraphedForward(model, batch[0], batch[1], batch[2]["img_size"])
+
+        def step(b):
+            return graphed(b[0], b[1], b[2]["img_size"])["pred_logits"]
 
     log("model + batch ready; warm-up")
     for i in range(args.warmup):

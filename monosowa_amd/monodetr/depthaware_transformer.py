@@ -254,6 +254,22 @@ class DepthAwareTransformer(nn.Module):
         constant_(self.reference_points.bias.data, 0.)
         normal_(self.level_embed)
 
+    def _pyramid_tensors(self, shapes, device):
+        """int64 [L,2] shapes and [L] level starts on the device, built once per (pyramid, device): they are
+        constants of the resolution, a host->device copy per step would also forbid hipGraph capture."""
+        cache = self.__dict__.setdefault("_pyramid_cache", {})
+        key = (shapes, str(device))
+        if key not in cache:
+            spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=device)
+            level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+            if spatial_shapes.is_cuda:   # the HIP kernels plan their launches from the host copy of the pyramid
+                starts = [0]
+                for h, w in shapes[:-1]:
+                    starts.append(starts[-1] + h * w)
+                _MSDA.attach_host_geometry(spatial_shapes, level_start_index, list(shapes), starts)
+            cache[key] = (spatial_shapes, level_start_index)
+        return cache[key]
+
     @staticmethod
     def get_valid_ratio(mask):
         _, H, W = mask.shape
@@ -274,13 +290,7 @@ class DepthAwareTransformer(nn.Module):
         src_flat = torch.cat(src_flat, 1)
         mask_flat = torch.cat(mask_flat, 1)
         pos_flat = torch.cat(pos_flat, 1)
-        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src_flat.device)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
-        if spatial_shapes.is_cuda:    # the HIP backward plans its launch from the pyramid: hand it the host copy
-            starts = [0]
-            for h, w in shapes[:-1]:
-                starts.append(starts[-1] + h * w)
-            _MSDA.attach_host_geometry(spatial_shapes, level_start_index, shapes, starts)
+        spatial_shapes, level_start_index = self._pyramid_tensors(tuple(shapes), src_flat.device)
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
 
         memory = self.encoder(src_flat, spatial_shapes, level_start_index, valid_ratios, pos_flat, mask_flat,

@@ -66,7 +66,13 @@ class MSDeformAttn(nn.Module):
         input_padding_mask [N,S] (True = padding) -> [N,Lq,C]."""
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
-        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        # the reference asserts sum(H_l * W_l) == Len_in on the device tensor (ms_deform_attn.py:136), a host
+        # synchronisation per call; the host copy of the pyramid answers it for free when the caller attached one
+        geom = getattr(input_spatial_shapes, "_msda_host_geometry", None)
+        if geom is not None:
+            assert sum(geom[0][2 * i] * geom[0][2 * i + 1] for i in range(len(geom[1]))) == Len_in
+        else:
+            assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
 
         value = token_linear(input_flatten, self.value_proj)
         if input_padding_mask is not None:

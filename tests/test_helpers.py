@@ -311,3 +311,28 @@ def test_native_lsap_equals_scipy_including_ties():
         assert np.array_equal(a, x) and np.array_equal(b, y)
     with pytest.raises(ValueError):
         lsap.linear_sum_assignment(np.full((2, 2), np.nan))
+
+
+def test_vectorised_decode_equals_loop_form():
+    from monosowa_amd.helpers.decode_helper import PinholeCalib, decode_detections, decode_detections_loop
+    rng = np.random.default_rng(3)
+    B, K = 4, 50
+    dets = rng.standard_normal((B, K, 37)).astype(np.float32)
+    dets[:, :, 0] = rng.integers(0, 3, (B, K))
+    dets[:, :, 1] = rng.uniform(0, 1, (B, K))
+    dets[:, :, 2:6] = rng.uniform(0.05, 0.9, (B, K, 4))
+    dets[:, :, 6] = rng.uniform(2, 60, (B, K))
+    dets[:, :, 34:36] = rng.uniform(0.1, 0.9, (B, K, 2))
+    dets[:, :, 36] = rng.uniform(0.2, 1, (B, K))
+    info = {"img_size": np.array([[1242, 375], [1224, 370], [1408, 376], [1920, 1280]]), "height_crop": np.array([1.0, 1.0, 1.1, 0.9]),
+            "canonical_scale": np.array([0.7, 0.9, 0.36, 1.2]), "img_id": np.arange(B) + 10}
+    cals = [PinholeCalib(np.array([[700. + 10 * i, 0, 600., 40.], [0, 705., 180., 2.], [0, 0, 1, 0.003]])) for i in range(B)]
+    mean = rng.uniform(0, 1, (3, 3)).astype(np.float32)
+    a = decode_detections(dets.copy(), info, cals, mean, threshold=0.2)
+    b = decode_detections_loop(dets.copy(), info, cals, mean, threshold=0.2)
+    assert list(a) == list(b)
+    for k in a:
+        assert len(a[k]) == len(b[k])
+        for ra, rb in zip(a[k], b[k]):
+            assert ra[0] == rb[0]
+            np.testing.assert_allclose(np.asarray(ra[1:], np.float64), np.asarray(rb[1:], np.float64), rtol=1e-6, atol=1e-6)

@@ -235,3 +235,28 @@ def test_token_linear_split_k_backward_matches_linear():
         assert (a - b).abs().max() <= 2e-5 * b.abs().max()
     small = torch.randn(2, 50, 256, device="cuda", requires_grad=True)
     assert "TokenLinear" not in type(token_linear(small, lin).grad_fn).__name__
+
+
+def test_eval_forward_replays_from_a_hipgraph():
+    """The C-ABI launches are capture-safe (no allocation, no host sync): the whole eval forward, MSDA included,
+    replays from a hipGraph and reproduces the eager outputs."""
+    import yaml
+    from monosowa_amd.helpers.model_helper import build_model, to_mi355x_layout
+    from monosowa_amd.helpers.tester_helper import GraphedForward
+    from monosowa_amd.synthetic import make_batch
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "configs", "monodetr.yaml")))
+    torch.manual_seed(1)
+    model, _ = build_model(dict(cfg["model"], device="cuda"))
+    model = to_mi355x_layout(model.cuda()).eval()
+    inputs, calibs, targets, _ = make_batch(2, "cuda", seed=3, resolution=(320, 96))
+    with torch.no_grad():
+        eager = model(inputs, calibs, None, targets["img_size"])
+    g = GraphedForward(model, inputs, calibs, targets["img_size"])
+    inputs2, calibs2, targets2, _ = make_batch(2, "cuda", seed=4, resolution=(320, 96))
+    out = {k: v.clone() for k, v in g(inputs, calibs, targets["img_size"]).items() if torch.is_tensor(v)}
+    for k in ("pred_logits", "pred_boxes", "pred_depth", "pred_angle", "pred_3d_dim"):
+        assert torch.allclose(out[k], eager[k], rtol=1e-4, atol=1e-5), k
+    with torch.no_grad():
+        eager2 = model(inputs2, calibs2, None, targets2["img_size"])
+    out2 = g(inputs2, calibs2, targets2["img_size"])
+    assert torch.allclose(out2["pred_boxes"], eager2["pred_boxes"], rtol=1e-4, atol=1e-5)
