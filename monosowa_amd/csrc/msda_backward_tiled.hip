@@ -7,13 +7,15 @@
 //
 //   K1 bwd_prep_kernel      transposes the sampling points into per-(batch, head, level) record
 //                           lists {h_im, w_im} / {attn_w} (12 B per point, coalesced for the
-//                           scans below); points failing the cuh:274 test get a sentinel.
+//                           scans below); points failing the cuh:274 test get a sentinel.  Per
+//                           64-point chunk it also emits the bounding box of the corner pixels,
+//                           and per (batch, head) max|attn_w|, max|grad_out|.
 //   K2 bwd_scatter_kernel   "tile owner": one workgroup owns a tile of one level of one
-//                           (batch, head) -- 256 value rows x 32 double accumulators in LDS.  It
-//                           scans the level's record list, queues the points with a corner inside
-//                           its tile, and adds w_corner * attn_w * grad_out[b,q,m,:] into LDS with
-//                           ds_add_f64 (8 lanes x 4 channels per point, channel order rotated per
-//                           lane group to spread the LDS banks).
+//                           (batch, head) -- 256 value rows x 32 64-bit fixed-point accumulators in
+//                           LDS.  It walks the level's chunk boxes, scans only chunks that touch
+//                           its tile, queues the points with a corner inside it, and adds
+//                           w_corner * attn_w * grad_out[b,q,m,:] into LDS with ds_add_u64 (8 lanes
+//                           x 4 channels per point, channel order rotated per lane group).
 //                           Tiles owned by a single workgroup are written back with plain stores
 //                           (no zero-fill, no atomics); coarse levels, whose few rows receive a
 //                           quarter of all points each, are split over several workgroups by
@@ -29,47 +31,136 @@ namespace msda {
 constexpr float kInvalidCoord = -8.0f;   // floor() = -8: no corner can fall inside any tile
 
 // ------------------------------------------------------------------------------------------ K1
-// one thread per output record; rec index o = (((b*M + m)*L + l)*Lq + q)*P + p
+// one thread per output record; rec index o = (((b*M + m)*L + l)*Lq + q)*P + p.  A wave covers 64
+// consecutive records of one (b, m, l) list = one "chunk": it also emits the chunk's bounding box of corner
+// pixels (so that tile workgroups can skip whole chunks) and folds max|attn_w|, max|grad_out| of its
+// (batch, head) into bounds[bm] (scale of the fixed-point accumulators in K2).
+struct ChunkBox {
+  short y_lo, y_hi, x_lo, x_hi;      // inclusive corner-pixel ranges; empty: y_lo > y_hi
+  float a_max, g_max;                // max|attn_w|, max|grad_out| seen by the chunk (folded per (b, m) by K1b)
+};
+
+// K1b: bounds[bm] = {max|attn_w|, max|grad_out|} over all chunks of the (batch, head); one workgroup per bm.
+// NaN / inf gradients poison the bound and therefore the whole (batch, head) -- as they poison the sums.
+__global__ __launch_bounds__(256) void bwd_bounds_kernel(const ChunkBox *__restrict__ boxes, float *__restrict__ bounds,
+                                                         int chunks_per_bm) {
+  __shared__ float red[2][4];
+  const ChunkBox *mine = boxes + (long long)blockIdx.x * chunks_per_bm;
+  float a = 0.f, g = 0.f;
+  bool bad = false;
+  for (int i = threadIdx.x; i < chunks_per_bm; i += 256) {
+    const float ca = mine[i].a_max, cg = mine[i].g_max;
+    bad |= !(ca == ca) || !(cg == cg);
+    a = fmaxf(a, ca);
+    g = fmaxf(g, cg);
+  }
+  if (bad) a = g = __int_as_float(0x7FC00000);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float oa = __shfl_xor(a, o), og = __shfl_xor(g, o);
+    a = (oa != oa || a != a) ? __int_as_float(0x7FC00000) : fmaxf(a, oa);
+    g = (og != og || g != g) ? __int_as_float(0x7FC00000) : fmaxf(g, og);
+  }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = g; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      a = (red[0][w] != red[0][w] || a != a) ? __int_as_float(0x7FC00000) : fmaxf(a, red[0][w]);
+      g = (red[1][w] != red[1][w] || g != g) ? __int_as_float(0x7FC00000) : fmaxf(g, red[1][w]);
+    }
+    bounds[2 * blockIdx.x] = a;
+    bounds[2 * blockIdx.x + 1] = g;
+  }
+}
+
 __global__ __launch_bounds__(256) void bwd_prep_kernel(
-    const float *__restrict__ loc, const float *__restrict__ attw, const int64_t *__restrict__ shapes,
-    float2 *__restrict__ rec_hw, float *__restrict__ rec_aw, int M, int L, int Lq, int P, long long n) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += stride) {
-    long long t = o;
-    const int p = (int)(t % P); t /= P;
-    const int q = (int)(t % Lq); t /= Lq;
-    const int l = (int)(t % L); t /= L;
-    const int m = (int)(t % M);
-    const long long b = t / M;
-    const long long src = (((b * Lq + q) * M + m) * L + l) * P + p;
-    const float2 xy = *reinterpret_cast<const float2 *>(loc + src * 2);
-    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-    const float h_im = scale_loc(xy.y, H), w_im = scale_loc(xy.x, W);
-    const bool ok = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
-    rec_hw[o] = ok ? make_float2(h_im, w_im) : make_float2(kInvalidCoord, kInvalidCoord);
-    rec_aw[o] = attw[src];
+    const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out,
+    const int64_t *__restrict__ shapes, float2 *__restrict__ rec_hw, float *__restrict__ rec_aw,
+    ChunkBox *__restrict__ boxes, int M, int L, int Lq, int P, int n_chunks_per_list, long long n_lists) {
+  // grid-stride over (list, chunk); a wave handles one chunk
+  const int lane = threadIdx.x & 63;
+  const long long n_pts = (long long)Lq * P;
+  const long long total = n_lists * n_chunks_per_list;
+  const long long wave_stride = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long wc = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wc < total; wc += wave_stride) {
+    const long long list = wc / n_chunks_per_list;          // (b*M + m)*L + l
+    const int chunk = (int)(wc - list * n_chunks_per_list);
+    const int l = (int)(list % L);
+    const long long bm = list / L;
+    const int m = (int)(bm % M);
+    const long long b = bm / M;
+    const long long pt = (long long)chunk * 64 + lane;       // q*P + p inside the list
+    const bool live = pt < n_pts;
+    int y_lo = 32767, y_hi = -32768, x_lo = 32767, x_hi = -32768;
+    float a_abs = 0.f, g_abs = 0.f;
+    if (live) {
+      const int q = (int)(pt / P), p = (int)(pt - (long long)q * P);
+      const long long pair = (b * Lq + q) * M + m;
+      const long long src = (pair * L + l) * P + p;
+      const float2 xy = *reinterpret_cast<const float2 *>(loc + src * 2);
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+      const float h_im = scale_loc(xy.y, H), w_im = scale_loc(xy.x, W);
+      const bool ok = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
+      const float aw = attw[src];
+      rec_hw[list * n_pts + pt] = ok ? make_float2(h_im, w_im) : make_float2(kInvalidCoord, kInvalidCoord);
+      rec_aw[list * n_pts + pt] = aw;
+      if (ok) {
+        const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+        y_lo = h_low; y_hi = h_low + 1; x_lo = w_low; x_hi = w_low + 1;
+      }
+      a_abs = fabsf(aw);
+      // the pair's 32 grad_out channels are shared out over its L*P = 16 points: 2 channels each
+      const float2 go = *reinterpret_cast<const float2 *>(grad_out + pair * 32 + (l * P + p) * 2);
+      g_abs = fmaxf(fabsf(go.x), fabsf(go.y));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      y_lo = min(y_lo, __shfl_xor(y_lo, o)); y_hi = max(y_hi, __shfl_xor(y_hi, o));
+      x_lo = min(x_lo, __shfl_xor(x_lo, o)); x_hi = max(x_hi, __shfl_xor(x_hi, o));
+      a_abs = fmaxf(a_abs, __shfl_xor(a_abs, o));
+      g_abs = fmaxf(g_abs, __shfl_xor(g_abs, o));
+    }
+    if (lane == 0) {
+      ChunkBox bx;
+      bx.y_lo = (short)max(y_lo, -32768); bx.y_hi = (short)min(y_hi, 32767);
+      bx.x_lo = (short)max(x_lo, -32768); bx.x_hi = (short)min(x_hi, 32767);
+      bx.a_max = a_abs;
+      bx.g_max = g_abs;
+      boxes[wc] = bx;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------ K2
-// LDS float atomics (ds_add_f32) are serialised per lane on gfx950 (0.33 lane-adds/clk/CU measured,
-// tools/ubench/lds_atomic*.hip) while ds_add_f64 runs at 3.9 and ds_add_u32 at 11-13: the tile is
-// accumulated in double, which is also more accurate than the reference's float atomics.
-constexpr int kQueue = 128;              // hit queue slots per wave (ring)
+// LDS float atomics (ds_add_f32) are serialised per lane on gfx950: 0.33 lane-adds/clk/CU measured, against
+// 3.9 for ds_add_f64, 7.1 for ds_add_u64 and 11-13 for ds_add_u32 (tools/ubench/lds_atomic*.hip).  The tile
+// is therefore accumulated in 64-bit FIXED POINT: a contribution c = w_corner * attn_w * grad_out is scaled
+// by a power of two chosen from the (batch, head)'s max|attn_w| * max|grad_out| (K1) such that |c| * scale
+// <= 2^kFixBits, rounded once to an integer, and added with ds_add_u64.  Integer sums are exact and
+// order-independent; the result is rounded to float once at write-back.  With up to 2^(62 - kFixBits)
+// contributions per accumulator there is no overflow (the host checks Lq*P against that).
+constexpr int kQueue = 64;               // hit records per wave (one scanned chunk at most)
 constexpr int kScatterThreads = 512;
 constexpr int kScatterWaves = kScatterThreads / 64;
 constexpr int kDrainBatches = 4;         // 8-hit batches whose grad_out rows are fetched together
+constexpr int kFixBits = 42;             // |contribution| <= 2^42 after scaling; sums of < 2^20 terms fit int64
+constexpr unsigned kNoRow = 0xFFFFu;
 
-__device__ __forceinline__ float pick(const float4 &v, int i) {
-  return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
+// round-to-nearest integer of x (|x| < 2^51) as two's-complement int64, by the 1.5 * 2^52 magic constant
+__device__ __forceinline__ unsigned long long to_fixed(double x) {
+  const double magic = 6755399441055744.0;
+  return (unsigned long long)(__double_as_longlong(x + magic) - __double_as_longlong(magic));
 }
 
+// FIXED = true: 64-bit fixed point (ds_add_u64).  FIXED = false: double (ds_add_f64).
+template <bool FIXED>
 __global__ __launch_bounds__(kScatterThreads, 4) void bwd_scatter_kernel(
-    const float2 *__restrict__ rec_hw, const float *__restrict__ rec_aw,
-    const float *__restrict__ grad_out, float *__restrict__ grad_value, const BwdPlan plan, int B, int S,
-    int M, int Lq, int P) {
-  __shared__ double acc[kTileRows * 32];                 // 64 KB
-  __shared__ float4 queue[kScatterWaves][kQueue];        // 16 KB
+    const float2 *__restrict__ rec_hw, const float *__restrict__ rec_aw, const ChunkBox *__restrict__ boxes,
+    const float *__restrict__ bounds, const float *__restrict__ grad_out, float *__restrict__ grad_value,
+    const BwdPlan plan, int B, int S, int M, int Lq, int P, int n_chunks_per_list) {
+  __shared__ unsigned long long acc[kTileRows * 32];     // 64 KB
+  // per wave: hit records {w1..w4 premultiplied by attn_w} , {rows(1,2), rows(3,4), query, -}
+  __shared__ float4 queue[kScatterWaves][kQueue][2];     // 16 KB
 
   // blockIdx -> (batch*head, item); all items of one (batch, head) share blockIdx % 8, i.e. one XCD
   // (speed only: they re-scan the same record lists out of that XCD's L2).
@@ -93,103 +184,159 @@ __global__ __launch_bounds__(kScatterThreads, 4) void bwd_scatter_kernel(
   const int pt_begin = (int)(n_pts * chunk / n_chunks), pt_end = (int)(n_pts * (chunk + 1) / n_chunks);
   const bool exclusive = n_chunks == 1;
 
-  for (int i = threadIdx.x; i < n_rows * 32; i += kScatterThreads) acc[i] = 0.0;
+  for (int i = threadIdx.x; i < n_rows * 32; i += kScatterThreads) acc[i] = 0ull;
   __syncthreads();
+
+  // fixed-point scale of this (batch, head): 2^(kFixBits - ceil(log2(bound)))
+  const float bound = bounds[2 * bm] * bounds[2 * bm + 1];
+  int e2 = 0;
+  (void)frexpf(bound, &e2);                               // bound = f * 2^e2, f in [0.5, 1)  =>  bound <= 2^e2
+  const bool representable = bound > 0.f && bound < 3.0e38f;      // 0, inf or NaN: nothing meaningful to accumulate
+  // scale = 2^(kFixBits - e2) can exceed the float range for tiny bounds: clamp the exponent (coarser than
+  // necessary only when bound < 2^-84, where the values are denormal-scale anyway)
+  const int sh = min(kFixBits - e2, 126);
+  const float scale_f = representable ? ldexpf(1.0f, sh) : 0.f;
+  const double inv_scale = representable ? ldexp(1.0, -sh) : (bound == 0.f ? 0.0 : (double)NAN);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane >> 3, sub = lane & 7;
-  const long long list = ((long long)bm * plan.n_levels + l) * n_pts;        // this level's record list
+  const long long list_id = (long long)bm * plan.n_levels + l;
+  const long long list = list_id * n_pts;                                   // this level's record list
   const float2 *hw_list = rec_hw + list;
   const float *aw_list = rec_aw + list;
+  const ChunkBox *box_list = boxes + list_id * n_chunks_per_list;
   const float *go_base = grad_out + ((long long)b * Lq * M + m) * 32 + sub * 4;     // + q * M*32
-  float4 *myq = queue[wave];
-  int qhead = 0, qtail = 0;
-  // rotate the channel order by the group index: in an LDS pass the groups of a 32-lane half then
-  // touch different banks of every 4-bank quad
+  float4 (*myq)[2] = queue[wave];
+  // rotate the channel order by the group index: in an LDS pass the groups then touch different banks
   const int r0 = grp & 3;
   const int c0 = sub * 4 + r0, c1 = sub * 4 + ((r0 + 1) & 3), c2 = sub * 4 + ((r0 + 2) & 3),
             c3 = sub * 4 + ((r0 + 3) & 3);
 
-  // Adds up to NB x 8 queued hits into the LDS tile, one hit per 8-lane group and batch; the
-  // grad_out rows of all batches are requested before the first is consumed.
-  auto drain = [&](const int nb) {
-    float4 rec[kDrainBatches], g[kDrainBatches];
+  // Adds the queued hits [first, n) into the LDS tile, one hit per 8-lane group and batch; the grad_out rows
+  // of up to kDrainBatches batches are requested before the first is consumed.  The scanning lane has already
+  // resolved the tap: a record holds the four corner weights (times attn_w) and the LDS rows they go to.
+  auto drain = [&](const int first, const int n) {
+    float4 wts[kDrainBatches], meta[kDrainBatches], g[kDrainBatches];
     bool active[kDrainBatches];
 #pragma unroll
     for (int k = 0; k < kDrainBatches; ++k) {
-      active[k] = (k < nb) && (qhead + 8 * k + grp) < qtail;
-      rec[k] = myq[(qhead + 8 * k + grp) & (kQueue - 1)];
-      const int q = __float_as_int(rec[k].w) / P;
-      g[k] = active[k] ? ld4(go_base + (long long)q * M * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int slot = first + 8 * k + grp;
+      active[k] = slot < n;
+      wts[k] = myq[slot & (kQueue - 1)][0];
+      meta[k] = myq[slot & (kQueue - 1)][1];
+      g[k] = active[k] ? ld4(go_base + (long long)__float_as_int(meta[k].z) * M * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    qhead += 8 * nb;
 #pragma unroll
     for (int k = 0; k < kDrainBatches; ++k) {
       if (!active[k]) continue;
-      const Tap<float> tp = make_tap_im(rec[k].x, rec[k].y, H, W);
-      const float aw = rec[k].z;
-      const float t0 = pick(g[k], r0) * aw, t1 = pick(g[k], (r0 + 1) & 3) * aw;
-      const float t2 = pick(g[k], (r0 + 2) & 3) * aw, t3 = pick(g[k], (r0 + 3) & 3) * aw;
-      const int ry0 = tp.y0 - y0, ry1 = tp.y1 - y0, rx0 = tp.x0 - x0, rx1 = tp.x1 - x0;
-      const bool iy0 = tp.t && (unsigned)ry0 < (unsigned)th, iy1 = tp.b && (unsigned)ry1 < (unsigned)th;
-      const bool ix0 = tp.l && (unsigned)rx0 < (unsigned)tw, ix1 = tp.r && (unsigned)rx1 < (unsigned)tw;
-      auto add_row = [&](int ry, int rx, float w) {
-        double *row = acc + (ry * tw + rx) * 32;
-        atomicAdd(row + c0, (double)(w * t0));
-        atomicAdd(row + c1, (double)(w * t1));
-        atomicAdd(row + c2, (double)(w * t2));
-        atomicAdd(row + c3, (double)(w * t3));
+      const float g0 = r0 == 0 ? g[k].x : (r0 == 1 ? g[k].y : (r0 == 2 ? g[k].z : g[k].w));
+      const float g1 = r0 == 0 ? g[k].y : (r0 == 1 ? g[k].z : (r0 == 2 ? g[k].w : g[k].x));
+      const float g2 = r0 == 0 ? g[k].z : (r0 == 1 ? g[k].w : (r0 == 2 ? g[k].x : g[k].y));
+      const float g3 = r0 == 0 ? g[k].w : (r0 == 1 ? g[k].x : (r0 == 2 ? g[k].y : g[k].z));
+      const unsigned rows12 = (unsigned)__float_as_int(meta[k].x), rows34 = (unsigned)__float_as_int(meta[k].y);
+      auto add_row = [&](unsigned r, float w) {
+        if (r == kNoRow) return;                        // corner outside the level or owned by another tile
+        unsigned long long *row = acc + r * 32;
+        if (FIXED) {
+          // power-of-two scaling is exact in float (|c| * scale <= 2^42); one conversion, one rounding
+          const float ws = w * scale_f;
+          atomicAdd(row + c0, to_fixed((double)(ws * g0)));
+          atomicAdd(row + c1, to_fixed((double)(ws * g1)));
+          atomicAdd(row + c2, to_fixed((double)(ws * g2)));
+          atomicAdd(row + c3, to_fixed((double)(ws * g3)));
+        } else {
+          double *drow = reinterpret_cast<double *>(row);
+          atomicAdd(drow + c0, (double)(w * g0));
+          atomicAdd(drow + c1, (double)(w * g1));
+          atomicAdd(drow + c2, (double)(w * g2));
+          atomicAdd(drow + c3, (double)(w * g3));
+        }
       };
-      if (iy0 && ix0) add_row(ry0, rx0, tp.w1);
-      if (iy0 && ix1) add_row(ry0, rx1, tp.w2);
-      if (iy1 && ix0) add_row(ry1, rx0, tp.w3);
-      if (iy1 && ix1) add_row(ry1, rx1, tp.w4);
+      add_row(rows12 & 0xFFFFu, wts[k].x);
+      add_row(rows12 >> 16, wts[k].y);
+      add_row(rows34 & 0xFFFFu, wts[k].z);
+      add_row(rows34 >> 16, wts[k].w);
     }
   };
 
-  const int step = kScatterWaves * 64;
-  int base = pt_begin + wave * 64;
-  float2 hw_next = make_float2(kInvalidCoord, kInvalidCoord);
-  if (base + lane < pt_end) hw_next = hw_list[base + lane];
-  for (; base < pt_end; base += step) {
-    const int idx = base + lane;
-    const float2 hw = hw_next;
-    hw_next = make_float2(kInvalidCoord, kInvalidCoord);
-    if (idx + step < pt_end) hw_next = hw_list[idx + step];          // prefetch the next slice
-    const int h_low = (int)floorf(hw.x), w_low = (int)floorf(hw.y);
-    // a corner row/col counts if it lies inside the tile (tiles lie inside the level, so this also
-    // implies the cuh:56-79 bounds checks)
-    const bool row_in = ((unsigned)(h_low - y0) < (unsigned)th) || ((unsigned)(h_low + 1 - y0) < (unsigned)th);
-    const bool col_in = ((unsigned)(w_low - x0) < (unsigned)tw) || ((unsigned)(w_low + 1 - x0) < (unsigned)tw);
-    const bool hit = row_in && col_in;
-    const unsigned long long mask = __ballot(hit);
-    if (hit) {
-      const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-      myq[(qtail + rank) & (kQueue - 1)] = make_float4(hw.x, hw.y, aw_list[idx], __int_as_float(idx));
+  // scan: chunks are dealt round-robin to the 8 waves (chunk c -> wave c % 8); a wave looks at 64 of its chunk
+  // boxes per step and scans only those that touch the tile
+  const int first_chunk = pt_begin >> 6, last_chunk = (pt_end + 63) >> 6;     // [first, last)
+  for (int cbase = first_chunk + wave; cbase < last_chunk; cbase += kScatterWaves * 64) {
+    const int my_chunk = cbase + lane * kScatterWaves;
+    bool touch = false;
+    if (my_chunk < last_chunk) {
+      const ChunkBox bx = box_list[my_chunk];
+      touch = bx.y_lo <= bx.y_hi && bx.y_hi >= y0 && bx.y_lo < y0 + th && bx.x_hi >= x0 && bx.x_lo < x0 + tw;
     }
-    __builtin_amdgcn_wave_barrier();      // queue writes above are read by other lanes of this wave below
-    qtail += __popcll(mask);
-    while (qtail - qhead >= 8 * kDrainBatches) drain(kDrainBatches);
+    unsigned long long todo = __ballot(touch);
+    // software pipeline over the touched chunks: the next chunk's records are in flight while this one is tested
+    auto fetch = [&](unsigned long long bits, float &aw) {
+      float2 hw = make_float2(kInvalidCoord, kInvalidCoord);
+      aw = 0.f;
+      if (bits) {
+        const int idx = (cbase + __builtin_ctzll(bits) * kScatterWaves) * 64 + lane;
+        if (idx >= pt_begin && idx < pt_end) { hw = hw_list[idx]; aw = aw_list[idx]; }
+      }
+      return hw;
+    };
+    float aw_next;
+    float2 hw_next = fetch(todo, aw_next);
+    while (todo) {
+      const int idx = (cbase + __builtin_ctzll(todo) * kScatterWaves) * 64 + lane;
+      todo &= todo - 1;
+      const float2 hw = hw_next;
+      const float aw = aw_next;
+      hw_next = fetch(todo, aw_next);
+      // resolve this lane's point against the tile: which of its corners exist (cuh:56-79) and are owned
+      bool hit = false;
+      float4 wts = make_float4(0.f, 0.f, 0.f, 0.f);
+      unsigned rows12 = 0, rows34 = 0;
+      if (hw.x > kInvalidCoord) {
+        const Tap<float> tp = make_tap_im(hw.x, hw.y, H, W);
+        const int ry0 = tp.y0 - y0, ry1 = tp.y1 - y0, rx0 = tp.x0 - x0, rx1 = tp.x1 - x0;
+        const bool iy0 = tp.t && (unsigned)ry0 < (unsigned)th, iy1 = tp.b && (unsigned)ry1 < (unsigned)th;
+        const bool ix0 = tp.l && (unsigned)rx0 < (unsigned)tw, ix1 = tp.r && (unsigned)rx1 < (unsigned)tw;
+        const unsigned q1 = (iy0 && ix0) ? (unsigned)(ry0 * tw + rx0) : kNoRow, q2 = (iy0 && ix1) ? (unsigned)(ry0 * tw + rx1) : kNoRow;
+        const unsigned q3 = (iy1 && ix0) ? (unsigned)(ry1 * tw + rx0) : kNoRow, q4 = (iy1 && ix1) ? (unsigned)(ry1 * tw + rx1) : kNoRow;
+        hit = (iy0 || iy1) && (ix0 || ix1);
+        rows12 = q1 | (q2 << 16);
+        rows34 = q3 | (q4 << 16);
+        wts = make_float4(tp.w1 * aw, tp.w2 * aw, tp.w3 * aw, tp.w4 * aw);
+      }
+      const unsigned long long mask = __ballot(hit);
+      const int n_hits = __popcll(mask);
+      if (hit) {
+        const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+        myq[rank][0] = wts;
+        myq[rank][1] = make_float4(__int_as_float((int)rows12), __int_as_float((int)rows34), __int_as_float(idx / P), 0.f);
+      }
+      wave_lds_order();                          // records written above are read by other lanes of this wave
+      for (int first = 0; first < n_hits; first += 8 * kDrainBatches) drain(first, n_hits);
+      wave_lds_order();                          // the queue is rewritten by the next chunk
+    }
   }
-  while (qhead < qtail) drain(min(kDrainBatches, (qtail - qhead + 7) / 8));
   __syncthreads();
 
-  // write the tile back (rounded to float once)
+  // write the tile back (converted to float once)
   const long long tok0 = (long long)b * S + plan.start[l];
+  auto to_float = [&](unsigned long long v) {
+    return FIXED ? (float)((double)(long long)v * inv_scale) : (float)__longlong_as_double((long long)v);
+  };
   if (exclusive) {
     for (int r = threadIdx.x >> 3; r < n_rows; r += kScatterThreads / 8) {
       const int ry = r / tw, rx = r - ry * tw;
       float *dst = grad_value + ((tok0 + (long long)(y0 + ry) * W + (x0 + rx)) * M + m) * 32 + sub * 4;
-      const double *a = acc + r * 32 + sub * 4;
-      st4(dst, make_float4((float)a[0], (float)a[1], (float)a[2], (float)a[3]));
+      const unsigned long long *a = acc + r * 32 + sub * 4;
+      st4(dst, make_float4(to_float(a[0]), to_float(a[1]), to_float(a[2]), to_float(a[3])));
     }
   } else {
     const int ch = threadIdx.x & 31;
     for (int r = threadIdx.x >> 5; r < n_rows; r += kScatterThreads / 32) {
-      const float v = (float)acc[r * 32 + ch];
+      const unsigned long long raw = acc[r * 32 + ch];
       const int ry = r / tw, rx = r - ry * tw;
-      if (v != 0.f)
-        atomicAdd(grad_value + ((tok0 + (long long)(y0 + ry) * W + (x0 + rx)) * M + m) * 32 + ch, v);
+      if (raw != 0ull || (FIXED && !representable))
+        atomicAdd(grad_value + ((tok0 + (long long)(y0 + ry) * W + (x0 + rx)) * M + m) * 32 + ch, to_float(raw));
     }
   }
 }

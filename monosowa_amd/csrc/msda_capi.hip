@@ -67,6 +67,13 @@ bool make_gather_geom(const int64_t *shapes_host, const int64_t *lsi_host, int B
 
 // MSDA_GATHER = 0: first-generation gather kernels; 1: tap records; 2 (default): records + coarse levels in LDS.
 // A tuning / A-B switch only; every mode computes the same function.
+// MSDA_SCATTER_FIXED = 1: 64-bit fixed-point tile accumulators (ds_add_u64, order-independent sums);
+// 0: double accumulators (ds_add_f64).  A-B switch, same function either way.
+inline bool scatter_fixed_point() {
+  static const bool on = [] { const char *e = std::getenv("MSDA_SCATTER_FIXED"); return e ? std::atoi(e) != 0 : true; }();
+  return on;
+}
+
 inline int gather_mode() {
   static const int mode = [] { const char *e = std::getenv("MSDA_GATHER"); return e ? std::atoi(e) : 2; }();
   return mode;
@@ -110,9 +117,24 @@ inline bool tiled_backward_applies(int elem_bytes, int D, int L, int P) {
   return elem_bytes == 4 && D == 32 && L == 4 && P == 4 && L <= msda::kMaxLevels;
 }
 
-inline size_t tiled_workspace_bytes(int B, int M, int L, int Lq, int P) {
-  return (size_t)B * M * L * Lq * P * 12;      // {h_im, w_im} + {attn_w} per sampling point
+inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+// workspace layout: [rec_hw: 8 B/point][rec_aw: 4 B/point][chunk boxes: 8 B per 64 points][bounds: 2 floats per (b, m)]
+struct TiledWorkspace {
+  size_t n_points, n_chunks_per_list, n_lists, off_aw, off_boxes, off_bounds, bytes;
+};
+inline TiledWorkspace tiled_workspace(int B, int M, int L, int Lq, int P) {
+  TiledWorkspace w;
+  w.n_lists = (size_t)B * M * L;
+  w.n_points = w.n_lists * Lq * P;
+  w.n_chunks_per_list = ((size_t)Lq * P + 63) / 64;
+  w.off_aw = align256(w.n_points * 8);
+  w.off_boxes = align256(w.off_aw + w.n_points * 4);
+  w.off_bounds = align256(w.off_boxes + w.n_lists * w.n_chunks_per_list * sizeof(msda::ChunkBox));
+  w.bytes = w.off_bounds + align256((size_t)B * M * 2 * sizeof(float));
+  return w;
 }
+inline size_t tiled_workspace_bytes(int B, int M, int L, int Lq, int P) { return tiled_workspace(B, M, L, Lq, P).bytes; }
 
 // Tiling of every level for the tile-owner scatter (msda_backward_tiled.hip, K2).
 msda::BwdPlan make_plan(const int64_t *shapes_host, const int64_t *lsi_host, int L, int Lq, int P) {
@@ -184,11 +206,20 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       }
       if (tokens != S) return MSDA_E_SHAPE;
       const msda::BwdPlan plan = make_plan(shapes_host, lsi_host, L, Lq, P);
-      float2 *rec_hw = reinterpret_cast<float2 *>(workspace);
-      float *rec_aw = reinterpret_cast<float *>(rec_hw + (size_t)B * M * L * Lq * P);
-      const long long n_rec = (long long)B * M * L * Lq * P;
-      msda::bwd_prep_kernel<<<grid_for(n_rec, 256), 256, 0, stream>>>(loc, attw, shapes, rec_hw, rec_aw, M, L,
-                                                                        Lq, P, n_rec);
+      if ((long long)Lq * P >= (1LL << (62 - msda::kFixBits))) return MSDA_E_SHAPE;   // fixed-point headroom
+      for (int l = 0; l < L; ++l)
+        if (shapes_host[2 * l] > 32000 || shapes_host[2 * l + 1] > 32000) return MSDA_E_SHAPE;   // 16-bit chunk boxes
+      const TiledWorkspace ws = tiled_workspace(B, M, L, Lq, P);
+      char *wsp = reinterpret_cast<char *>(workspace);
+      float2 *rec_hw = reinterpret_cast<float2 *>(wsp);
+      float *rec_aw = reinterpret_cast<float *>(wsp + ws.off_aw);
+      msda::ChunkBox *boxes = reinterpret_cast<msda::ChunkBox *>(wsp + ws.off_boxes);
+      float *bounds = reinterpret_cast<float *>(wsp + ws.off_bounds);
+      const long long n_wave_chunks = (long long)ws.n_lists * ws.n_chunks_per_list;
+      msda::bwd_prep_kernel<<<grid_for(n_wave_chunks, 4), 256, 0, stream>>>(
+          loc, attw, grad_out, shapes, rec_hw, rec_aw, boxes, M, L, Lq, P, (int)ws.n_chunks_per_list,
+          (long long)ws.n_lists);
+      msda::bwd_bounds_kernel<<<B * M, 256, 0, stream>>>(boxes, bounds, (int)(L * ws.n_chunks_per_list));
       // levels shared by several workgroups are accumulated with atomics: zero exactly those rows
       for (int l = 0; l < L; ++l) {
         if (plan.n_chunks[l] == 1) continue;
@@ -197,8 +228,12 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         if (e != hipSuccess) return (int)e;
       }
       const int bm_groups = (B * M + 7) / 8;
-      msda::bwd_scatter_kernel<<<8 * plan.n_items * bm_groups, msda::kScatterThreads, 0, stream>>>(
-          rec_hw, rec_aw, grad_out, grad_value, plan, B, S, M, Lq, P);
+      if (scatter_fixed_point())
+        msda::bwd_scatter_kernel<true><<<8 * plan.n_items * bm_groups, msda::kScatterThreads, 0, stream>>>(
+            rec_hw, rec_aw, boxes, bounds, grad_out, grad_value, plan, B, S, M, Lq, P, (int)ws.n_chunks_per_list);
+      else
+        msda::bwd_scatter_kernel<false><<<8 * plan.n_items * bm_groups, msda::kScatterThreads, 0, stream>>>(
+            rec_hw, rec_aw, boxes, bounds, grad_out, grad_value, plan, B, S, M, Lq, P, (int)ws.n_chunks_per_list);
       msda::GatherGeom geom;
       const bool can_stage = make_gather_geom(shapes_host, lsi_host, B, M, Lq, S, geom);
       if (gather_mode() > 1 && can_stage) {

@@ -70,6 +70,16 @@ __device__ __forceinline__ long long xcd_chunked_block(long long n_blocks_padded
   return (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
 }
 
+// Ordering point for wave-private LDS hand-offs (lane A writes, lane B of the SAME wave reads): the LDS
+// executes one wave's instructions in order, so only the compiler has to be kept from moving accesses
+// across.  (A wavefront-scope release/acquire fence would also emit s_waitcnt vmcnt(0) lgkmcnt(0) and drain
+// every prefetch and LDS atomic in flight -- measured: +40 % on the scatter kernel.)
+__device__ __forceinline__ void wave_lds_order() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 

@@ -35,12 +35,6 @@ struct GatherGeom {
   int n_chunks;                            // query slices per (batch, head) (staged variants)
 };
 
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 template <int CTRL>
 __device__ __forceinline__ float dpp_x(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
@@ -138,7 +132,7 @@ void gather_rec_kernel(
         r[3] = make_float4(-sy * tp.hw * k1, -sy * tp.lw * k2, sy * tp.hw * k3, sy * tp.lw * k4);
       }
     }
-    wave_lds_fence();
+    wave_lds_order();
 
     // ---- phase 2: stream the pair's 16 records ------------------------------------------------------
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -217,7 +211,7 @@ void gather_rec_kernel(
       st4(grad_loc + pair * 32 + sub * 4, out_loc);
       *reinterpret_cast<float2 *>(grad_attw + pair * 16 + sub * 2) = out_aw;
     }
-    wave_lds_fence();          // records are rewritten by the next iteration
+    wave_lds_order();          // records are rewritten by the next iteration
   }
 }
 
