@@ -60,6 +60,11 @@ extern "C" {
 int msda_abi_version(void);
 const char *msda_strerror(int code);
 
+/* Kernel-generation switches for A/B measurements and tests (process-wide; not thread-safe against
+ * concurrent launches).  "gather": 0 | 1 | 2 (default 2), "scatter_fixed": 0 | 1 (default 1).  Every setting
+ * computes the same function.  Returns 0, or MSDA_E_UNSUPPORTED for an unknown name / value. */
+int msda_set_option(const char *name, int value);
+
 /* Bytes of device scratch the backward needs for this geometry (0 if none); the caller allocates
  * it (any alignment >= 16) and passes it to msda_backward_*; it may be NULL when the answer is 0.
  * Contents need not be preserved between calls. */

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmonosowa_msda.so")
 
 # every symbol include/monosowa_msda.h declares
-SYMBOLS = ("msda_abi_version", "msda_strerror", "msda_backward_workspace_bytes",
+SYMBOLS = ("msda_abi_version", "msda_strerror", "msda_set_option", "msda_backward_workspace_bytes",
            "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64")
 
 _lib = None
@@ -31,6 +31,8 @@ def load():
     lib.msda_abi_version.restype = I
     lib.msda_strerror.restype = ctypes.c_char_p
     lib.msda_strerror.argtypes = [I]
+    lib.msda_set_option.restype = I
+    lib.msda_set_option.argtypes = [ctypes.c_char_p, I]
     lib.msda_backward_workspace_bytes.restype = Z
     lib.msda_backward_workspace_bytes.argtypes = [I] * 8
     for suf in ("f32", "f64"):
@@ -49,3 +51,7 @@ def load():
 def check(code, what):
     if code != 0:
         raise RuntimeError("%s failed: %s (code %d)" % (what, load().msda_strerror(code).decode(), code))
+
+
+def set_option(name, value):
+    check(load().msda_set_option(name.encode(), int(value)), "msda_set_option(%s, %s)" % (name, value))

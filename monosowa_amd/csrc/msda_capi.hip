@@ -8,6 +8,7 @@
 #include "msda_backward_tiled.hip"
 #include "msda_gather_rec.hip"
 #include <cstdlib>
+#include <string>
 #include <algorithm>
 #include <vector>
 
@@ -67,17 +68,24 @@ bool make_gather_geom(const int64_t *shapes_host, const int64_t *lsi_host, int B
 
 // MSDA_GATHER = 0: first-generation gather kernels; 1: tap records; 2 (default): records + coarse levels in LDS.
 // A tuning / A-B switch only; every mode computes the same function.
-// MSDA_SCATTER_FIXED = 1: 64-bit fixed-point tile accumulators (ds_add_u64, order-independent sums);
-// 0: double accumulators (ds_add_f64).  A-B switch, same function either way.
-inline bool scatter_fixed_point() {
-  static const bool on = [] { const char *e = std::getenv("MSDA_SCATTER_FIXED"); return e ? std::atoi(e) != 0 : true; }();
-  return on;
+// Kernel-generation switches (A/B measurement and test coverage; every setting computes the same function).
+//   gather        0: first-generation gather kernels, 1: tap records, 2 (default): records + coarse levels in LDS
+//   scatter_fixed 1 (default): 64-bit fixed-point tile accumulators (ds_add_u64), 0: double (ds_add_f64)
+// Initialised from MSDA_GATHER / MSDA_SCATTER_FIXED, changed at run time with msda_set_option().
+struct Options {
+  int gather = 2;
+  int scatter_fixed = 1;
+  Options() {
+    if (const char *e = std::getenv("MSDA_GATHER")) gather = std::atoi(e);
+    if (const char *e = std::getenv("MSDA_SCATTER_FIXED")) scatter_fixed = std::atoi(e) != 0;
+  }
+};
+inline Options &options() {
+  static Options o;
+  return o;
 }
-
-inline int gather_mode() {
-  static const int mode = [] { const char *e = std::getenv("MSDA_GATHER"); return e ? std::atoi(e) : 2; }();
-  return mode;
-}
+inline bool scatter_fixed_point() { return options().scatter_fixed != 0; }
+inline int gather_mode() { return options().gather; }
 
 template <typename T>
 int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc,
@@ -263,6 +271,14 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
 extern "C" {
 
 int msda_abi_version(void) { return MSDA_ABI_VERSION; }
+
+int msda_set_option(const char *name, int value) {
+  if (!name) return MSDA_E_NULLPTR;
+  const std::string n(name);
+  if (n == "gather" && value >= 0 && value <= 2) { options().gather = value; return 0; }
+  if (n == "scatter_fixed" && (value == 0 || value == 1)) { options().scatter_fixed = value; return 0; }
+  return MSDA_E_UNSUPPORTED;
+}
 
 const char *msda_strerror(int code) {
   switch (code) {

@@ -260,3 +260,50 @@ def test_eval_forward_replays_from_a_hipgraph():
         eager2 = model(inputs2, calibs2, None, targets2["img_size"])
     out2 = g(inputs2, calibs2, targets2["img_size"])
     assert torch.allclose(out2["pred_boxes"], eager2["pred_boxes"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("gather,fixed", [(0, 0), (1, 1), (2, 0), (2, 1)])
+def test_every_kernel_generation_computes_the_same_function(gather, fixed):
+    """The earlier kernel generations stay selectable (msda_set_option) for A/B measurements; all of them must
+    pass the same parity bar on the shipped geometry (encoder-like and decoder-like query sets)."""
+    from monosowa_amd import _lib
+    try:
+        _lib.set_option("gather", gather)
+        _lib.set_option("scatter_fixed", fixed)
+        for B, Lq, levels in ((2, 1275, [(24, 40), (12, 20), (6, 10), (3, 5)]), (2, 550, [(12, 40), (6, 20), (3, 10), (2, 5)])):
+            value, shapes, lsi, loc, w, go = _random_case(gather * 7 + fixed, B, 8, 32, Lq, levels, 4, np.float32)
+            want, want64 = _oracle_want(value, shapes, lsi, loc, w, go)
+            MSDA = _msda()
+            s = _dev(shapes)
+            starts = [0]
+            for h, wd in levels[:-1]:
+                starts.append(starts[-1] + h * wd)
+            MSDA.attach_host_geometry(s, _dev(lsi), levels, starts)           # lets the forward use the planned kernels
+            v, i, lc, ww, g = map(_dev, (value, lsi, loc, w, go))
+            out = MSDA.ms_deform_attn_forward(v, s, i, lc, ww, 64)
+            gv, gl, gw = MSDA.ms_deform_attn_backward(v, s, i, lc, ww, g, 64)
+            for got, ref, name in ((out, want[0], "out"), (gv, want[1], "grad_value"), (gl, want[2], "grad_loc"), (gw, want[3], "grad_attw")):
+                _close(got, ref, 1e-4, "%s (gather=%d fixed=%d)" % (name, gather, fixed))
+            _close(gv, want64[1], 1e-4, "grad_value vs f64")
+    finally:
+        _lib.set_option("gather", 2)
+        _lib.set_option("scatter_fixed", 1)
+    with pytest.raises(RuntimeError):
+        _lib.set_option("no_such_option", 1)
+
+
+def test_fixed_point_scatter_keeps_small_rows_accurate_under_outliers():
+    """grad_out with one 1e6 outlier: the fixed-point accumulators are scaled per (batch, head) from max|grad_out|,
+    rows far from the outlier must still match the f64 oracle to float precision relative to their own scale."""
+    B, M, D, Lq, levels, P = 1, 8, 32, 300, [(12, 40), (6, 20), (3, 10), (2, 5)], 4
+    value, shapes, lsi, loc, w, go = _random_case(77, B, M, D, Lq, levels, P, np.float32, 0.05, 0.95)
+    go = go.reshape(B, Lq, M, D)
+    go[0, 0, 0, :] = 1e6                                    # head 0 only
+    go = go.reshape(B, Lq, M * D)
+    d = lambda a: a.astype(np.float64)
+    ref = O.backward(d(value), shapes, lsi, d(loc), d(w), d(go))[0]
+    MSDA = _msda()
+    gv = MSDA.ms_deform_attn_backward(*map(_dev, (value, shapes, lsi, loc, w, go)), 64)[0].cpu().numpy().astype(np.float64)
+    other = ref[:, :, 1:, :]                                # heads without the outlier: own scale
+    assert np.abs(gv[:, :, 1:, :] - other).max() <= 1e-5 * np.abs(other).max()
+    assert np.abs(gv[:, :, 0, :] - ref[:, :, 0, :]).max() <= 1e-5 * np.abs(ref[:, :, 0, :]).max()

@@ -58,7 +58,8 @@ for (k, grid), cs in sorted(msda.items()):
 by_kernel = defaultdict(list)
 for (k, grid), cs in msda.items():
     by_kernel[k].append((int(grid), k, grid))
-ops = {"msda_fwd": ["fwd_d32_kernel"], "msda_bwd": ["bwd_prep_kernel", "bwd_scatter_kernel", "bwd_gather_kernel"]}
+ops = {"msda_fwd": ["fwd_d32_kernel", "gather_rec_kernel<false"],
+       "msda_bwd": ["bwd_prep_kernel", "bwd_bounds_kernel", "bwd_scatter_kernel", "bwd_gather_kernel", "gather_rec_kernel<true"]}
 for shape_i, tag in ((-1, "Lq10200_B16"), (0, "Lq550_B16")):
     for op, names in ops.items():
         tot = 0.0
