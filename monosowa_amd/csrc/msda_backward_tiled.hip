@@ -31,10 +31,10 @@ namespace msda {
 constexpr float kInvalidCoord = -8.0f;   // floor() = -8: no corner can fall inside any tile
 
 // ------------------------------------------------------------------------------------------ K1
-// one thread per output record; rec index o = (((b*M + m)*L + l)*Lq + q)*P + p.  A wave covers 64
-// consecutive records of one (b, m, l) list = one "chunk": it also emits the chunk's bounding box of corner
-// pixels (so that tile workgroups can skip whole chunks) and folds max|attn_w|, max|grad_out| of its
-// (batch, head) into bounds[bm] (scale of the fixed-point accumulators in K2).
+// record index o = (((b*M + m)*L + l)*Lq + q)*P + p.  64 consecutive records of one (b, m, l) list = one
+// "chunk" (16 queries): K1 also emits the chunk's bounding box of corner pixels (so that tile workgroups can
+// skip whole chunks) and its max|attn_w|, max|grad_out| (K1b folds those per (batch, head): the scale of the
+// fixed-point accumulators in K2).
 struct ChunkBox {
   short y_lo, y_hi, x_lo, x_hi;      // inclusive corner-pixel ranges; empty: y_lo > y_hi
   float a_max, g_max;                // max|attn_w|, max|grad_out| seen by the chunk (folded per (b, m) by K1b)
@@ -73,61 +73,75 @@ __global__ __launch_bounds__(256) void bwd_bounds_kernel(const ChunkBox *__restr
   }
 }
 
-__global__ __launch_bounds__(256) void bwd_prep_kernel(
+// Workgroup = (batch, 16 consecutive queries) x all (head, level) lists: thread t serves list t / 8 and the
+// two queries 2*(t % 8), +1.  The 16 queries' loc / attn_w / grad_out are 16 KB / 8 KB / 16 KB contiguous
+// blocks read in 256-byte runs, every list receives one 64-point chunk = 512 contiguous bytes, and the chunk
+// box is an 8-lane reduction.  (The first version walked list-major and fetched 3.3x its input.)
+template <int P>
+__global__ __launch_bounds__(1024) void bwd_prep_kernel(
     const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out,
     const int64_t *__restrict__ shapes, float2 *__restrict__ rec_hw, float *__restrict__ rec_aw,
-    ChunkBox *__restrict__ boxes, int M, int L, int Lq, int P, int n_chunks_per_list, long long n_lists) {
-  // grid-stride over (list, chunk); a wave handles one chunk
-  const int lane = threadIdx.x & 63;
+    ChunkBox *__restrict__ boxes, int M, int L, int Lq, int n_chunks_per_list) {
+  static_assert(P == 4, "one float4 of attention weights / two float4 of locations per (query, head, level)");
+  const int chunk = blockIdx.x % n_chunks_per_list;
+  const long long b = blockIdx.x / n_chunks_per_list;
+  const int ml = threadIdx.x >> 3;                   // m * L + l
+  const int j = threadIdx.x & 7;
+  const int m = ml / L, l = ml - m * L;
   const long long n_pts = (long long)Lq * P;
-  const long long total = n_lists * n_chunks_per_list;
-  const long long wave_stride = (long long)gridDim.x * (blockDim.x >> 6);
-  for (long long wc = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); wc < total; wc += wave_stride) {
-    const long long list = wc / n_chunks_per_list;          // (b*M + m)*L + l
-    const int chunk = (int)(wc - list * n_chunks_per_list);
-    const int l = (int)(list % L);
-    const long long bm = list / L;
-    const int m = (int)(bm % M);
-    const long long b = bm / M;
-    const long long pt = (long long)chunk * 64 + lane;       // q*P + p inside the list
-    const bool live = pt < n_pts;
-    int y_lo = 32767, y_hi = -32768, x_lo = 32767, x_hi = -32768;
-    float a_abs = 0.f, g_abs = 0.f;
-    if (live) {
-      const int q = (int)(pt / P), p = (int)(pt - (long long)q * P);
-      const long long pair = (b * Lq + q) * M + m;
-      const long long src = (pair * L + l) * P + p;
-      const float2 xy = *reinterpret_cast<const float2 *>(loc + src * 2);
-      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-      const float h_im = scale_loc(xy.y, H), w_im = scale_loc(xy.x, W);
+  const long long list = (b * M + m) * L + l;
+  const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+  int y_lo = 32767, y_hi = -32768, x_lo = 32767, x_hi = -32768;
+  float a_abs = 0.f, g_abs = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int q = chunk * 16 + 2 * j + k;
+    if (q >= Lq) continue;
+    const long long pair = (b * Lq + q) * M + m;
+    const float *lp = loc + (pair * L + l) * P * 2;
+    const float4 xy01 = ld4(lp), xy23 = ld4(lp + 4);
+    const float4 aw = ld4(attw + (pair * L + l) * P);
+    const float4 g0 = ld4(grad_out + pair * 32 + l * 8), g1 = ld4(grad_out + pair * 32 + l * 8 + 4);
+    const float xs[4] = {xy01.x, xy01.z, xy23.x, xy23.z}, ys[4] = {xy01.y, xy01.w, xy23.y, xy23.w};
+    float2 hw[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float h_im = scale_loc(ys[p], H), w_im = scale_loc(xs[p], W);
       const bool ok = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
-      const float aw = attw[src];
-      rec_hw[list * n_pts + pt] = ok ? make_float2(h_im, w_im) : make_float2(kInvalidCoord, kInvalidCoord);
-      rec_aw[list * n_pts + pt] = aw;
+      hw[p] = ok ? make_float2(h_im, w_im) : make_float2(kInvalidCoord, kInvalidCoord);
       if (ok) {
         const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-        y_lo = h_low; y_hi = h_low + 1; x_lo = w_low; x_hi = w_low + 1;
+        y_lo = min(y_lo, h_low); y_hi = max(y_hi, h_low + 1);
+        x_lo = min(x_lo, w_low); x_hi = max(x_hi, w_low + 1);
       }
-      a_abs = fabsf(aw);
-      // the pair's 32 grad_out channels are shared out over its L*P = 16 points: 2 channels each
-      const float2 go = *reinterpret_cast<const float2 *>(grad_out + pair * 32 + (l * P + p) * 2);
-      g_abs = fmaxf(fabsf(go.x), fabsf(go.y));
     }
+    float4 *dst = reinterpret_cast<float4 *>(rec_hw + list * n_pts + (long long)q * P);
+    dst[0] = make_float4(hw[0].x, hw[0].y, hw[1].x, hw[1].y);
+    dst[1] = make_float4(hw[2].x, hw[2].y, hw[3].x, hw[3].y);
+    st4(rec_aw + list * n_pts + (long long)q * P, aw);
+    // fmaxf would drop a NaN: keep it so that it poisons the bound
+    const float av[4] = {aw.x, aw.y, aw.z, aw.w};
+    const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      y_lo = min(y_lo, __shfl_xor(y_lo, o)); y_hi = max(y_hi, __shfl_xor(y_hi, o));
-      x_lo = min(x_lo, __shfl_xor(x_lo, o)); x_hi = max(x_hi, __shfl_xor(x_hi, o));
-      a_abs = fmaxf(a_abs, __shfl_xor(a_abs, o));
-      g_abs = fmaxf(g_abs, __shfl_xor(g_abs, o));
-    }
-    if (lane == 0) {
-      ChunkBox bx;
-      bx.y_lo = (short)max(y_lo, -32768); bx.y_hi = (short)min(y_hi, 32767);
-      bx.x_lo = (short)max(x_lo, -32768); bx.x_hi = (short)min(x_hi, 32767);
-      bx.a_max = a_abs;
-      bx.g_max = g_abs;
-      boxes[wc] = bx;
-    }
+    for (int i = 0; i < 4; ++i) a_abs = (av[i] != av[i]) ? av[i] : fmaxf(a_abs, fabsf(av[i]));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g_abs = (gv[i] != gv[i]) ? gv[i] : fmaxf(g_abs, fabsf(gv[i]));
+  }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) {                  // the 8 threads of a list are adjacent lanes
+    y_lo = min(y_lo, __shfl_xor(y_lo, o)); y_hi = max(y_hi, __shfl_xor(y_hi, o));
+    x_lo = min(x_lo, __shfl_xor(x_lo, o)); x_hi = max(x_hi, __shfl_xor(x_hi, o));
+    const float oa = __shfl_xor(a_abs, o), og = __shfl_xor(g_abs, o);
+    a_abs = (oa != oa || a_abs != a_abs) ? __int_as_float(0x7FC00000) : fmaxf(a_abs, oa);
+    g_abs = (og != og || g_abs != g_abs) ? __int_as_float(0x7FC00000) : fmaxf(g_abs, og);
+  }
+  if (j == 0) {
+    ChunkBox bx;
+    bx.y_lo = (short)max(y_lo, -32768); bx.y_hi = (short)min(y_hi, 32767);
+    bx.x_lo = (short)max(x_lo, -32768); bx.x_hi = (short)min(x_hi, 32767);
+    bx.a_max = a_abs;
+    bx.g_max = g_abs;
+    boxes[list * n_chunks_per_list + chunk] = bx;
   }
 }
 

@@ -124,6 +124,7 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
 inline bool tiled_backward_applies(int elem_bytes, int D, int L, int P) {
   return elem_bytes == 4 && D == 32 && L == 4 && P == 4 && L <= msda::kMaxLevels;
 }
+// K1 runs M * L * 8 threads per workgroup
 
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
@@ -194,7 +195,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
   const long long n_pairs = (long long)B * Lq * M;
 
   if constexpr (sizeof(T) == 4) {
-    if (tiled_backward_applies(4, D, L, P)) {
+    if (tiled_backward_applies(4, D, L, P) && M * L * 8 <= 1024) {
       const size_t need = tiled_workspace_bytes(B, M, L, Lq, P);
       if (!workspace || workspace_bytes < need) return MSDA_E_WORKSPACE;
       int64_t host_geom[3 * msda::kMaxLevels];
@@ -223,10 +224,8 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       float *rec_aw = reinterpret_cast<float *>(wsp + ws.off_aw);
       msda::ChunkBox *boxes = reinterpret_cast<msda::ChunkBox *>(wsp + ws.off_boxes);
       float *bounds = reinterpret_cast<float *>(wsp + ws.off_bounds);
-      const long long n_wave_chunks = (long long)ws.n_lists * ws.n_chunks_per_list;
-      msda::bwd_prep_kernel<<<grid_for(n_wave_chunks, 4), 256, 0, stream>>>(
-          loc, attw, grad_out, shapes, rec_hw, rec_aw, boxes, M, L, Lq, P, (int)ws.n_chunks_per_list,
-          (long long)ws.n_lists);
+      msda::bwd_prep_kernel<4><<<(unsigned)(B * ws.n_chunks_per_list), M * L * 8, 0, stream>>>(
+          loc, attw, grad_out, shapes, rec_hw, rec_aw, boxes, M, L, Lq, (int)ws.n_chunks_per_list);
       msda::bwd_bounds_kernel<<<B * M, 256, 0, stream>>>(boxes, bounds, (int)(L * ws.n_chunks_per_list));
       // levels shared by several workgroups are accumulated with atomics: zero exactly those rows
       for (int l = 0; l < L; ++l) {
@@ -294,7 +293,7 @@ const char *msda_strerror(int code) {
 size_t msda_backward_workspace_bytes(int B, int S, int M, int D, int L, int Lq, int P, int elem_bytes) {
   (void)S;
   if (B <= 0 || M <= 0 || L <= 0 || Lq <= 0 || P <= 0) return 0;
-  return tiled_backward_applies(elem_bytes, D, L, P) ? tiled_workspace_bytes(B, M, L, Lq, P) : 0;
+  return (tiled_backward_applies(elem_bytes, D, L, P) && M * L * 8 <= 1024) ? tiled_workspace_bytes(B, M, L, Lq, P) : 0;
 }
 
 int msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
