@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 3
+#define MSDA_ABI_VERSION 4
 
 #define MSDA_E_NULLPTR (-1)   /* a required pointer is NULL                        */
 #define MSDA_E_SHAPE (-2)     /* a dimension is <= 0 or exceeds the indexing range */
@@ -93,6 +93,32 @@ int msda_backward_f64(const double *value, const int64_t *shapes, const int64_t 
                       int B, int S, int M, int D, int L, int Lq, int P,
                       const int64_t *shapes_host, const int64_t *level_start_host,
                       void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Fused operator: the pointwise prologue of the reference MODULE,
+ * ops/modules/ms_deform_attn.py:146-155, evaluated inside the kernels so that neither the sampling locations nor
+ * the attention weights make a round trip through HBM:
+ *     attn_w = softmax over the L*P logits of each (query, head)
+ *     loc    = ref[l] + offset / (W_l, H_l)                                           (ref_dim == 2)
+ *            = ref[l][:2] + offset / P * (ref[l][2]+ref[l][3], ref[l][4]+ref[l][5]) * 0.5   (ref_dim == 6)
+ *   offsets [B, Lq, M, L, P, 2]  raw output of the `sampling_offsets` projection
+ *   logits  [B, Lq, M, L, P]     raw output of the `attention_weights` projection
+ *   ref     [B, Lq, L, ref_dim]  per-level reference points (no gradient is produced for them)
+ * The backward returns grad_value, grad_offsets, grad_logits.  Only the fast geometry is supported
+ * (float, D = 32, L = P = 4): anything else returns MSDA_E_UNSUPPORTED and the caller uses the unfused entry
+ * points.  The host copies of the pyramid are required.
+ */
+int msda_fused_forward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                           const float *offsets, const float *logits, const float *ref, int ref_dim, float *out,
+                           int B, int S, int M, int D, int L, int Lq, int P,
+                           const int64_t *shapes_host, const int64_t *level_start_host, void *stream);
+
+int msda_fused_backward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                            const float *offsets, const float *logits, const float *ref, int ref_dim,
+                            const float *grad_out, float *grad_value, float *grad_offsets, float *grad_logits,
+                            int B, int S, int M, int D, int L, int Lq, int P,
+                            const int64_t *shapes_host, const int64_t *level_start_host,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

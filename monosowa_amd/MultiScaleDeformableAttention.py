@@ -22,7 +22,8 @@ import torch
 
 from . import _lib
 
-__all__ = ["ms_deform_attn_forward", "ms_deform_attn_backward", "install", "LaunchTimer"]
+__all__ = ["ms_deform_attn_forward", "ms_deform_attn_backward", "ms_deform_attn_fused_forward",
+           "ms_deform_attn_fused_backward", "fused_supported", "install", "LaunchTimer"]
 
 
 class LaunchTimer:
@@ -174,6 +175,76 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
             e1.record(stream)
     _lib.check(code, "ms_deform_attn_backward")
     return [grad_value, grad_loc, grad_w]
+
+
+def fused_supported(value, spatial_shapes, sampling_offsets, reference_points):
+    """The fused operator covers the shipped geometry: float32 on the GPU, head dim 32, 4 levels x 4 points,
+    reference points without gradient, and a pyramid whose host copy is attached."""
+    return (value.is_cuda and value.dtype == torch.float32 and value.dim() == 4 and value.size(3) == 32
+            and sampling_offsets.dim() == 6 and sampling_offsets.size(3) == 4 and sampling_offsets.size(4) == 4
+            and value.size(2) * 32 <= 1024 and reference_points.size(-1) in (2, 6) and not reference_points.requires_grad
+            and getattr(spatial_shapes, "_msda_host_geometry", None) is not None)
+
+
+def _fused_dims(value, offsets, logits, ref):
+    B, S, M, D = value.shape
+    _, Lq, _, L, P, _ = offsets.shape
+    _assert(tuple(logits.shape) in ((B, Lq, M, L, P), (B, Lq, M, L * P)), "logits shape mismatch")
+    _assert(tuple(ref.shape[:3]) == (B, Lq, L) and ref.size(3) in (2, 6), "reference_points must be [B, Lq, L, 2|6]")
+    for name, t in (("value", value), ("sampling_offsets", offsets), ("attention_logits", logits), ("reference_points", ref)):
+        _assert(t.is_contiguous() and t.is_cuda and t.dtype == torch.float32, "%s must be a contiguous float32 CUDA tensor" % name)
+    return B, S, M, D, L, Lq, P
+
+
+def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, sampling_offsets, attention_logits,
+                                 reference_points):
+    """softmax + sampling-location arithmetic + sampling in one kernel (msda_fused_forward_f32) -> [B, Lq, M*D]."""
+    B, S, M, D, L, Lq, P = _fused_dims(value, sampling_offsets, attention_logits, reference_points)
+    geom = host_geometry(spatial_shapes, level_start_index)
+    out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    timer = LaunchTimer.active
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream()
+        if timer is not None:
+            e0, e1 = timer.bracket("fwd", (B, S, M, D, L, Lq, P))
+            e0.record(stream)
+        code = _lib.load().msda_fused_forward_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_offsets.data_ptr(),
+            attention_logits.data_ptr(), reference_points.data_ptr(), reference_points.size(3), out.data_ptr(),
+            B, S, M, D, L, Lq, P, geom[0], geom[1], stream.cuda_stream)
+        if timer is not None:
+            e1.record(stream)
+    _lib.check(code, "ms_deform_attn_fused_forward")
+    return out
+
+
+def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, sampling_offsets, attention_logits,
+                                  reference_points, grad_output):
+    """-> [grad_value, grad_sampling_offsets, grad_attention_logits]"""
+    B, S, M, D, L, Lq, P = _fused_dims(value, sampling_offsets, attention_logits, reference_points)
+    _assert(grad_output.is_contiguous() and grad_output.numel() == B * Lq * M * D, "grad_output shape mismatch")
+    lib = _lib.load()
+    geom = host_geometry(spatial_shapes, level_start_index)
+    grad_value = torch.empty_like(value)
+    grad_off = torch.empty_like(sampling_offsets)
+    grad_logits = torch.empty_like(attention_logits)
+    ws_bytes = lib.msda_backward_workspace_bytes(B, S, M, D, L, Lq, P, 4)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
+    timer = LaunchTimer.active
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream()
+        if timer is not None:
+            e0, e1 = timer.bracket("bwd", (B, S, M, D, L, Lq, P))
+            e0.record(stream)
+        code = lib.msda_fused_backward_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_offsets.data_ptr(),
+            attention_logits.data_ptr(), reference_points.data_ptr(), reference_points.size(3), grad_output.data_ptr(),
+            grad_value.data_ptr(), grad_off.data_ptr(), grad_logits.data_ptr(), B, S, M, D, L, Lq, P, geom[0], geom[1],
+            ws.data_ptr(), ws_bytes, stream.cuda_stream)
+        if timer is not None:
+            e1.record(stream)
+    _lib.check(code, "ms_deform_attn_fused_backward")
+    return [grad_value, grad_off, grad_logits]
 
 
 def install():

@@ -77,11 +77,15 @@ __global__ __launch_bounds__(256) void bwd_bounds_kernel(const ChunkBox *__restr
 // two queries 2*(t % 8), +1.  The 16 queries' loc / attn_w / grad_out are 16 KB / 8 KB / 16 KB contiguous
 // blocks read in 256-byte runs, every list receives one 64-point chunk = 512 contiguous bytes, and the chunk
 // box is an 8-lane reduction.  (The first version walked list-major and fetched 3.3x its input.)
-template <int P>
+// FUSED: `loc` / `attw` are the raw offsets / logits and `ref` [B, Lq, L, ref_dim] the reference points; the
+// prologue (softmax over the pair's 16 logits, location arithmetic) is evaluated here exactly as in the gather
+// kernels (msda_gather_rec.hip), so K2 scatters with the same locations and weights the forward used.
+template <int P, bool FUSED>
 __global__ __launch_bounds__(1024) void bwd_prep_kernel(
     const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out,
     const int64_t *__restrict__ shapes, float2 *__restrict__ rec_hw, float *__restrict__ rec_aw,
-    ChunkBox *__restrict__ boxes, int M, int L, int Lq, int n_chunks_per_list) {
+    ChunkBox *__restrict__ boxes, const float *__restrict__ ref, int ref_dim, int M, int L, int Lq,
+    int n_chunks_per_list) {
   static_assert(P == 4, "one float4 of attention weights / two float4 of locations per (query, head, level)");
   const int chunk = blockIdx.x % n_chunks_per_list;
   const long long b = blockIdx.x / n_chunks_per_list;
@@ -99,8 +103,34 @@ __global__ __launch_bounds__(1024) void bwd_prep_kernel(
     if (q >= Lq) continue;
     const long long pair = (b * Lq + q) * M + m;
     const float *lp = loc + (pair * L + l) * P * 2;
-    const float4 xy01 = ld4(lp), xy23 = ld4(lp + 4);
-    const float4 aw = ld4(attw + (pair * L + l) * P);
+    float4 xy01 = ld4(lp), xy23 = ld4(lp + 4);
+    float4 aw = ld4(attw + (pair * L + l) * P);
+    if (FUSED) {
+      const float *lg = attw + pair * L * P;                       // the pair's 16 logits
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, lg[i]);
+      // same association as the 8-lane reduction of the gather kernels: (lane pairs) mirror, xor 2, xor 1
+      float e[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) e[i] = expf(lg[i] - mx);
+      float part[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) part[i] = e[2 * i] + e[2 * i + 1];
+      float m1[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m1[i] = part[i] + part[7 - i];
+      float m2[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m2[i] = m1[i] + m1[i ^ 2];
+      const float denom = m2[0] + m2[1];
+      aw = make_float4(e[l * 4] / denom, e[l * 4 + 1] / denom, e[l * 4 + 2] / denom, e[l * 4 + 3] / denom);
+      const RefScale rs = load_ref(ref + ((b * Lq + q) * L + l) * ref_dim, ref_dim, H, W);
+      xy01 = make_float4(loc_from_offset<4>(rs.rx, xy01.x, rs.sx, ref_dim), loc_from_offset<4>(rs.ry, xy01.y, rs.sy, ref_dim),
+                         loc_from_offset<4>(rs.rx, xy01.z, rs.sx, ref_dim), loc_from_offset<4>(rs.ry, xy01.w, rs.sy, ref_dim));
+      xy23 = make_float4(loc_from_offset<4>(rs.rx, xy23.x, rs.sx, ref_dim), loc_from_offset<4>(rs.ry, xy23.y, rs.sy, ref_dim),
+                         loc_from_offset<4>(rs.rx, xy23.z, rs.sx, ref_dim), loc_from_offset<4>(rs.ry, xy23.w, rs.sy, ref_dim));
+    }
     const float4 g0 = ld4(grad_out + pair * 32 + l * 8), g1 = ld4(grad_out + pair * 32 + l * 8 + 4);
     const float xs[4] = {xy01.x, xy01.z, xy23.x, xy23.z}, ys[4] = {xy01.y, xy01.w, xy23.y, xy23.w};
     float2 hw[4];

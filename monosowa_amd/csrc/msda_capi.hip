@@ -87,6 +87,27 @@ inline Options &options() {
 inline bool scatter_fixed_point() { return options().scatter_fixed != 0; }
 inline int gather_mode() { return options().gather; }
 
+// Launch of the record-based gather kernels (forward or the backward's grad_loc / grad_attn_w pass), staged when
+// the tail of the pyramid fits LDS and the option allows it.
+template <bool BWD, bool FUSED>
+void launch_gather(const float *value, const float *loc, const float *attw, const float *grad_out, float *out,
+                   float *grad_loc, float *grad_attw, const float *ref, int ref_dim, const int64_t *shapes_host,
+                   const int64_t *lsi_host, int B, int S, int M, int Lq, hipStream_t stream) {
+  msda::GatherGeom geom;
+  const long long n_pairs = (long long)B * Lq * M;
+  const bool staged = make_gather_geom(shapes_host, lsi_host, B, M, Lq, S, geom) && gather_mode() > 1;
+  if (staged) {
+    const int bm_groups = (B * M + 7) / 8;
+    msda::gather_rec_kernel<BWD, true, FUSED>
+        <<<8 * geom.n_chunks * bm_groups, BWD ? msda::kStagedThreadsBwd : msda::kStagedThreadsFwd, 0, stream>>>(
+            value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, geom, B, S, M, Lq, n_pairs);
+  } else {
+    geom.first_lds_level = 4;
+    msda::gather_rec_kernel<BWD, false, FUSED><<<grid_pairs(n_pairs), msda::kPlainThreads, 0, stream>>>(
+        value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, geom, B, S, M, Lq, n_pairs);
+  }
+}
+
 template <typename T>
 int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc,
                  const T *attw, T *out, int B, int S, int M, int D, int L, int Lq, int P,
@@ -97,18 +118,9 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
   const long long n_pairs = (long long)B * Lq * M;
   if constexpr (sizeof(T) == 4) {
     if (D == 32 && L == 4 && P == 4) {
-      msda::GatherGeom geom;
       if (shapes_host && lsi_host && gather_mode() > 0) {
-        const bool staged = make_gather_geom(shapes_host, lsi_host, B, M, Lq, S, geom) && gather_mode() > 1;
-        if (staged) {
-          const int bm_groups = (B * M + 7) / 8;
-          msda::gather_rec_kernel<false, true><<<8 * geom.n_chunks * bm_groups, msda::kStagedThreadsFwd, 0, stream>>>(
-              value, loc, attw, nullptr, out, nullptr, nullptr, geom, B, S, M, Lq, n_pairs);
-        } else {
-          geom.first_lds_level = 4;
-          msda::gather_rec_kernel<false, false><<<grid_pairs(n_pairs), msda::kPlainThreads, 0, stream>>>(
-              value, loc, attw, nullptr, out, nullptr, nullptr, geom, B, S, M, Lq, n_pairs);
-        }
+        launch_gather<false, false>(value, loc, attw, nullptr, out, nullptr, nullptr, nullptr, 0, shapes_host, lsi_host,
+                                    B, S, M, Lq, stream);
         return (int)hipGetLastError();
       }
       msda::fwd_d32_kernel<4, 4><<<grid_pairs(n_pairs), 256, 0, stream>>>(
@@ -187,7 +199,8 @@ template <typename T>
 int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, const T *loc,
                   const T *attw, const T *grad_out, T *grad_value, T *grad_loc, T *grad_attw,
                   int B, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
-                  const int64_t *lsi_host, void *workspace, size_t workspace_bytes, void *stream_) {
+                  const int64_t *lsi_host, void *workspace, size_t workspace_bytes, void *stream_,
+                  const float *fused_ref = nullptr, int fused_ref_dim = 0) {
   if (!value || !shapes || !lsi || !loc || !attw || !grad_out || !grad_value || !grad_loc || !grad_attw)
     return MSDA_E_NULLPTR;
   if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
@@ -224,8 +237,12 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       float *rec_aw = reinterpret_cast<float *>(wsp + ws.off_aw);
       msda::ChunkBox *boxes = reinterpret_cast<msda::ChunkBox *>(wsp + ws.off_boxes);
       float *bounds = reinterpret_cast<float *>(wsp + ws.off_bounds);
-      msda::bwd_prep_kernel<4><<<(unsigned)(B * ws.n_chunks_per_list), M * L * 8, 0, stream>>>(
-          loc, attw, grad_out, shapes, rec_hw, rec_aw, boxes, M, L, Lq, (int)ws.n_chunks_per_list);
+      if (fused_ref)
+        msda::bwd_prep_kernel<4, true><<<(unsigned)(B * ws.n_chunks_per_list), M * L * 8, 0, stream>>>(
+            loc, attw, grad_out, shapes, rec_hw, rec_aw, boxes, fused_ref, fused_ref_dim, M, L, Lq, (int)ws.n_chunks_per_list);
+      else
+        msda::bwd_prep_kernel<4, false><<<(unsigned)(B * ws.n_chunks_per_list), M * L * 8, 0, stream>>>(
+            loc, attw, grad_out, shapes, rec_hw, rec_aw, boxes, nullptr, 0, M, L, Lq, (int)ws.n_chunks_per_list);
       msda::bwd_bounds_kernel<<<B * M, 256, 0, stream>>>(boxes, bounds, (int)(L * ws.n_chunks_per_list));
       // levels shared by several workgroups are accumulated with atomics: zero exactly those rows
       for (int l = 0; l < L; ++l) {
@@ -241,15 +258,13 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       else
         msda::bwd_scatter_kernel<false><<<8 * plan.n_items * bm_groups, msda::kScatterThreads, 0, stream>>>(
             rec_hw, rec_aw, boxes, bounds, grad_out, grad_value, plan, B, S, M, Lq, P, (int)ws.n_chunks_per_list);
-      msda::GatherGeom geom;
-      const bool can_stage = make_gather_geom(shapes_host, lsi_host, B, M, Lq, S, geom);
-      if (gather_mode() > 1 && can_stage) {
-        msda::gather_rec_kernel<true, true><<<8 * geom.n_chunks * bm_groups, msda::kStagedThreadsBwd, 0, stream>>>(
-            value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, geom, B, S, M, Lq, n_pairs);
-      } else if (gather_mode() > 0) {
-        geom.first_lds_level = 4;
-        msda::gather_rec_kernel<true, false><<<grid_pairs(n_pairs), msda::kPlainThreads, 0, stream>>>(
-            value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, geom, B, S, M, Lq, n_pairs);
+      if (gather_mode() > 0 || fused_ref) {
+        if (fused_ref)
+          launch_gather<true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
+                                    shapes_host, lsi_host, B, S, M, Lq, stream);
+        else
+          launch_gather<true, false>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, nullptr, 0, shapes_host,
+                                     lsi_host, B, S, M, Lq, stream);
       } else {
         msda::bwd_gather_kernel<4, 4><<<grid_pairs(n_pairs), 256, 0, stream>>>(
             value, shapes, lsi, loc, attw, grad_out, grad_loc, grad_attw, S, M, Lq, n_pairs);
@@ -320,6 +335,32 @@ int msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *
   return backward_impl<float>(value, shapes, level_start, loc, attn_w, grad_out, grad_value, grad_loc,
                               grad_attn_w, B, S, M, D, L, Lq, P, shapes_host, level_start_host, workspace,
                               workspace_bytes, stream);
+}
+
+// ---- fused operator: prologue of ops/modules/ms_deform_attn.py:146-155 inside the kernels --------------------
+int msda_fused_forward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                           const float *offsets, const float *logits, const float *ref, int ref_dim, float *out,
+                           int B, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
+                           const int64_t *level_start_host, void *stream) {
+  if (!value || !shapes || !level_start || !offsets || !logits || !ref || !out || !shapes_host || !level_start_host)
+    return MSDA_E_NULLPTR;
+  if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
+  if (!(D == 32 && L == 4 && P == 4) || (ref_dim != 2 && ref_dim != 6)) return MSDA_E_UNSUPPORTED;
+  launch_gather<false, true>(value, offsets, logits, nullptr, out, nullptr, nullptr, ref, ref_dim, shapes_host,
+                             level_start_host, B, S, M, Lq, (hipStream_t)stream);
+  return (int)hipGetLastError();
+}
+
+int msda_fused_backward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                            const float *offsets, const float *logits, const float *ref, int ref_dim,
+                            const float *grad_out, float *grad_value, float *grad_offsets, float *grad_logits,
+                            int B, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
+                            const int64_t *level_start_host, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!ref || !shapes_host || !level_start_host) return MSDA_E_NULLPTR;
+  if (!(D == 32 && L == 4 && P == 4) || (ref_dim != 2 && ref_dim != 6) || M * L * 8 > 1024) return MSDA_E_UNSUPPORTED;
+  return backward_impl<float>(value, shapes, level_start, offsets, logits, grad_out, grad_value, grad_offsets,
+                              grad_logits, B, S, M, D, L, Lq, P, shapes_host, level_start_host, workspace,
+                              workspace_bytes, stream, ref, ref_dim);
 }
 
 int msda_backward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,

@@ -112,6 +112,46 @@ __device__ __forceinline__ Tap<float> make_tap_im(float h_im, float w_im, int H,
   return tp;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_x(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+
+// ---- fused prologue (FUSED kernels): the module-level arithmetic of ops/modules/ms_deform_attn.py:146-155 --------
+// attention weights = softmax over the pair's L*P = 16 logits; sampling location of point (l, p):
+//   ref_dim 2: ref[l] + offset / (W_l, H_l)                                       (ms_deform_attn.py:149-152)
+//   ref_dim 6: ref[l][:2] + offset / P * (ref[l][2]+ref[l][3], ref[l][4]+ref[l][5]) * 0.5     (:153-155)
+// evaluated operation by operation (no contraction) like the PyTorch expressions.
+struct RefScale { float rx, ry, sx, sy; };   // location = (rx, ry) + f(offset, sx, sy)
+
+__device__ __forceinline__ RefScale load_ref(const float *rp, int ref_dim, int H, int W) {
+  RefScale r;
+  r.rx = rp[0];
+  r.ry = rp[1];
+  if (ref_dim == 2) { r.sx = (float)W; r.sy = (float)H; }
+  else { r.sx = __fadd_rn(rp[2], rp[3]); r.sy = __fadd_rn(rp[4], rp[5]); }
+  return r;
+}
+template <int P>
+__device__ __forceinline__ float loc_from_offset(float ref, float off, float s, int ref_dim) {
+  if (ref_dim == 2) return __fadd_rn(ref, __fdiv_rn(off, s));
+  return __fadd_rn(ref, __fmul_rn(__fmul_rn(__fdiv_rn(off, (float)P), s), 0.5f));
+}
+template <int P>
+__device__ __forceinline__ float offset_grad(float g, float s, int ref_dim) {       // autograd of the line above
+  if (ref_dim == 2) return __fdiv_rn(g, s);
+  return __fdiv_rn(__fmul_rn(__fmul_rn(g, 0.5f), s), (float)P);
+}
+// sum / max over the 8 lanes of a (query, head) group (all lanes get the result)
+__device__ __forceinline__ float group_sum(float v) {
+  v += dpp_x<0x141>(v); v += dpp_x<0x4E>(v); v += dpp_x<0xB1>(v);
+  return v;
+}
+__device__ __forceinline__ float group_max(float v) {
+  v = fmaxf(v, dpp_x<0x141>(v)); v = fmaxf(v, dpp_x<0x4E>(v)); v = fmaxf(v, dpp_x<0xB1>(v));
+  return v;
+}
+
 // ---- host/device shared plan of the tile-owner backward (passed to the kernel by value) -------
 // Work items are never materialised: item -> (level, tile, query chunk) is derived on the device
 // from per-level tilings, so any image size fits the kernel argument.

@@ -35,11 +35,6 @@ struct GatherGeom {
   int n_chunks;                            // query slices per (batch, head) (staged variants)
 };
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_x(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
-}
-
 // Corner offsets (in floats, relative to the (batch, head) base of the source the level lives in) of one
 // tap: rows are `row_stride` floats apart (tok in global memory, kRowPad when staged), `base` = level origin.
 __device__ __forceinline__ int4 corner_offsets(const Tap<float> &tp, int W, int base, int row_stride) {
@@ -53,12 +48,15 @@ __device__ __forceinline__ int sel4(int i, const int (&a)[4]) {        // lane-v
 }
 
 // BWD = false: out[pair] = sum of sampled rows.   BWD = true: grad_loc / grad_attn_w of the pair.
-template <bool BWD, bool STAGED>
+// FUSED: `loc` / `attw` carry the raw sampling offsets / attention logits, `ref` the per-level reference points
+// [B, Lq, 4, ref_dim]; the backward then writes grad_offsets / grad_logits in place of grad_loc / grad_attn_w.
+template <bool BWD, bool STAGED, bool FUSED>
 __global__ __launch_bounds__(STAGED ? (BWD ? kStagedThreadsBwd : kStagedThreadsFwd) : kPlainThreads, BWD && STAGED ? 2 : 4)
 void gather_rec_kernel(
     const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attw,
     const float *__restrict__ grad_out, float *__restrict__ out, float *__restrict__ grad_loc,
-    float *__restrict__ grad_attw, const GatherGeom g, int B, int S, int M, int Lq, long long n_pairs) {
+    float *__restrict__ grad_attw, const float *__restrict__ ref, int ref_dim, const GatherGeom g, int B, int S,
+    int M, int Lq, long long n_pairs) {
   constexpr int kThreads = STAGED ? (BWD ? kStagedThreadsBwd : kStagedThreadsFwd) : kPlainThreads;
   constexpr int kWaves = kThreads / 64;
   constexpr int kRecF4 = BWD ? 4 : 2;                          // float4 slots per record
@@ -101,8 +99,8 @@ void gather_rec_kernel(
     const int b = (int)(pair / ((long long)M * Lq));
     const float *vb = value + ((long long)b * S * M + m) * 32 + sub * 4;      // + corner offset
     const float *sb = staged + sub * 4;
-    const float4 lc = ld4(loc + pair * 32 + sub * 4);                         // points 2*sub, 2*sub+1: x,y,x,y
-    const float2 aw = *reinterpret_cast<const float2 *>(attw + pair * 16 + sub * 2);
+    float4 lc = ld4(loc + pair * 32 + sub * 4);                               // points 2*sub, 2*sub+1: x,y,x,y
+    float2 aw = *reinterpret_cast<const float2 *>(attw + pair * 16 + sub * 2);
     float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
     if (BWD) go = ld4(grad_out + pair * 32 + sub * 4);
 
@@ -112,6 +110,18 @@ void gather_rec_kernel(
     const bool mine_staged = STAGED && l_mine >= g.first_lds_level;
     const int row_stride = mine_staged ? kRowPad : tok;
     const int lvl_base = mine_staged ? (lvl_start - g.lds_token0) * kRowPad : lvl_start * tok;
+    RefScale rs{};
+    if (FUSED) {
+      // softmax over the pair's 16 logits (2 per lane), then the two sampling locations of this lane
+      const float mx = group_max(fmaxf(aw.x, aw.y));
+      const float e0 = expf(aw.x - mx), e1 = expf(aw.y - mx);
+      const float denom = group_sum(e0 + e1);
+      aw = make_float2(e0 / denom, e1 / denom);
+      const long long q_lin = pair / M;                                       // b * Lq + q
+      rs = load_ref(ref + (q_lin * 4 + l_mine) * ref_dim, ref_dim, H, W);
+      lc = make_float4(loc_from_offset<4>(rs.rx, lc.x, rs.sx, ref_dim), loc_from_offset<4>(rs.ry, lc.y, rs.sy, ref_dim),
+                       loc_from_offset<4>(rs.rx, lc.z, rs.sx, ref_dim), loc_from_offset<4>(rs.ry, lc.w, rs.sy, ref_dim));
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const float lx = k ? lc.z : lc.x, ly = k ? lc.w : lc.y, wt = k ? aw.y : aw.x;
@@ -208,6 +218,14 @@ void gather_rec_kernel(
     if (!BWD) {
       st4(out + pair * 32 + sub * 4, acc);
     } else {
+      if (FUSED) {
+        // chain rule through the prologue for this lane's own two points: softmax backward
+        // (grad - sum(grad * prob)) * prob and the offset scale
+        const float dot = group_sum(out_aw.x * aw.x + out_aw.y * aw.y);
+        out_aw = make_float2((out_aw.x - dot) * aw.x, (out_aw.y - dot) * aw.y);
+        out_loc = make_float4(offset_grad<4>(out_loc.x, rs.sx, ref_dim), offset_grad<4>(out_loc.y, rs.sy, ref_dim),
+                              offset_grad<4>(out_loc.z, rs.sx, ref_dim), offset_grad<4>(out_loc.w, rs.sy, ref_dim));
+      }
       st4(grad_loc + pair * 32 + sub * 4, out_loc);
       *reinterpret_cast<float2 *>(grad_attw + pair * 16 + sub * 2) = out_aw;
     }

@@ -30,6 +30,7 @@ class MSDeformAttn(nn.Module):
         if not _is_power_of_2(d_model // n_heads):
             warnings.warn("MSDeformAttn: a power-of-2 head dimension (32 in MonoDETR) takes the fast HIP path")
         self.im2col_step = 64          # ms_deform_attn.py:87
+        self.fuse_prologue = True      # MI355X: softmax + sampling locations inside the MSDA kernels when supported
         self.d_model = d_model
         self.n_levels = n_levels
         self.n_heads = n_heads
@@ -82,6 +83,13 @@ class MSDeformAttn(nn.Module):
             N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
         attention_weights = token_linear(query, self.attention_weights).view(
             N, Len_q, self.n_heads, self.n_levels * self.n_points)
+        if self.fuse_prologue and _func.MSDA.fused_supported(value, input_spatial_shapes, sampling_offsets, reference_points) \
+                and _func.MSDeformAttnFunction.__module__ == _func.__name__:
+            # softmax + location arithmetic evaluated inside the kernels (no loc / attn_w tensors in HBM)
+            output = _func.MSDeformAttnFusedFunction.apply(
+                value.contiguous(), input_spatial_shapes, input_level_start_index, sampling_offsets.contiguous(),
+                attention_weights.contiguous(), reference_points.contiguous())
+            return token_linear(output, self.output_proj)
         attention_weights = F.softmax(attention_weights, -1).view(
             N, Len_q, self.n_heads, self.n_levels, self.n_points)
         if reference_points.shape[-1] == 2:

@@ -33,3 +33,32 @@ class MSDeformAttnFunction(Function):
         grad_value, grad_loc, grad_attw = MSDA.ms_deform_attn_backward(
             value, shapes, lsi, loc, attw, grad_output.contiguous(), ctx.im2col_step, host_geom=ctx.host_geom)
         return grad_value, None, None, grad_loc, grad_attw, None
+
+
+class MSDeformAttnFusedFunction(Function):
+    """value, shapes, level starts, raw sampling offsets, raw attention logits, per-level reference points ->
+    output.  The softmax over the L*P logits and the sampling-location formula of the module
+    (ops/modules/ms_deform_attn.py:146-155) run inside the HIP kernels; no gradient flows to the reference
+    points (callers check ``MSDA.fused_supported``)."""
+
+    @staticmethod
+    def forward(ctx, value, spatial_shapes, level_start_index, sampling_offsets, attention_logits, reference_points):
+        output = MSDA.ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, sampling_offsets,
+                                                   attention_logits, reference_points)
+        ctx.save_for_backward(value, spatial_shapes, level_start_index, sampling_offsets, attention_logits, reference_points)
+        ctx.host_geom = MSDA.host_geometry(spatial_shapes, level_start_index)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, offsets, logits, ref = ctx.saved_tensors
+        MSDA.attach_host_geometry(shapes, lsi, *_unpack_geom(ctx.host_geom))
+        gv, goff, glog = MSDA.ms_deform_attn_fused_backward(value, shapes, lsi, offsets, logits, ref, grad_output.contiguous())
+        return gv, None, None, goff, glog, None
+
+
+def _unpack_geom(geom):
+    sh, ls = geom
+    L = len(ls)
+    return [(int(sh[2 * i]), int(sh[2 * i + 1])) for i in range(L)], [int(x) for x in ls]

@@ -307,3 +307,49 @@ def test_fixed_point_scatter_keeps_small_rows_accurate_under_outliers():
     other = ref[:, :, 1:, :]                                # heads without the outlier: own scale
     assert np.abs(gv[:, :, 1:, :] - other).max() <= 1e-5 * np.abs(other).max()
     assert np.abs(gv[:, :, 0, :] - ref[:, :, 0, :]).max() <= 1e-5 * np.abs(ref[:, :, 0, :]).max()
+
+
+@pytest.mark.parametrize("ref_dim", [2, 6])
+def test_fused_prologue_matches_the_unfused_operator(ref_dim):
+    """msda_fused_*: softmax + sampling-location arithmetic inside the kernels (ms_deform_attn.py:146-155) against
+    the same arithmetic in PyTorch followed by the unfused operator -- output and all three gradients."""
+    from monosowa_amd.ms_deform_attn_func import MSDeformAttnFunction, MSDeformAttnFusedFunction
+    MSDA = _msda()
+    torch.manual_seed(ref_dim)
+    levels = [(12, 40), (6, 20), (3, 10), (2, 5)]
+    B, M, D, L, P, Lq = 2, 8, 32, 4, 4, 333
+    shapes = torch.tensor(levels, dtype=torch.long, device="cuda")
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    starts = [0]
+    for h, w in levels[:-1]:
+        starts.append(starts[-1] + h * w)
+    MSDA.attach_host_geometry(shapes, lsi, levels, starts)
+    S = int(shapes.prod(1).sum())
+    value = torch.randn(B, S, M, D, device="cuda", requires_grad=True)
+    offsets = (torch.randn(B, Lq, M, L, P, 2, device="cuda") * 3).requires_grad_(True)
+    logits = torch.randn(B, Lq, M, L * P, device="cuda", requires_grad=True)
+    if ref_dim == 2:
+        ref = torch.rand(B, Lq, L, 2, device="cuda") * 1.2 - 0.1
+    else:
+        ref = torch.cat([torch.rand(B, Lq, L, 2, device="cuda"), torch.rand(B, Lq, L, 4, device="cuda") * 0.3], -1)
+    go = torch.randn(B, Lq, M * D, device="cuda")
+
+    out_f = MSDeformAttnFusedFunction.apply(value, shapes, lsi, offsets, logits, ref)
+    out_f.backward(go)
+    got = [out_f.detach().clone(), value.grad.clone(), offsets.grad.clone(), logits.grad.clone()]
+    value.grad = offsets.grad = logits.grad = None
+
+    aw = torch.softmax(logits, -1).view(B, Lq, M, L, P)
+    if ref_dim == 2:
+        norm = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+        loc = ref[:, :, None, :, None, :] + offsets / norm[None, None, None, :, None, :]
+    else:
+        loc = ref[:, :, None, :, None, :2] + offsets / P * (ref[:, :, None, :, None, 2::2] + ref[:, :, None, :, None, 3::2]) * 0.5
+    out_u = MSDeformAttnFunction.apply(value, shapes, lsi, loc.contiguous(), aw.contiguous(), 64)
+    out_u.backward(go)
+    want = [out_u.detach(), value.grad, offsets.grad, logits.grad]
+    for name, a, b in zip(("out", "grad_value", "grad_offsets", "grad_logits"), got, want):
+        assert (a - b).abs().max() <= 2e-5 * b.abs().max(), (name, ((a - b).abs().max() / b.abs().max()).item())
+    # the C-ABI refuses what it does not cover
+    from monosowa_amd import _lib
+    assert _lib.load().msda_fused_forward_f32(1, 1, 1, 1, 1, 1, 3, 1, 1, 1, 1, 32, 4, 1, 4, 1, 1, None) == -3
