@@ -353,3 +353,31 @@ def test_fused_prologue_matches_the_unfused_operator(ref_dim):
     # the C-ABI refuses what it does not cover
     from monosowa_amd import _lib
     assert _lib.load().msda_fused_forward_f32(1, 1, 1, 1, 1, 1, 3, 1, 1, 1, 1, 32, 4, 1, 4, 1, 1, None) == -3
+
+
+def test_train_val_cli_runs_an_epoch_and_writes_kitti_results(tmp_path):
+    """tools/train_val.py (the reference's CLI): one tiny epoch on synthetic data through Trainer -> checkpoint ->
+    Tester.inference -> KITTI result files, then `-e` evaluation-only from the saved checkpoint."""
+    import subprocess
+    import sys
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "configs", "monodetr.yaml")))
+    cfg["dataset"].update(batch_size=2, resolution=[320, 96], num_samples=4)
+    cfg["trainer"].update(max_epoch=1, save_path="out/")        # the reference prefixes './' (trainer_helper.py:40)
+    cfg["tester"].update(threshold=0.0)
+    path = tmp_path / "tiny.yaml"
+    yaml.safe_dump(cfg, open(path, "w"))
+    env = dict(os.environ, PYTHONPATH=root)
+    for extra in ([], ["-e"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "train_val.py"), "--config", str(path), "--workers", "0"] + extra,
+                           cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+    out = tmp_path / "out" / "monodetr"
+    assert (out / "checkpoint_epoch_1.pth").exists()
+    ckpt = torch.load(out / "checkpoint_epoch_1.pth", map_location="cpu", weights_only=False)
+    assert set(ckpt) == {"epoch", "model_state", "optimizer_state", "best_result", "best_epoch"} and ckpt["epoch"] == 1
+    files = sorted((out / "outputs" / "data").glob("*.txt"))
+    assert len(files) == 4
+    line = files[0].read_text().splitlines()[0].split(" ")
+    assert line[0] in ("Pedestrian", "Car", "Cyclist") and len(line) == 16
