@@ -1,0 +1,23 @@
+/*
+ * monosowa_pointwise.h -- C-ABI of the pointwise HIP kernels used around the library convolutions of the
+ * MonoDETR backbone (frozen batch-norm folded into the convolution; reference:
+ * MonoDETR/lib/models/monodetr/backbone.py:28-65 FrozenBatchNorm2d + torchvision's Bottleneck
+ * `relu(bn(conv(x)))` / `relu(bn3(conv3(.)) + identity)`).  Device pointers, float32, NHWC ([rows, C] contiguous).
+ * Return 0, a hipError_t (> 0), -1 (NULL pointer) or -2 (shape / alignment: C % 4 == 0, 16-byte aligned).
+ */
+#ifndef MONOSOWA_POINTWISE_H_
+#define MONOSOWA_POINTWISE_H_
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* y[r, c] = act(y[r, c] + bias[c] (+ residual[r, c])) in place; residual may be NULL; relu != 0 applies max(., 0). */
+int mono_bias_act_f32(float *y, const float *bias, const float *residual, long long rows, int C, int relu, void *stream);
+
+/* grad_in[i] = y[i] > 0 ? grad_out[i] : 0   (n % 4 == 0; grad_in may alias grad_out). */
+int mono_relu_grad_f32(const float *grad_out, const float *y, float *grad_in, long long n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -18,6 +18,7 @@ ARCH = "gfx950"
 # csrc/ counts as a dependency as well
 LIBS = {
     "libmonosowa_msda.so": ("msda_capi.hip", [os.path.join("..", "..", "include", "monosowa_msda.h")]),
+    "libmonosowa_pointwise.so": ("pointwise.hip", [os.path.join("..", "..", "include", "monosowa_pointwise.h")]),
 }
 
 FLAGS = ["-O3", "--offload-arch=" + ARCH, "-munsafe-fp-atomics", "-fPIC", "-shared", "-std=c++17",

@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..pointwise import bias_act
 from .misc import NestedTensor
 from .position_encoding import build_position_encoding
 
@@ -46,13 +47,18 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
 
 
-def conv_bn(x, conv, bn):
-    """conv followed by a frozen BN, evaluated as one convolution with folded weights."""
+def conv_bn(x, conv, bn, residual=None, relu=True):
+    """relu(frozen_bn(conv(x)) (+ residual)): one convolution with the BN scale folded into the weights, then ONE
+    in-place pointwise pass for shift, residual and ReLU (``monosowa_amd.pointwise``; ATen would issue a bias pass,
+    an add pass and a ReLU pass)."""
     if isinstance(bn, FrozenBatchNorm2d):
         scale, shift = bn.scale_shift()
-        return F.conv2d(x, conv.weight * scale.view(-1, 1, 1, 1), shift, conv.stride, conv.padding,
-                        conv.dilation, conv.groups)
-    return bn(conv(x))
+        y = F.conv2d(x, conv.weight * scale.view(-1, 1, 1, 1), None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        return bias_act(y, shift, residual, relu)
+    y = bn(conv(x))
+    if residual is not None:
+        y = y + residual
+    return F.relu(y, inplace=True) if relu else y
 
 
 class Bottleneck(nn.Module):
@@ -70,11 +76,10 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        out = F.relu(conv_bn(x, self.conv1, self.bn1), inplace=True)
-        out = F.relu(conv_bn(out, self.conv2, self.bn2), inplace=True)
-        out = conv_bn(out, self.conv3, self.bn3)
-        identity = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1])
-        return F.relu(out + identity, inplace=True)
+        out = conv_bn(x, self.conv1, self.bn1)
+        out = conv_bn(out, self.conv2, self.bn2)
+        identity = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], relu=False)
+        return conv_bn(out, self.conv3, self.bn3, residual=identity)
 
 
 _DEPTHS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}
@@ -114,7 +119,7 @@ class ResNetBody(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = F.relu(conv_bn(x, self.conv1, self.bn1), inplace=True)
+        x = conv_bn(x, self.conv1, self.bn1)
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
         x = self.layer1(x)
         c3 = self.layer2(x)

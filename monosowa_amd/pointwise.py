@@ -1,0 +1,76 @@
+"""Fused bias (+ residual) + ReLU after a convolution, in place, through the C-ABI pointwise library
+(include/monosowa_pointwise.h).  Used by the backbone's frozen-BN convolutions on channels_last tensors."""
+import ctypes
+import os
+
+import torch
+
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
+SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32")
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            raise RuntimeError("HIP extension %s is missing: run `python -m monosowa_amd.build`" % _PATH)
+        lib = ctypes.CDLL(_PATH)
+        P, I, LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
+        lib.mono_bias_act_f32.restype = I
+        lib.mono_bias_act_f32.argtypes = [P, P, P, LL, I, I, P]
+        lib.mono_relu_grad_f32.restype = I
+        lib.mono_relu_grad_f32.argtypes = [P, P, P, LL, P]
+        _lib = lib
+    return _lib
+
+
+def _nhwc_ok(t):
+    return t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.size(1) % 4 == 0 \
+        and t.is_contiguous(memory_format=torch.channels_last) and t.data_ptr() % 16 == 0
+
+
+class _BiasAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, bias, residual, relu):
+        rows = y.numel() // y.size(1)
+        with torch.cuda.device(y.device):
+            code = load().mono_bias_act_f32(y.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                            rows, y.size(1), int(relu), torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_bias_act_f32 failed with code %d" % code)
+        ctx.mark_dirty(y)
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        ctx.bias_grad = bias.requires_grad
+        if relu:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        if ctx.relu:
+            (y,) = ctx.saved_tensors
+            grad = grad.contiguous(memory_format=torch.channels_last)
+            g = torch.empty_like(grad, memory_format=torch.channels_last)
+            with torch.cuda.device(y.device):
+                code = load().mono_relu_grad_f32(grad.data_ptr(), y.data_ptr(), g.data_ptr(), grad.numel(),
+                                                 torch.cuda.current_stream().cuda_stream)
+            if code:
+                raise RuntimeError("mono_relu_grad_f32 failed with code %d" % code)
+        else:
+            g = grad
+        gb = g.sum((0, 2, 3)) if ctx.bias_grad else None
+        return g, gb, (g if ctx.has_res else None), None
+
+
+def bias_act(y, bias, residual=None, relu=True):
+    """``relu(y + bias[None, :, None, None] (+ residual))`` -- in place on ``y`` through the HIP kernel when the
+    tensors are float32 channels_last on the GPU, with plain PyTorch ops otherwise."""
+    if _nhwc_ok(y) and bias.is_cuda and bias.dtype == torch.float32 and bias.data_ptr() % 16 == 0 \
+            and (residual is None or (_nhwc_ok(residual) and residual.shape == y.shape)):
+        return _BiasAct.apply(y, bias.contiguous(), residual, relu)
+    out = y + bias.view(1, -1, 1, 1)
+    if residual is not None:
+        out = out + residual
+    return torch.relu(out) if relu else out

@@ -66,3 +66,17 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
                 assert "libmsda_oracle" not in src
+
+
+def test_pointwise_library_exports_declared_symbols():
+    from monosowa_amd import pointwise
+    text = open(os.path.join(ROOT, "include", "monosowa_pointwise.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(mono_[a-z0-9_]+)\s*\(", text)))
+    assert names == sorted(pointwise.SYMBOLS)
+    lib = ctypes.CDLL(pointwise._PATH)
+    for n in names:
+        assert hasattr(lib, n)
+    # CPU tensors take the plain PyTorch formulation
+    y, b, r = torch.randn(2, 8, 3, 5), torch.randn(8), torch.randn(2, 8, 3, 5)
+    assert torch.allclose(pointwise.bias_act(y.clone(), b, r), torch.relu(y + b.view(1, -1, 1, 1) + r))

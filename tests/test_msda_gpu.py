@@ -381,3 +381,27 @@ def test_train_val_cli_runs_an_epoch_and_writes_kitti_results(tmp_path):
     assert len(files) == 4
     line = files[0].read_text().splitlines()[0].split(" ")
     assert line[0] in ("Pedestrian", "Car", "Cyclist") and len(line) == 16
+
+
+def test_pointwise_bias_residual_relu_kernel():
+    """mono_bias_act_f32 / mono_relu_grad_f32 against the PyTorch formulation, forward and gradients."""
+    from monosowa_amd.pointwise import bias_act
+    torch.manual_seed(0)
+    for res in (False, True):
+        for relu in (True, False):
+            y0 = torch.randn(3, 64, 17, 23, device="cuda").contiguous(memory_format=torch.channels_last)
+            b = torch.randn(64, device="cuda")
+            r = torch.randn_like(y0).contiguous(memory_format=torch.channels_last).requires_grad_(True) if res else None
+            src = y0.clone().requires_grad_(True)
+            out = bias_act(src * 1.0, b, r, relu)
+            go = torch.randn_like(out)
+            out.backward(go)
+            ref_src = y0.clone().requires_grad_(True)
+            ref_r = r.detach().clone().requires_grad_(True) if res else None
+            ref = ref_src + b.view(1, -1, 1, 1) + (ref_r if res else 0)
+            ref = torch.relu(ref) if relu else ref
+            ref.backward(go)
+            assert torch.equal(out, ref)
+            assert torch.equal(src.grad, ref_src.grad)
+            if res:
+                assert torch.equal(r.grad, ref_r.grad)
