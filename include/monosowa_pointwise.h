@@ -17,6 +17,18 @@ int mono_bias_act_f32(float *y, const float *bias, const float *residual, long l
 /* grad_in[i] = y[i] > 0 ? grad_out[i] : 0   (n % 4 == 0; grad_in may alias grad_out). */
 int mono_relu_grad_f32(const float *grad_out, const float *y, float *grad_in, long long n, void *stream);
 
+/* y = LayerNorm_256(x + dropout_p(z)) over rows of C = 256 channels (reference: the post-norm residual blocks of
+ * depthaware_transformer.py:339-354,500-515).  The keep mask is a hash of (seed, element index): the backward
+ * recomputes it from the same seed.  Saves s = x + dropout(z), mean, rstd [rows] for the backward. */
+int mono_dropout_add_layernorm_fwd_f32(const float *x, const float *z, const float *gamma, const float *beta, float *y,
+                                       float *s, float *mean, float *rstd, long long rows, int C, float p,
+                                       unsigned long long seed, float eps, void *stream);
+
+/* gx, gz [rows, 256]; ggamma, gbeta [256] must be zeroed by the caller (accumulated). */
+int mono_dropout_add_layernorm_bwd_f32(const float *gy, const float *s, const float *mean, const float *rstd,
+                                       const float *gamma, float *gx, float *gz, float *ggamma, float *gbeta,
+                                       long long rows, int C, float p, unsigned long long seed, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,100 @@ __global__ __launch_bounds__(256) void relu_grad_kernel(const float *__restrict_
   }
 }
 
+// ---- LayerNorm(x + dropout(z)) over rows of 256 channels: one wave per row, float4 per lane -----------------
+// (reference: `src = self.norm1(src + self.dropout1(src2))`, depthaware_transformer.py:339-354,500-515).
+// The keep mask is a counter-based hash of (seed, element index), recomputed in the backward: no mask tensor.
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float keep_scale(unsigned long long seed, long long idx, unsigned threshold, float scale) {
+  const unsigned h = mix32((unsigned)idx * 0x9E3779B1u ^ (unsigned)seed) ^ mix32((unsigned)(idx >> 32) + (unsigned)(seed >> 32));
+  return h >= threshold ? scale : 0.f;        // P(drop) = threshold / 2^32
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
+    const float *__restrict__ x, const float *__restrict__ z, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float *__restrict__ y, float *__restrict__ s_out, float *__restrict__ mean_out,
+    float *__restrict__ rstd_out, long long rows, unsigned threshold, float scale, unsigned long long seed, float eps) {
+  const int lane = threadIdx.x & 63;
+  const float4 g = reinterpret_cast<const float4 *>(gamma)[lane], b = reinterpret_cast<const float4 *>(beta)[lane];
+  const long long wave_stride = (long long)gridDim.x * 4;
+  for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += wave_stride) {
+    const long long e = r * 256 + lane * 4;
+    const float4 xv = *reinterpret_cast<const float4 *>(x + e);
+    float4 zv = *reinterpret_cast<const float4 *>(z + e);
+    if (threshold) {
+      zv.x *= keep_scale(seed, e, threshold, scale); zv.y *= keep_scale(seed, e + 1, threshold, scale);
+      zv.z *= keep_scale(seed, e + 2, threshold, scale); zv.w *= keep_scale(seed, e + 3, threshold, scale);
+    }
+    const float4 sv = make_float4(xv.x + zv.x, xv.y + zv.y, xv.z + zv.z, xv.w + zv.w);
+    const float mean = wave_sum(sv.x + sv.y + sv.z + sv.w) * (1.f / 256.f);
+    const float dx = sv.x - mean, dy = sv.y - mean, dz = sv.z - mean, dw = sv.w - mean;
+    const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / 256.f);
+    const float rstd = rsqrtf(var + eps);
+    *reinterpret_cast<float4 *>(s_out + e) = sv;
+    *reinterpret_cast<float4 *>(y + e) = make_float4(dx * rstd * g.x + b.x, dy * rstd * g.y + b.y, dz * rstd * g.z + b.z, dw * rstd * g.w + b.w);
+    if (lane == 0) { mean_out[r] = mean; rstd_out[r] = rstd; }
+  }
+}
+
+// gs = rstd * (gy*gamma - mean(gy*gamma) - xhat * mean(gy*gamma*xhat));  gx = gs;  gz = gs * keep_scale;
+// ggamma += sum_rows gy * xhat, gbeta += sum_rows gy  (per-workgroup partial sums, then one atomic per column)
+__global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
+    const float *__restrict__ gy, const float *__restrict__ s, const float *__restrict__ mean_in,
+    const float *__restrict__ rstd_in, const float *__restrict__ gamma, float *__restrict__ gx, float *__restrict__ gz,
+    float *__restrict__ ggamma, float *__restrict__ gbeta, long long rows, unsigned threshold, float scale,
+    unsigned long long seed) {
+  __shared__ float4 part[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float4 g = reinterpret_cast<const float4 *>(gamma)[lane];
+  float4 acc_g = make_float4(0.f, 0.f, 0.f, 0.f), acc_b = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long wave_stride = (long long)gridDim.x * 4;
+  for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += wave_stride) {
+    const long long e = r * 256 + lane * 4;
+    const float4 gv = *reinterpret_cast<const float4 *>(gy + e);
+    const float4 sv = *reinterpret_cast<const float4 *>(s + e);
+    const float mean = mean_in[r], rstd = rstd_in[r];
+    const float4 xh = make_float4((sv.x - mean) * rstd, (sv.y - mean) * rstd, (sv.z - mean) * rstd, (sv.w - mean) * rstd);
+    const float4 t = make_float4(gv.x * g.x, gv.y * g.y, gv.z * g.z, gv.w * g.w);
+    const float m1 = wave_sum(t.x + t.y + t.z + t.w) * (1.f / 256.f);
+    const float m2 = wave_sum(t.x * xh.x + t.y * xh.y + t.z * xh.z + t.w * xh.w) * (1.f / 256.f);
+    const float4 gs = make_float4(rstd * (t.x - m1 - xh.x * m2), rstd * (t.y - m1 - xh.y * m2),
+                                  rstd * (t.z - m1 - xh.z * m2), rstd * (t.w - m1 - xh.w * m2));
+    *reinterpret_cast<float4 *>(gx + e) = gs;
+    float4 gzv = gs;
+    if (threshold) {
+      gzv.x *= keep_scale(seed, e, threshold, scale); gzv.y *= keep_scale(seed, e + 1, threshold, scale);
+      gzv.z *= keep_scale(seed, e + 2, threshold, scale); gzv.w *= keep_scale(seed, e + 3, threshold, scale);
+    }
+    *reinterpret_cast<float4 *>(gz + e) = gzv;
+    acc_g.x += gv.x * xh.x; acc_g.y += gv.y * xh.y; acc_g.z += gv.z * xh.z; acc_g.w += gv.w * xh.w;
+    acc_b.x += gv.x; acc_b.y += gv.y; acc_b.z += gv.z; acc_b.w += gv.w;
+  }
+  part[0][wave][lane] = acc_g;
+  part[1][wave][lane] = acc_b;
+  __syncthreads();
+  if (wave == 0) {
+    float4 a = part[0][0][lane], b = part[1][0][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 pa = part[0][w][lane], pb = part[1][w][lane];
+      a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
+      b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
+    }
+    atomicAdd(ggamma + lane * 4, a.x); atomicAdd(ggamma + lane * 4 + 1, a.y);
+    atomicAdd(ggamma + lane * 4 + 2, a.z); atomicAdd(ggamma + lane * 4 + 3, a.w);
+    atomicAdd(gbeta + lane * 4, b.x); atomicAdd(gbeta + lane * 4 + 1, b.y);
+    atomicAdd(gbeta + lane * 4 + 2, b.z); atomicAdd(gbeta + lane * 4 + 3, b.w);
+  }
+}
+
 inline int grid_for_vec(long long n_vec) {
   long long g = (n_vec + 255) / 256;
   if (g > 256LL * 32) g = 256LL * 32;
@@ -66,6 +160,38 @@ int mono_relu_grad_f32(const float *grad_out, const float *y, float *grad_in, lo
   if (!grad_out || !y || !grad_in) return -1;
   if (n <= 0 || (n & 3) || ((uintptr_t)grad_out & 15) || ((uintptr_t)y & 15) || ((uintptr_t)grad_in & 15)) return -2;
   mono::relu_grad_kernel<<<mono::grid_for_vec(n / 4), 256, 0, (hipStream_t)stream_>>>(grad_out, y, grad_in, n / 4);
+  return (int)hipGetLastError();
+}
+
+
+// LayerNorm over C = 256 of x + dropout(z), rows x 256 contiguous.  p in [0, 1): drop probability (0 = no dropout);
+// the keep mask depends only on (seed, element index).  s (the pre-norm sum), mean, rstd are saved for the backward.
+int mono_dropout_add_layernorm_fwd_f32(const float *x, const float *z, const float *gamma, const float *beta, float *y,
+                                       float *s, float *mean, float *rstd, long long rows, int C, float p,
+                                       unsigned long long seed, float eps, void *stream_) {
+  if (!x || !z || !gamma || !beta || !y || !s || !mean || !rstd) return -1;
+  if (rows <= 0 || C != 256 || !(p >= 0.f && p < 1.f)) return -2;
+  const unsigned threshold = (unsigned)((double)p * 4294967296.0);
+  const float scale = 1.f / (1.f - p);
+  long long g = (rows + 3) / 4;
+  if (g > 256 * 16) g = 256 * 16;
+  mono::dropout_add_ln_fwd_kernel<<<(int)g, 256, 0, (hipStream_t)stream_>>>(x, z, gamma, beta, y, s, mean, rstd, rows,
+                                                                           threshold, scale, seed, eps);
+  return (int)hipGetLastError();
+}
+
+// ggamma / gbeta [256] must be zero on entry (accumulated with atomics).
+int mono_dropout_add_layernorm_bwd_f32(const float *gy, const float *s, const float *mean, const float *rstd,
+                                       const float *gamma, float *gx, float *gz, float *ggamma, float *gbeta,
+                                       long long rows, int C, float p, unsigned long long seed, void *stream_) {
+  if (!gy || !s || !mean || !rstd || !gamma || !gx || !gz || !ggamma || !gbeta) return -1;
+  if (rows <= 0 || C != 256 || !(p >= 0.f && p < 1.f)) return -2;
+  const unsigned threshold = (unsigned)((double)p * 4294967296.0);
+  const float scale = 1.f / (1.f - p);
+  long long g = (rows + 3) / 4;
+  if (g > 256 * 4) g = 256 * 4;
+  mono::dropout_add_ln_bwd_kernel<<<(int)g, 256, 0, (hipStream_t)stream_>>>(gy, s, mean, rstd, gamma, gx, gz, ggamma,
+                                                                           gbeta, rows, threshold, scale, seed);
   return (int)hipGetLastError();
 }
 

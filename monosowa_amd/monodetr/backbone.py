@@ -155,7 +155,7 @@ class Backbone(nn.Module):
         out = {}
         for name, x in self.body(images).items():
             mask = torch.zeros(x.shape[0], x.shape[2], x.shape[3], dtype=torch.bool, device=x.device)
-            out[name] = NestedTensor(x, mask)
+            out[name] = NestedTensor(x, mask, all_valid=True)
         return out
 
 

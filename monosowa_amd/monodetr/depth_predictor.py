@@ -74,7 +74,7 @@ class DepthPredictor(nn.Module):
         self.depth_encoder = DepthEncoder(DepthEncoderLayer(d, nhead=8, dim_feedforward=256, dropout=0.1), 1)
         self.depth_pos_embed = nn.Embedding(int(self.depth_max) + 1, 256)
 
-    def forward(self, feature, mask, pos):
+    def forward(self, feature, mask, pos, all_valid=False):
         """feature: 4 projected levels [B,256,H_l,W_l]; mask/pos: of the stride-16 level.
         -> depth_logits [B,bins+1,H,W], depth_embed [B,256,H,W], weighted_depth [B,H,W],
            depth_pos_embed_ip [B,256,H,W]."""
@@ -90,7 +90,7 @@ class DepthPredictor(nn.Module):
 
         B, C, H, W = src.shape
         tokens = src.flatten(2).permute(2, 0, 1)
-        depth_embed = self.depth_encoder(tokens, mask.flatten(1), pos.flatten(2).permute(2, 0, 1))
+        depth_embed = self.depth_encoder(tokens, None if all_valid else mask.flatten(1), pos.flatten(2).permute(2, 0, 1))
         depth_embed = depth_embed.permute(1, 2, 0).reshape(B, C, H, W)
         depth_pos_embed_ip = self.interpolate_depth_embed(weighted_depth)
         return depth_logits, depth_embed + depth_pos_embed_ip, weighted_depth, depth_pos_embed_ip

@@ -10,9 +10,12 @@ import torch.distributed as dist
 
 
 class NestedTensor(object):
-    def __init__(self, tensors, mask):
+    def __init__(self, tensors, mask, all_valid=False):
         self.tensors = tensors
         self.mask = mask
+        # True when the producer built ``mask`` as all-False (no padding anywhere): consumers may then skip
+        # masking passes without looking at the device tensor
+        self.all_valid = all_valid
 
     def to(self, device, non_blocking=False):
         m = self.mask.to(device, non_blocking=non_blocking) if self.mask is not None else None

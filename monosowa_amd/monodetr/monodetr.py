@@ -109,6 +109,7 @@ class MonoDETR(nn.Module):
 
     def project_features(self, features, pos):
         srcs, masks = [], []
+        all_valid = all(getattr(f, "all_valid", False) for f in features)
         for l, feat in enumerate(features):
             src, mask = feat.decompose()
             assert mask is not None
@@ -120,6 +121,7 @@ class MonoDETR(nn.Module):
             pos.append(self.backbone[1](NestedTensor(src, mask)).to(src.dtype))
             srcs.append(src)
             masks.append(mask)
+        self._all_valid = all_valid          # the extra levels are built with all-False masks above
         return srcs, masks, pos
 
     def forward(self, images, calibs, targets, img_sizes, dn_args=None):
@@ -131,10 +133,10 @@ class MonoDETR(nn.Module):
         query_embeds = self.query_embed.weight if self.training else self.query_embed.weight[:self.num_queries]
 
         pred_depth_map_logits, depth_pos_embed, weighted_depth, depth_pos_embed_ip = \
-            self.depth_predictor(srcs, masks[1], pos[1])
+            self.depth_predictor(srcs, masks[1], pos[1], all_valid=self._all_valid)
 
         hs, init_reference, inter_references, inter_references_dim, _, _ = self.depthaware_transformer(
-            srcs, masks, pos, query_embeds, depth_pos_embed, depth_pos_embed_ip)
+            srcs, masks, pos, query_embeds, depth_pos_embed, depth_pos_embed_ip, all_valid=self._all_valid)
 
         coords, classes, dims3d, depths, angles = [], [], [], [], []
         fu = calibs[:, 0, 0].unsqueeze(1)

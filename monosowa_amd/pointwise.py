@@ -6,7 +6,8 @@ import os
 import torch
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
-SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32")
+SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
+           "mono_dropout_add_layernorm_bwd_f32")
 _lib = None
 
 
@@ -21,6 +22,11 @@ def load():
         lib.mono_bias_act_f32.argtypes = [P, P, P, LL, I, I, P]
         lib.mono_relu_grad_f32.restype = I
         lib.mono_relu_grad_f32.argtypes = [P, P, P, LL, P]
+        U, F = ctypes.c_ulonglong, ctypes.c_float
+        lib.mono_dropout_add_layernorm_fwd_f32.restype = I
+        lib.mono_dropout_add_layernorm_fwd_f32.argtypes = [P] * 8 + [LL, I, F, U, F, P]
+        lib.mono_dropout_add_layernorm_bwd_f32.restype = I
+        lib.mono_dropout_add_layernorm_bwd_f32.argtypes = [P] * 9 + [LL, I, F, U, P]
         _lib = lib
     return _lib
 
@@ -74,3 +80,59 @@ def bias_act(y, bias, residual=None, relu=True):
     if residual is not None:
         out = out + residual
     return torch.relu(out) if relu else out
+
+
+# ---------------------------------------------------------------------------------------------------------
+_seed_counter = [0]
+
+
+def _next_seed():
+    """A fresh 64-bit seed per call, reproducible under torch.manual_seed and distinct across ranks."""
+    _seed_counter[0] += 1
+    rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter[0] * 0xD1B54A32D192ED03 + rank * 0x94D049BB133111EB) & (2 ** 64 - 1)
+
+
+class _DropoutAddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, z, weight, bias, p, eps):
+        x, z = x.contiguous(), z.contiguous()
+        rows = x.numel() // 256
+        y, s = torch.empty_like(x), torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        seed = _next_seed() if p > 0 else 0
+        with torch.cuda.device(x.device):
+            code = load().mono_dropout_add_layernorm_fwd_f32(
+                x.data_ptr(), z.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), s.data_ptr(), mean.data_ptr(),
+                rstd.data_ptr(), rows, 256, float(p), seed, float(eps), torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_dropout_add_layernorm_fwd_f32 failed with code %d" % code)
+        ctx.save_for_backward(s, mean, rstd, weight)
+        ctx.p, ctx.seed = p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        s, mean, rstd, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx, gz = torch.empty_like(s), torch.empty_like(s)
+        gw = torch.zeros(2, 256, dtype=torch.float32, device=s.device)
+        with torch.cuda.device(s.device):
+            code = load().mono_dropout_add_layernorm_bwd_f32(
+                gy.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), weight.data_ptr(), gx.data_ptr(), gz.data_ptr(),
+                gw[0].data_ptr(), gw[1].data_ptr(), s.numel() // 256, 256, float(ctx.p), ctx.seed,
+                torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_dropout_add_layernorm_bwd_f32 failed with code %d" % code)
+        return gx, gz, gw[0], gw[1], None, None
+
+
+def dropout_add_layernorm(x, z, norm, dropout):
+    """``norm(x + dropout(z))`` for an ``nn.LayerNorm(256)`` and an ``nn.Dropout``: one HIP kernel forward, one
+    backward, on float32 GPU tensors; the PyTorch formulation otherwise."""
+    p = dropout.p if dropout.training else 0.0
+    if x.is_cuda and x.dtype == torch.float32 and z.dtype == torch.float32 and x.shape == z.shape and x.shape[-1] == 256 \
+            and tuple(norm.normalized_shape) == (256,) and norm.elementwise_affine and norm.bias is not None and p < 1.0:
+        return _DropoutAddLayerNorm.apply(x, z, norm.weight, norm.bias, p, norm.eps)
+    return norm(x + dropout(z))

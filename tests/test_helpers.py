@@ -336,3 +336,32 @@ def test_vectorised_decode_equals_loop_form():
         for ra, rb in zip(a[k], b[k]):
             assert ra[0] == rb[0]
             np.testing.assert_allclose(np.asarray(ra[1:], np.float64), np.asarray(rb[1:], np.float64), rtol=1e-6, atol=1e-6)
+
+
+def test_all_valid_shortcut_equals_masked_path(monkeypatch):
+    """MonoDETR's backbone builds all-False masks; the transformer then skips the masking passes.  Same outputs as
+    the general path fed with explicit all-False masks."""
+    import monosowa_amd.ms_deform_attn_func as F
+    from oracle import msda_oracle as O
+    from monosowa_amd.monodetr.depthaware_transformer import DepthAwareTransformer, MLP
+
+    class _Fn:
+        @staticmethod
+        def apply(value, shapes, lsi, loc, w, step):
+            return O.msda_core_torch(value, shapes, loc, w)
+    monkeypatch.setattr(F, "MSDeformAttnFunction", _Fn)
+    torch.manual_seed(0)
+    t = DepthAwareTransformer(d_model=256, nhead=8, num_encoder_layers=1, num_decoder_layers=2, dim_feedforward=64, dropout=0.0,
+                              return_intermediate_dec=True, group_num=2).eval()
+    t.decoder.bbox_embed = torch.nn.ModuleList([MLP(256, 256, 6, 3) for _ in range(2)])
+    t.decoder.dim_embed = torch.nn.ModuleList([MLP(256, 256, 3, 2) for _ in range(2)])
+    sizes = [(6, 8), (3, 4), (2, 2), (1, 1)]
+    srcs = [torch.randn(2, 256, h, w) for h, w in sizes]
+    masks = [torch.zeros(2, h, w, dtype=torch.bool) for h, w in sizes]
+    pos = [torch.randn(2, 256, h, w) for h, w in sizes]
+    qe, dpe = torch.randn(50, 512), torch.randn(2, 256, 3, 4)
+    with torch.no_grad():
+        a = t(srcs, masks, pos, qe, dpe, dpe, all_valid=False)
+        b = t(srcs, masks, pos, qe, dpe, dpe, all_valid=True)
+    for x, y in zip(a[:4], b[:4]):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-6)

@@ -405,3 +405,41 @@ def test_pointwise_bias_residual_relu_kernel():
             assert torch.equal(src.grad, ref_src.grad)
             if res:
                 assert torch.equal(r.grad, ref_r.grad)
+
+
+def test_fused_dropout_add_layernorm():
+    """mono_dropout_add_layernorm_*: exact LayerNorm(x + z) parity without dropout (forward + all gradients); with
+    dropout the kept fraction matches p, kept elements are scaled by 1/(1-p), and the backward reuses the same mask."""
+    from monosowa_amd.pointwise import dropout_add_layernorm
+    torch.manual_seed(0)
+    norm = torch.nn.LayerNorm(256).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(7, 1021, 256, device="cuda", requires_grad=True)
+    z = torch.randn(7, 1021, 256, device="cuda", requires_grad=True)
+    go = torch.randn(7, 1021, 256, device="cuda")
+    drop = torch.nn.Dropout(0.1).cuda().eval()
+    y = dropout_add_layernorm(x, z, norm, drop)
+    y.backward(go)
+    got = [y.detach().clone(), x.grad.clone(), z.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone()]
+    x.grad = z.grad = None
+    norm.zero_grad()
+    ref = norm(x + z)
+    ref.backward(go)
+    for a, b, n in zip(got, [ref.detach(), x.grad, z.grad, norm.weight.grad, norm.bias.grad], ("y", "gx", "gz", "gw", "gb")):
+        assert (a - b).abs().max() <= 2e-5 * b.abs().max(), n
+    # training mode: recover the mask from gz / gx (gz = gx * keep / (1 - p))
+    drop.train()
+    x.grad = z.grad = None
+    y = dropout_add_layernorm(x, z, norm, drop)
+    y.backward(go)
+    ratio = z.grad / x.grad
+    kept = ratio.abs() > 0.5
+    assert abs(kept.float().mean().item() - 0.9) < 0.005
+    assert torch.allclose(ratio[kept], torch.full_like(ratio[kept], 1 / 0.9), rtol=1e-4)
+    mask = kept.float() / 0.9
+    ref = norm(x.detach() + z.detach() * mask)
+    assert (y - ref).abs().max() <= 2e-5 * ref.abs().max()
+    y2 = dropout_add_layernorm(x, z, norm, drop)          # a new call draws a new mask
+    assert not torch.equal(y2, y)
