@@ -29,6 +29,18 @@ int mono_dropout_add_layernorm_bwd_f32(const float *gy, const float *s, const fl
                                        const float *gamma, float *gx, float *gz, float *ggamma, float *gbeta,
                                        long long rows, int C, float p, unsigned long long seed, void *stream);
 
+/* GroupNorm(32 groups, 256 channels) (+ ReLU when relu != 0) on a channels-last tensor x [B, HW, 256]
+ * (reference: nn.GroupNorm(32, hidden_dim) in monodetr.py:68-88 input_proj and depth_predictor.py:27-52).
+ * stats: f64 [B, 32, 2] scratch, ZERO on entry.  mean_rstd: f32 [B, 32, 2], saved for the backward. */
+int mono_groupnorm_nhwc_fwd_f32(const float *x, const float *gamma, const float *beta, float *y, double *stats,
+                                float *mean_rstd, int B, int HW, int C, int G, float eps, int relu, void *stream);
+
+/* gx [B, HW, 256].  part: f64 [B, 256, 2], ZERO on entry; on return part[b][c] = {sum gy'*xhat, sum gy'} so that
+ * ggamma[c] = sum_b part[b][c][0], gbeta[c] = sum_b part[b][c][1].  y = forward output (ReLU mask), NULL if relu == 0. */
+int mono_groupnorm_nhwc_bwd_f32(const float *gy, const float *x, const float *y, const float *mean_rstd,
+                                const float *gamma, float *gx, double *part, int B, int HW, int C, int G, int relu,
+                                void *stream);
+
 #ifdef __cplusplus
 }
 #endif

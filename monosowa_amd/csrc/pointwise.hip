@@ -4,6 +4,8 @@
 // (frozen batch-norm is folded into the conv weights and `bias`, lib/models/monodetr/backbone.py:28-65).
 // HBM-bound: one read (+ one for the residual) and one write per element, float4 per lane.
 #include <hip/hip_runtime.h>
+
+#include "groupnorm.hip"
 #include <stdint.h>
 
 namespace mono {
@@ -192,6 +194,40 @@ int mono_dropout_add_layernorm_bwd_f32(const float *gy, const float *s, const fl
   if (g > 256 * 4) g = 256 * 4;
   mono::dropout_add_ln_bwd_kernel<<<(int)g, 256, 0, (hipStream_t)stream_>>>(gy, s, mean, rstd, gamma, gx, gz, ggamma,
                                                                            gbeta, rows, threshold, scale, seed);
+  return (int)hipGetLastError();
+}
+
+
+// GroupNorm(G = 32, C = 256) (+ ReLU) on channels-last x [B, HW, 256].  stats [B, 32, 2] f64 must be zero on entry;
+// mean_rstd [B, 32, 2] f32 is written for the backward.
+int mono_groupnorm_nhwc_fwd_f32(const float *x, const float *gamma, const float *beta, float *y, double *stats,
+                                float *mean_rstd, int B, int HW, int C, int G, float eps, int relu, void *stream_) {
+  if (!x || !gamma || !beta || !y || !stats || !mean_rstd) return -1;
+  if (B <= 0 || HW <= 0 || C != mono::kGnC || G != mono::kGnG || B > 65535) return -2;
+  hipStream_t st = (hipStream_t)stream_;
+  const dim3 grid((HW + mono::kGnPix - 1) / mono::kGnPix, B);
+  mono::gn_stats_kernel<<<grid, 256, 0, st>>>(x, stats, HW);
+  if (relu) mono::gn_apply_kernel<true><<<grid, 256, 0, st>>>(x, stats, gamma, beta, y, mean_rstd, HW, eps);
+  else mono::gn_apply_kernel<false><<<grid, 256, 0, st>>>(x, stats, gamma, beta, y, mean_rstd, HW, eps);
+  return (int)hipGetLastError();
+}
+
+// part [B, 256, 2] f64 must be zero on entry; on return part[b][c] = {sum gy' xhat, sum gy'} (ggamma / gbeta are its
+// sums over b).  y (the forward output) is read only when relu != 0.
+int mono_groupnorm_nhwc_bwd_f32(const float *gy, const float *x, const float *y, const float *mean_rstd,
+                                const float *gamma, float *gx, double *part, int B, int HW, int C, int G, int relu,
+                                void *stream_) {
+  if (!gy || !x || !mean_rstd || !gamma || !gx || !part || (relu && !y)) return -1;
+  if (B <= 0 || HW <= 0 || C != mono::kGnC || G != mono::kGnG || B > 65535) return -2;
+  hipStream_t st = (hipStream_t)stream_;
+  const dim3 grid((HW + mono::kGnPix - 1) / mono::kGnPix, B);
+  if (relu) {
+    mono::gn_bwd_stats_kernel<true><<<grid, 256, 0, st>>>(gy, x, y, mean_rstd, part, HW);
+    mono::gn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(gy, x, y, mean_rstd, gamma, part, gx, HW);
+  } else {
+    mono::gn_bwd_stats_kernel<false><<<grid, 256, 0, st>>>(gy, x, y, mean_rstd, part, HW);
+    mono::gn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(gy, x, y, mean_rstd, gamma, part, gx, HW);
+  }
   return (int)hipGetLastError();
 }
 

@@ -11,6 +11,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..pointwise import group_norm
+
 
 class DepthEncoderLayer(nn.Module):
     """Post-norm transformer encoder layer: q = k = src + pos, v = src (transformer.py:57-65)."""
@@ -79,10 +81,13 @@ class DepthPredictor(nn.Module):
         -> depth_logits [B,bins+1,H,W], depth_embed [B,256,H,W], weighted_depth [B,H,W],
            depth_pos_embed_ip [B,256,H,W]."""
         assert len(feature) == 4
-        src_16 = self.proj(feature[1])
-        src_32 = self.upsample(F.interpolate(feature[2], size=src_16.shape[-2:], mode="bilinear"))
-        src_8 = self.downsample(feature[0])
-        src = self.depth_head((src_8 + src_16 + src_32) / 3)
+        # Conv2d + GroupNorm(32, d) (+ ReLU) blocks: the norms run through the channels-last HIP kernels
+        src_16 = group_norm(self.proj[0](feature[1]), self.proj[1])
+        src_32 = group_norm(self.upsample[0](F.interpolate(feature[2], size=src_16.shape[-2:], mode="bilinear")), self.upsample[1])
+        src_8 = group_norm(self.downsample[0](feature[0]), self.downsample[1])
+        src = (src_8 + src_16 + src_32) / 3
+        src = group_norm(self.depth_head[0](src), self.depth_head[1], relu=True)
+        src = group_norm(self.depth_head[3](src), self.depth_head[4], relu=True)
         depth_logits = self.depth_classifier(src)
 
         depth_probs = F.softmax(depth_logits, dim=1)

@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..pointwise import group_norm
 from .depthaware_transformer import MLP
 from .misc import NestedTensor, inverse_sigmoid
 
@@ -107,16 +108,21 @@ class MonoDETR(nn.Module):
         return [n for n, _ in self.named_parameters()
                 if n.startswith(self.UNUSED_PARAMETER_PREFIXES) or n.endswith(self.UNUSED_PARAMETER_SUFFIXES)]
 
+    def _project(self, l, x):
+        """input_proj[l] = Conv2d + GroupNorm(32, hidden_dim) (monodetr.py:68-88), the norm through the NHWC kernel."""
+        conv, gn = self.input_proj[l]
+        return group_norm(conv(x), gn)
+
     def project_features(self, features, pos):
         srcs, masks = [], []
         all_valid = all(getattr(f, "all_valid", False) for f in features)
         for l, feat in enumerate(features):
             src, mask = feat.decompose()
             assert mask is not None
-            srcs.append(self.input_proj[l](src))
+            srcs.append(self._project(l, src))
             masks.append(mask)
         for l in range(len(srcs), self.num_feature_levels):   # extra stride-2 levels from C5
-            src = self.input_proj[l](features[-1].tensors if l == len(features) else srcs[-1])
+            src = self._project(l, features[-1].tensors if l == len(features) else srcs[-1])
             mask = torch.zeros(src.shape[0], src.shape[2], src.shape[3], dtype=torch.bool, device=src.device)
             pos.append(self.backbone[1](NestedTensor(src, mask)).to(src.dtype))
             srcs.append(src)

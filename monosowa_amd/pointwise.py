@@ -7,7 +7,7 @@ import torch
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
-           "mono_dropout_add_layernorm_bwd_f32")
+           "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32")
 _lib = None
 
 
@@ -27,6 +27,10 @@ def load():
         lib.mono_dropout_add_layernorm_fwd_f32.argtypes = [P] * 8 + [LL, I, F, U, F, P]
         lib.mono_dropout_add_layernorm_bwd_f32.restype = I
         lib.mono_dropout_add_layernorm_bwd_f32.argtypes = [P] * 9 + [LL, I, F, U, P]
+        lib.mono_groupnorm_nhwc_fwd_f32.restype = I
+        lib.mono_groupnorm_nhwc_fwd_f32.argtypes = [P] * 6 + [I, I, I, I, F, I, P]
+        lib.mono_groupnorm_nhwc_bwd_f32.restype = I
+        lib.mono_groupnorm_nhwc_bwd_f32.argtypes = [P] * 7 + [I, I, I, I, I, P]
         _lib = lib
     return _lib
 
@@ -136,3 +140,47 @@ def dropout_add_layernorm(x, z, norm, dropout):
             and tuple(norm.normalized_shape) == (256,) and norm.elementwise_affine and norm.bias is not None and p < 1.0:
         return _DropoutAddLayerNorm.apply(x, z, norm.weight, norm.bias, p, norm.eps)
     return norm(x + dropout(z))
+
+
+# ---------------------------------------------------------------------------------------------------------
+class _GroupNormNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, relu):
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)                                       # keeps the channels_last strides
+        stats = torch.zeros(B, 32, 2, dtype=torch.float64, device=x.device)
+        mean_rstd = torch.empty(B, 32, 2, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            code = load().mono_groupnorm_nhwc_fwd_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                                      stats.data_ptr(), mean_rstd.data_ptr(), B, H * W, C, 32, float(eps),
+                                                      int(relu), torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_groupnorm_nhwc_fwd_f32 failed with code %d" % code)
+        ctx.relu = relu
+        ctx.save_for_backward(x, y if relu else None, mean_rstd, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, mean_rstd, weight = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(x)
+        part = torch.zeros(B, C, 2, dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            code = load().mono_groupnorm_nhwc_bwd_f32(gy.data_ptr(), x.data_ptr(), y.data_ptr() if ctx.relu else None,
+                                                      mean_rstd.data_ptr(), weight.data_ptr(), gx.data_ptr(), part.data_ptr(),
+                                                      B, H * W, C, 32, int(ctx.relu), torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_groupnorm_nhwc_bwd_f32 failed with code %d" % code)
+        gwb = part.sum(0).float()
+        return gx, gwb[:, 0].contiguous(), gwb[:, 1].contiguous(), None, None
+
+
+def group_norm(x, gn, relu=False):
+    """``gn(x)`` (+ ReLU) for an ``nn.GroupNorm(32, 256)`` on a channels-last float32 GPU tensor: two HIP kernels
+    forward, two backward, no layout copies; the PyTorch formulation for anything else."""
+    if _nhwc_ok(x) and x.size(1) == 256 and gn.num_groups == 32 and gn.affine and x.size(0) <= 65535:
+        return _GroupNormNHWC.apply(x, gn.weight, gn.bias, gn.eps, relu)
+    y = gn(x)
+    return torch.relu(y) if relu else y

@@ -443,3 +443,32 @@ def test_fused_dropout_add_layernorm():
     assert (y - ref).abs().max() <= 2e-5 * ref.abs().max()
     y2 = dropout_add_layernorm(x, z, norm, drop)          # a new call draws a new mask
     assert not torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("shape", [(3, 256, 24, 80), (2, 256, 7, 9), (1, 256, 1, 1)])
+def test_groupnorm_nhwc_matches_torch(shape, relu):
+    """mono_groupnorm_nhwc_*: GroupNorm(32, 256) (+ ReLU) on channels-last tensors equals F.group_norm (forward,
+    grad_input, grad_weight, grad_bias), including a large-mean input (f64 statistics) and ragged pixel counts."""
+    from monosowa_amd.pointwise import group_norm
+    torch.manual_seed(1)
+    gn = torch.nn.GroupNorm(32, 256).cuda()
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.uniform_(-0.5, 0.5)
+    x = (torch.randn(shape, device="cuda") * 2 + 5).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    go = torch.randn(shape, device="cuda").contiguous(memory_format=torch.channels_last)
+    y = group_norm(x, gn, relu=relu)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(go)
+    got = [y.detach().clone(), x.grad.clone(), gn.weight.grad.clone(), gn.bias.grad.clone()]
+    x.grad = None
+    gn.zero_grad()
+    xd = x.detach().double().contiguous().requires_grad_(True)
+    gnd = torch.nn.GroupNorm(32, 256).cuda().double()
+    gnd.load_state_dict({k: v.double() for k, v in gn.state_dict().items()})
+    ref = gnd(xd)
+    ref = torch.relu(ref) if relu else ref
+    ref.backward(go.double())
+    for a, b, n in zip(got, [ref.detach(), xd.grad, gnd.weight.grad, gnd.bias.grad], ("y", "gx", "gw", "gb")):
+        assert (a.double() - b).abs().max() <= 3e-5 * max(b.abs().max().item(), 1.0), n
