@@ -24,10 +24,19 @@ int mono_dropout_add_layernorm_fwd_f32(const float *x, const float *z, const flo
                                        float *s, float *mean, float *rstd, long long rows, int C, float p,
                                        unsigned long long seed, float eps, void *stream);
 
-/* gx, gz [rows, 256]; ggamma, gbeta [256] must be zeroed by the caller (accumulated). */
+/* Number of workgroups, = rows of scratch the two row reductions below need, for `rows` input rows. */
+int mono_reduce_blocks(long long rows);
+
+/* gx, gz [rows, 256]; ggamma_gbeta [2, 256] (ggamma then gbeta), overwritten.
+ * partials: scratch of mono_reduce_blocks(rows) * 512 floats (per-workgroup partial sums; no atomics: deterministic). */
 int mono_dropout_add_layernorm_bwd_f32(const float *gy, const float *s, const float *mean, const float *rstd,
-                                       const float *gamma, float *gx, float *gz, float *ggamma, float *gbeta,
+                                       const float *gamma, float *gx, float *gz, float *ggamma_gbeta, float *partials,
                                        long long rows, int C, float p, unsigned long long seed, void *stream);
+
+/* out[c] = sum_r g[r][c] for a row-major [rows, C] matrix (C % 4 == 0, C <= 1024): the bias gradient of a linear
+ * layer over tokens (autograd's `grad.sum(0)` for nn.Linear in the reference).  out is overwritten.
+ * partials: scratch of mono_reduce_blocks(rows) * C floats. */
+int mono_colsum_f32(const float *g, float *out, float *partials, long long rows, int C, void *stream);
 
 /* GroupNorm(32 groups, 256 channels) (+ ReLU when relu != 0) on a channels-last tensor x [B, HW, 256]
  * (reference: nn.GroupNorm(32, hidden_dim) in monodetr.py:68-88 input_proj and depth_predictor.py:27-52).

@@ -84,12 +84,12 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
 }
 
 // gs = rstd * (gy*gamma - mean(gy*gamma) - xhat * mean(gy*gamma*xhat));  gx = gs;  gz = gs * keep_scale;
-// ggamma += sum_rows gy * xhat, gbeta += sum_rows gy  (per-workgroup partial sums, then one atomic per column)
+// ggamma = sum_rows gy * xhat, gbeta = sum_rows gy: per-workgroup partial rows [gridDim.x][512], added up by
+// partial_sum_kernel (no same-address atomics)
 __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
     const float *__restrict__ gy, const float *__restrict__ s, const float *__restrict__ mean_in,
     const float *__restrict__ rstd_in, const float *__restrict__ gamma, float *__restrict__ gx, float *__restrict__ gz,
-    float *__restrict__ ggamma, float *__restrict__ gbeta, long long rows, unsigned threshold, float scale,
-    unsigned long long seed) {
+    float *__restrict__ partials, long long rows, unsigned threshold, float scale, unsigned long long seed) {
   __shared__ float4 part[2][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float4 g = reinterpret_cast<const float4 *>(gamma)[lane];
@@ -127,10 +127,76 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
       a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
       b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
     }
-    atomicAdd(ggamma + lane * 4, a.x); atomicAdd(ggamma + lane * 4 + 1, a.y);
-    atomicAdd(ggamma + lane * 4 + 2, a.z); atomicAdd(ggamma + lane * 4 + 3, a.w);
-    atomicAdd(gbeta + lane * 4, b.x); atomicAdd(gbeta + lane * 4 + 1, b.y);
-    atomicAdd(gbeta + lane * 4 + 2, b.z); atomicAdd(gbeta + lane * 4 + 3, b.w);
+    float *dst = partials + (long long)blockIdx.x * 512 + lane * 4;
+    *reinterpret_cast<float4 *>(dst) = a;
+    *reinterpret_cast<float4 *>(dst + 256) = b;
+  }
+}
+
+// ---- column sums of a row-major [rows, C] matrix (bias gradients): out[c] += sum_r g[r][c] --------------------
+// PyTorch's reduce kernel takes 26 us for [8800, 256] (few workgroups); here a wave walks rows with float4 lanes,
+// the 4 waves of a workgroup combine through LDS into one partial row; partial_sum_kernel adds the partial rows.
+// (Same-address global atomics serialise in L2: 1275 workgroups x 256 atomics cost 100 us, hence two stages.)
+template <int JJ>
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ g, float *__restrict__ partials, long long rows,
+                                                     int C, int rows_per_block) {
+  __shared__ float4 red[3][JJ][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cv = C >> 2;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float4 acc[JJ];
+#pragma unroll
+  for (int j = 0; j < JJ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (long long r = r0 + wave; r < r1; r += 4) {
+#pragma unroll
+    for (int j = 0; j < JJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < cv) {
+        const float4 v = *reinterpret_cast<const float4 *>(g + r * C + c * 4);
+        acc[j].x += v.x; acc[j].y += v.y; acc[j].z += v.z; acc[j].w += v.w;
+      }
+    }
+  }
+  if (wave) {
+#pragma unroll
+    for (int j = 0; j < JJ; ++j) red[wave - 1][j][lane] = acc[j];
+  }
+  __syncthreads();
+  if (!wave) {
+#pragma unroll
+    for (int j = 0; j < JJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < cv) {
+        const float4 a = red[0][j][lane], b = red[1][j][lane], d = red[2][j][lane];
+        *reinterpret_cast<float4 *>(partials + (long long)blockIdx.x * C + c * 4) =
+            make_float4(acc[j].x + a.x + b.x + d.x, acc[j].y + a.y + b.y + d.y, acc[j].z + a.z + b.z + d.z, acc[j].w + a.w + b.w + d.w);
+      }
+    }
+  }
+}
+
+// out[c] = sum_k partials[k][c], k < n: one 16-wave workgroup per 64 float4 columns, the waves split the rows.
+__global__ __launch_bounds__(1024) void partial_sum_kernel(const float *__restrict__ partials, float *__restrict__ out, int n, int C) {
+  __shared__ float4 red[15][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < (C >> 2)) {
+#pragma unroll 8
+    for (int k = wave; k < n; k += 16) {
+      const float4 v = *reinterpret_cast<const float4 *>(partials + (long long)k * C + c * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  if (wave) red[wave - 1][lane] = acc;
+  __syncthreads();
+  if (!wave && c < (C >> 2)) {
+#pragma unroll
+    for (int w = 0; w < 15; ++w) {
+      const float4 a = red[w][lane];
+      acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+    *reinterpret_cast<float4 *>(out + c * 4) = acc;
   }
 }
 
@@ -143,6 +209,8 @@ inline int grid_for_vec(long long n_vec) {
 }  // namespace mono
 
 extern "C" {
+
+int mono_reduce_blocks(long long rows);
 
 // y [rows, C] is updated in place; residual may be NULL; C % 4 == 0 and 16-byte aligned pointers required.
 int mono_bias_act_f32(float *y, const float *bias, const float *residual, long long rows, int C, int relu, void *stream_) {
@@ -182,21 +250,43 @@ int mono_dropout_add_layernorm_fwd_f32(const float *x, const float *z, const flo
   return (int)hipGetLastError();
 }
 
-// ggamma / gbeta [256] must be zero on entry (accumulated with atomics).
+// ggamma_gbeta: [2, 256] contiguous (ggamma then gbeta), overwritten.  partials: scratch of
+// mono_reduce_blocks(rows) * 512 floats.
 int mono_dropout_add_layernorm_bwd_f32(const float *gy, const float *s, const float *mean, const float *rstd,
-                                       const float *gamma, float *gx, float *gz, float *ggamma, float *gbeta,
+                                       const float *gamma, float *gx, float *gz, float *ggamma_gbeta, float *partials,
                                        long long rows, int C, float p, unsigned long long seed, void *stream_) {
-  if (!gy || !s || !mean || !rstd || !gamma || !gx || !gz || !ggamma || !gbeta) return -1;
+  if (!gy || !s || !mean || !rstd || !gamma || !gx || !gz || !ggamma_gbeta || !partials) return -1;
   if (rows <= 0 || C != 256 || !(p >= 0.f && p < 1.f)) return -2;
   const unsigned threshold = (unsigned)((double)p * 4294967296.0);
   const float scale = 1.f / (1.f - p);
-  long long g = (rows + 3) / 4;
-  if (g > 256 * 4) g = 256 * 4;
-  mono::dropout_add_ln_bwd_kernel<<<(int)g, 256, 0, (hipStream_t)stream_>>>(gy, s, mean, rstd, gamma, gx, gz, ggamma,
-                                                                           gbeta, rows, threshold, scale, seed);
+  const int g = mono_reduce_blocks(rows);
+  hipStream_t st = (hipStream_t)stream_;
+  mono::dropout_add_ln_bwd_kernel<<<g, 256, 0, st>>>(gy, s, mean, rstd, gamma, gx, gz, partials, rows, threshold, scale, seed);
+  mono::partial_sum_kernel<<<2, 1024, 0, st>>>(partials, ggamma_gbeta, g, 512);
   return (int)hipGetLastError();
 }
 
+// Number of workgroups (= partial rows of C floats the caller provides) the row reductions below use for `rows` rows.
+int mono_reduce_blocks(long long rows) {
+  long long rpb = 64;
+  while ((rows + rpb - 1) / rpb > 1024) rpb *= 2;
+  return (int)((rows + rpb - 1) / rpb);
+}
+
+// out[c] = sum over rows of g[r][c];  g row-major [rows, C], C % 4 == 0, C <= 1024.
+// partials: scratch of mono_reduce_blocks(rows) * C floats.
+int mono_colsum_f32(const float *g, float *out, float *partials, long long rows, int C, void *stream_) {
+  if (!g || !out || !partials) return -1;
+  if (rows <= 0 || C <= 0 || C % 4 || C > 1024) return -2;
+  hipStream_t st = (hipStream_t)stream_;
+  const int grid = mono_reduce_blocks(rows);
+  const int rpb = (int)((rows + grid - 1) / grid + 63) / 64 * 64;
+  if (C <= 256) mono::colsum_kernel<1><<<grid, 256, 0, st>>>(g, partials, rows, C, rpb);
+  else if (C <= 512) mono::colsum_kernel<2><<<grid, 256, 0, st>>>(g, partials, rows, C, rpb);
+  else mono::colsum_kernel<4><<<grid, 256, 0, st>>>(g, partials, rows, C, rpb);
+  mono::partial_sum_kernel<<<(C / 4 + 63) / 64, 1024, 0, st>>>(partials, out, grid, C);
+  return (int)hipGetLastError();
+}
 
 // GroupNorm(G = 32, C = 256) (+ ReLU) on channels-last x [B, HW, 256].  stats [B, 32, 2] f64 must be zero on entry;
 // mean_rstd [B, 32, 2] f32 is written for the backward.

@@ -11,7 +11,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..pointwise import group_norm
+from ..pointwise import dropout_add_layernorm, group_norm
+from ..token_linear import token_linear
 
 
 class DepthEncoderLayer(nn.Module):
@@ -31,9 +32,9 @@ class DepthEncoderLayer(nn.Module):
     def forward(self, src, src_key_padding_mask, pos):
         qk = src if pos is None else src + pos
         attn = self.self_attn(qk, qk, value=src, key_padding_mask=src_key_padding_mask, need_weights=False)[0]
-        src = self.norm1(src + self.dropout1(attn))
-        ff = self.linear2(self.dropout(F.relu(self.linear1(src))))
-        return self.norm2(src + self.dropout2(ff))
+        src = dropout_add_layernorm(src, attn, self.norm1, self.dropout1)
+        ff = token_linear(self.dropout(F.relu(token_linear(src, self.linear1))), self.linear2)
+        return dropout_add_layernorm(src, ff, self.norm2, self.dropout2)
 
 
 class DepthEncoder(nn.Module):

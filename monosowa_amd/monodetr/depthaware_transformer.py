@@ -34,7 +34,7 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = layer(x)
+            x = token_linear(x, layer)
             if i < self.num_layers - 1:
                 x = F.relu(x)
         return x
@@ -170,7 +170,7 @@ class DepthAwareDecoderLayer(nn.Module):
                                level_start_index, src_padding_mask)
         tgt = dropout_add_layernorm(tgt, tgt2, self.norm1, self.dropout1)
         # ffn
-        ff = self.linear2(self.dropout3(F.relu(self.linear1(tgt))))
+        ff = token_linear(self.dropout3(F.relu(token_linear(tgt, self.linear1))), self.linear2)
         return dropout_add_layernorm(tgt, ff, self.norm3, self.dropout4)
 
 

@@ -7,7 +7,7 @@ import torch
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
-           "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32")
+           "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_colsum_f32", "mono_reduce_blocks")
 _lib = None
 
 
@@ -27,10 +27,14 @@ def load():
         lib.mono_dropout_add_layernorm_fwd_f32.argtypes = [P] * 8 + [LL, I, F, U, F, P]
         lib.mono_dropout_add_layernorm_bwd_f32.restype = I
         lib.mono_dropout_add_layernorm_bwd_f32.argtypes = [P] * 9 + [LL, I, F, U, P]
+        lib.mono_reduce_blocks.restype = I
+        lib.mono_reduce_blocks.argtypes = [LL]
         lib.mono_groupnorm_nhwc_fwd_f32.restype = I
         lib.mono_groupnorm_nhwc_fwd_f32.argtypes = [P] * 6 + [I, I, I, I, F, I, P]
         lib.mono_groupnorm_nhwc_bwd_f32.restype = I
         lib.mono_groupnorm_nhwc_bwd_f32.argtypes = [P] * 7 + [I, I, I, I, I, P]
+        lib.mono_colsum_f32.restype = I
+        lib.mono_colsum_f32.argtypes = [P, P, P, LL, I, P]
         _lib = lib
     return _lib
 
@@ -121,12 +125,13 @@ class _DropoutAddLayerNorm(torch.autograd.Function):
         s, mean, rstd, weight = ctx.saved_tensors
         gy = gy.contiguous()
         gx, gz = torch.empty_like(s), torch.empty_like(s)
-        gw = torch.zeros(2, 256, dtype=torch.float32, device=s.device)
+        rows = s.numel() // 256
+        gw = torch.empty(2, 256, dtype=torch.float32, device=s.device)
+        partials = torch.empty(load().mono_reduce_blocks(rows) * 512, dtype=torch.float32, device=s.device)
         with torch.cuda.device(s.device):
             code = load().mono_dropout_add_layernorm_bwd_f32(
                 gy.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), weight.data_ptr(), gx.data_ptr(), gz.data_ptr(),
-                gw[0].data_ptr(), gw[1].data_ptr(), s.numel() // 256, 256, float(ctx.p), ctx.seed,
-                torch.cuda.current_stream().cuda_stream)
+                gw.data_ptr(), partials.data_ptr(), rows, 256, float(ctx.p), ctx.seed, torch.cuda.current_stream().cuda_stream)
         if code:
             raise RuntimeError("mono_dropout_add_layernorm_bwd_f32 failed with code %d" % code)
         return gx, gz, gw[0], gw[1], None, None
@@ -184,3 +189,19 @@ def group_norm(x, gn, relu=False):
         return _GroupNormNHWC.apply(x, gn.weight, gn.bias, gn.eps, relu)
     y = gn(x)
     return torch.relu(y) if relu else y
+
+
+def colsum(g2):
+    """``g2.sum(0)`` of a [rows, C] matrix (bias gradients); HIP kernel for contiguous float32 GPU input with
+    C % 4 == 0 and C <= 256 (wider matrices: the PyTorch reduction is as fast), torch otherwise."""
+    if g2.is_cuda and g2.dtype == torch.float32 and g2.dim() == 2 and g2.is_contiguous() and g2.size(1) % 4 == 0 \
+            and g2.size(1) <= 256 and g2.size(0) > 0 and g2.data_ptr() % 16 == 0:
+        out = torch.empty(g2.size(1), dtype=torch.float32, device=g2.device)
+        partials = torch.empty(load().mono_reduce_blocks(g2.size(0)) * g2.size(1), dtype=torch.float32, device=g2.device)
+        with torch.cuda.device(g2.device):
+            code = load().mono_colsum_f32(g2.data_ptr(), out.data_ptr(), partials.data_ptr(), g2.size(0), g2.size(1),
+                                          torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_colsum_f32 failed with code %d" % code)
+        return out
+    return g2.sum(0)

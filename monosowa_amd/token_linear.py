@@ -10,7 +10,10 @@ Same math as ``F.linear`` (fp32 summation order differs in the weight gradient: 
 import torch
 import torch.nn.functional as F
 
-MIN_TOKENS = 32768
+from .pointwise import colsum
+
+MIN_TOKENS = 32768      # split-K weight gradient from here on
+MIN_ROWS = int(__import__('os').environ.get('MONOSOWA_TL_MIN_ROWS', '32768'))   # our backward from here on
 
 
 def _slices(tokens):
@@ -36,19 +39,19 @@ class _TokenLinear(torch.autograd.Function):
             gx = (g2 @ weight).view_as(x)
         if ctx.needs_input_grad[1]:
             x2 = x.reshape(-1, x.shape[-1])
-            s = _slices(x2.shape[0])
+            s = _slices(x2.shape[0]) if x2.shape[0] >= MIN_TOKENS else 0
             if s:
                 gw = torch.bmm(g2.view(s, -1, g2.shape[1]).transpose(1, 2), x2.view(s, -1, x2.shape[1])).sum(0)
             else:
                 gw = g2.t() @ x2
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g2.sum(0)
+            gb = colsum(g2.contiguous())
         return gx, gw, gb
 
 
 def token_linear(x, linear):
-    """``linear(x)`` for an ``nn.Linear``; routes through the split-K backward when there are enough tokens."""
-    tokens = x.numel() // x.shape[-1]
-    if x.is_cuda and tokens >= MIN_TOKENS and torch.is_grad_enabled() and linear.weight.requires_grad and _slices(tokens):
+    """``linear(x)`` for an ``nn.Linear``.  On the GPU under autograd the backward is ours: split-K weight gradient
+    when there are enough tokens, bias gradient through the column-sum kernel."""
+    if x.is_cuda and torch.is_grad_enabled() and linear.weight.requires_grad and x.numel() // x.shape[-1] >= MIN_ROWS:
         return _TokenLinear.apply(x, linear.weight, linear.bias)
     return linear(x)

@@ -234,7 +234,7 @@ def test_token_linear_split_k_backward_matches_linear():
     for a, b in zip(got, (x.grad, lin.weight.grad, lin.bias.grad)):
         assert (a - b).abs().max() <= 2e-5 * b.abs().max()
     small = torch.randn(2, 50, 256, device="cuda", requires_grad=True)
-    assert "TokenLinear" not in type(token_linear(small, lin).grad_fn).__name__
+    assert "TokenLinear" not in type(token_linear(small, lin).grad_fn).__name__      # few rows: plain nn.Linear
 
 
 def test_eval_forward_replays_from_a_hipgraph():
@@ -472,3 +472,15 @@ def test_groupnorm_nhwc_matches_torch(shape, relu):
     ref.backward(go.double())
     for a, b, n in zip(got, [ref.detach(), xd.grad, gnd.weight.grad, gnd.bias.grad], ("y", "gx", "gw", "gb")):
         assert (a.double() - b).abs().max() <= 3e-5 * max(b.abs().max().item(), 1.0), n
+
+
+@pytest.mark.parametrize("rows,C", [(8800, 256), (163200, 128), (30720, 512), (777, 1024), (5, 24), (1, 4)])
+def test_colsum_matches_torch(rows, C):
+    """mono_colsum_f32 (bias gradients) equals a float64 column sum."""
+    from monosowa_amd.pointwise import colsum
+    torch.manual_seed(rows)
+    g = torch.randn(rows, C, device="cuda")
+    ref = g.double().sum(0)
+    got = colsum(g)
+    assert got.shape == (C,)
+    assert (got.double() - ref).abs().max() <= 2e-6 * g.abs().double().sum(0).max()
