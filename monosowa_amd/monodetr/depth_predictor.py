@@ -107,9 +107,17 @@ class DepthPredictor(nn.Module):
 
     def interpolate_1d(self, coord, embed):
         """Linear interpolation in a learned 1-D table; the floor index is integer bookkeeping
-        (depth_predictor.py:99-104)."""
+        (depth_predictor.py:99-104: ``embed(floor) * (1 - delta) + embed(ceil) * delta``).
+
+        Evaluated as ``W @ embed.weight`` with W [pixels, table rows] holding the two interpolation weights of
+        each pixel: the table has 61 rows, so both the lookup and its gradient (30,720 pixels scattered into 61
+        rows; the embedding backward sorts them, 0.7 ms each) are small dense products."""
         floor_coord = coord.floor()
-        delta = (coord - floor_coord).unsqueeze(-1)
+        delta = coord - floor_coord
         floor_idx = floor_coord.long()
         ceil_idx = (floor_idx + 1).clamp(max=embed.num_embeddings - 1)
-        return embed(floor_idx) * (1 - delta) + embed(ceil_idx) * delta
+        n = coord.numel()
+        w = torch.zeros((n, embed.num_embeddings), dtype=coord.dtype, device=coord.device)
+        w = w.scatter(1, floor_idx.reshape(n, 1), (1 - delta).reshape(n, 1))
+        w = w.scatter_add(1, ceil_idx.reshape(n, 1), delta.reshape(n, 1))
+        return (w @ embed.weight).view(*coord.shape, embed.embedding_dim)

@@ -41,9 +41,10 @@ def main():
         torch.cuda.synchronize()
     want = sys.argv[1:] or ["aten::copy_", "aten::add", "aten::add_", "aten::sum", "aten::mul", "aten::index_put_", "aten::_index_put_impl_",
                             "aten::fill_", "aten::zero_", "aten::cat", "aten::clamp", "aten::upsample_bilinear2d"]
-    rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in want]
+    rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in want or "--all" in sys.argv]
+    want = [w for w in want if w != "--all"]
     rows.sort(key=lambda e: -e.self_device_time_total)
-    for e in rows[:70]:
+    for e in rows[:110 if '--all' in sys.argv else 70]:
         print("%-26s %8.1f us %4d x  %s" % (e.key, e.self_device_time_total, e.count, str(e.input_shapes)[:150]), flush=True)
 
 
