@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
     ap.add_argument("--graph", action="store_true", help="infer mode: replay the forward from a captured hipGraph")
     ap.add_argument("--miopen-find", action="store_true", help="cudnn.benchmark=True: MIOpen searches per conv shape (slow start)")
+    ap.add_argument("--no-miopen-db", action="store_true",
+                    help="ignore the shipped MIOpen find results (monosowa_amd/miopen_db) and use MIOpen's heuristics")
     return ap.parse_args()
 
 
@@ -157,9 +159,19 @@ class _StdoutGuard:
         os.close(self.saved)
 
 
+def default_conv_workload(args):
+    """The configuration the shipped find-db was measured on (every other one would start a search)."""
+    return args.batch == 16 and args.backbone == "resnet50" and args.resolution == "1280x384"
+
+
 def main():
     args = parse()
     guard = _StdoutGuard()
+    # measured MIOpen kernel choices for the default workload (monosowa_amd/miopen_tuning.py); before torch loads MIOpen
+    from monosowa_amd import miopen_tuning
+    tuned = None
+    if not args.no_miopen_db and not args.miopen_find and default_conv_workload(args):
+        tuned = miopen_tuning.use_shipped_db(int(os.environ.get("RANK", "0")))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -174,7 +186,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=device)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find or tuned)
+    log("MIOpen: %s" % ("shipped find-db " + tuned if tuned else "search" if args.miopen_find else "heuristics"))
     log("torch %s on %s, world %d" % (torch.__version__, torch.cuda.get_device_name(local_rank), world))
 
     from monosowa_amd import MultiScaleDeformableAttention as MSDA

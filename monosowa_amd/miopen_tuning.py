@@ -1,0 +1,37 @@
+"""Shipped MIOpen find results for the MonoDETR convolutions on MI355X.
+
+MIOpen picks a convolution kernel per problem either from its heuristics (PyTorch's default, `cudnn.benchmark =
+False`) or from a measured search ("find", `cudnn.benchmark = True`).  The search takes ~165 s for the ~160
+(problem, direction) pairs of a ResNet-50 MonoDETR train step at B = 16, 1280x384 and makes the step 2 % faster.
+`miopen_db/` holds the outcome of that search (MIOpen's own user find-db / perf-db text files, produced on an
+MI355X by `python bench.py --miopen-find` with MIOPEN_USER_DB_PATH pointing here, plus the kernel cache of the
+JIT-compiled winners when present), so a fresh process gets the measured choices without searching.
+
+`use_shipped_db()` must run before the first convolution (MIOpen reads the variables when its handle is created).
+Each rank works on its own copy: MIOpen appends to these files.
+"""
+import glob
+import os
+import shutil
+import tempfile
+
+DB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
+
+
+def shipped_db_available():
+    return bool(glob.glob(os.path.join(DB_DIR, "*.ufdb.txt")))
+
+
+def use_shipped_db(rank=0):
+    """Point MIOpen at a per-rank copy of the shipped find-db; returns the directory or None when there is none
+    (or when the caller already chose a MIOPEN_USER_DB_PATH)."""
+    if not shipped_db_available() or "MIOPEN_USER_DB_PATH" in os.environ:
+        return None
+    dst = os.path.join(tempfile.gettempdir(), "monosowa_miopen_%d_r%d_%d" % (os.getuid(), rank, os.getpid()))
+    os.makedirs(dst, exist_ok=True)
+    for f in glob.glob(os.path.join(DB_DIR, "*")):
+        if os.path.isfile(f) and not f.endswith(".md"):
+            shutil.copy(f, dst)
+    os.environ["MIOPEN_USER_DB_PATH"] = dst
+    os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = dst
+    return dst
