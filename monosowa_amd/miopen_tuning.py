@@ -30,8 +30,24 @@ def use_shipped_db(rank=0):
     dst = os.path.join(tempfile.gettempdir(), "monosowa_miopen_%d_r%d_%d" % (os.getuid(), rank, os.getpid()))
     os.makedirs(dst, exist_ok=True)
     for f in glob.glob(os.path.join(DB_DIR, "*")):
-        if os.path.isfile(f) and not f.endswith(".md"):
+        if os.path.isfile(f) and not f.endswith((".md", ".csv")):
             shutil.copy(f, dst)
     os.environ["MIOPEN_USER_DB_PATH"] = dst
     os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = dst
+    use_shipped_gemm_choices(dst)
     return dst
+
+
+def use_shipped_gemm_choices(scratch):
+    """PyTorch TunableOp results (which rocBLAS / hipBLASLt solution per GEMM shape of the train step; produced by
+    `PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 python bench.py`, 70 s) are replayed without tuning.
+    TunableOp appends the device ordinal to the file name, so the file is laid out once per ordinal; its
+    validator lines make PyTorch ignore it when the library versions differ."""
+    src = os.path.join(DB_DIR, "tunableop_gfx950.csv")
+    if not os.path.exists(src) or "PYTORCH_TUNABLEOP_ENABLED" in os.environ:
+        return
+    for ordinal in range(8):
+        shutil.copy(src, os.path.join(scratch, "tunableop%d.csv" % ordinal))
+    os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
+    os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
+    os.environ["PYTORCH_TUNABLEOP_FILENAME"] = os.path.join(scratch, "tunableop.csv")
