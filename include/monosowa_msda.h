@@ -61,7 +61,8 @@ int msda_abi_version(void);
 const char *msda_strerror(int code);
 
 /* Kernel-generation switches for A/B measurements and tests (process-wide; not thread-safe against
- * concurrent launches).  "gather": 0 | 1 | 2 (default 2), "scatter_fixed": 0 | 1 (default 1).  Every setting
+ * concurrent launches).  "gather": 0 | 1 | 2 (default 2), "scatter_fixed": 0 | 1 (default 1),
+ * "scatter_sorted": 0 | 1 | 2 (default 0; 1: the sort-then-sum scatter on long record lists, 2: always).  Every setting
  * computes the same function.  Returns 0, or MSDA_E_UNSUPPORTED for an unknown name / value. */
 int msda_set_option(const char *name, int value);
 

@@ -6,6 +6,7 @@
 #include "../../include/monosowa_msda.h"
 #include "msda_kernels.hip"
 #include "msda_backward_tiled.hip"
+#include "msda_backward_sorted.hip"
 #include "msda_gather_rec.hip"
 #include <cstdlib>
 #include <string>
@@ -70,14 +71,21 @@ bool make_gather_geom(const int64_t *shapes_host, const int64_t *lsi_host, int B
 // A tuning / A-B switch only; every mode computes the same function.
 // Kernel-generation switches (A/B measurement and test coverage; every setting computes the same function).
 //   gather        0: first-generation gather kernels, 1: tap records, 2 (default): records + coarse levels in LDS
+//   scatter_sorted 0 (default): never, 1: counting sort by bilinear cell + register sums (msda_backward_sorted.hip)
+//                  when a level's record list has >= 8192 points, 2: always.  Measured at B = 16, Lq = 10200:
+//                  0.90 vs 1.04 ms on random +-4 px offsets (tools/msda_kernel_bench.py) but 2.02 vs 1.88 ms per
+//                  backward inside the train step, whose freshly initialised offsets are whole pixels with ~5
+//                  points per cell -- hence opt-in.  Otherwise LDS-atomic tile accumulators, flavour by scatter_fixed:
 //   scatter_fixed 1 (default): 64-bit fixed-point tile accumulators (ds_add_u64), 0: double (ds_add_f64)
 // Initialised from MSDA_GATHER / MSDA_SCATTER_FIXED, changed at run time with msda_set_option().
 struct Options {
   int gather = 2;
   int scatter_fixed = 1;
+  int scatter_sorted = 0;
   Options() {
     if (const char *e = std::getenv("MSDA_GATHER")) gather = std::atoi(e);
     if (const char *e = std::getenv("MSDA_SCATTER_FIXED")) scatter_fixed = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MSDA_SCATTER_SORTED")) scatter_sorted = std::atoi(e);
   }
 };
 inline Options &options() {
@@ -252,7 +260,12 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         if (e != hipSuccess) return (int)e;
       }
       const int bm_groups = (B * M + 7) / 8;
-      if (scatter_fixed_point())
+      // measured (B = 16, KITTI pyramid): sorted 0.90 ms vs 1.04 ms at Lq = 10200; 0.259 vs 0.245 at Lq = 550; 0.137 vs
+      // 0.091 at Lq = 50 -- the batches' barriers only pay off on long record lists
+      if (options().scatter_sorted == 1 ? Lq * P >= 8192 : options().scatter_sorted == 2)
+        msda::bwd_scatter_sorted_kernel<<<8 * plan.n_items * bm_groups, msda::kSortThreads, 0, stream>>>(
+            rec_hw, rec_aw, boxes, grad_out, grad_value, plan, B, S, M, Lq, P, (int)ws.n_chunks_per_list);
+      else if (scatter_fixed_point())
         msda::bwd_scatter_kernel<true><<<8 * plan.n_items * bm_groups, msda::kScatterThreads, 0, stream>>>(
             rec_hw, rec_aw, boxes, bounds, grad_out, grad_value, plan, B, S, M, Lq, P, (int)ws.n_chunks_per_list);
       else
@@ -291,6 +304,7 @@ int msda_set_option(const char *name, int value) {
   const std::string n(name);
   if (n == "gather" && value >= 0 && value <= 2) { options().gather = value; return 0; }
   if (n == "scatter_fixed" && (value == 0 || value == 1)) { options().scatter_fixed = value; return 0; }
+  if (n == "scatter_sorted" && value >= 0 && value <= 2) { options().scatter_sorted = value; return 0; }
   return MSDA_E_UNSUPPORTED;
 }
 

@@ -262,14 +262,15 @@ def test_eval_forward_replays_from_a_hipgraph():
     assert torch.allclose(out2["pred_boxes"], eager2["pred_boxes"], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("gather,fixed", [(0, 0), (1, 1), (2, 0), (2, 1)])
-def test_every_kernel_generation_computes_the_same_function(gather, fixed):
+@pytest.mark.parametrize("gather,fixed,sorted_", [(0, 0, 0), (1, 1, 0), (2, 0, 0), (2, 1, 0), (2, 1, 2), (0, 0, 2)])
+def test_every_kernel_generation_computes_the_same_function(gather, fixed, sorted_):
     """The earlier kernel generations stay selectable (msda_set_option) for A/B measurements; all of them must
     pass the same parity bar on the shipped geometry (encoder-like and decoder-like query sets)."""
     from monosowa_amd import _lib
     try:
         _lib.set_option("gather", gather)
         _lib.set_option("scatter_fixed", fixed)
+        _lib.set_option("scatter_sorted", sorted_)
         for B, Lq, levels in ((2, 1275, [(24, 40), (12, 20), (6, 10), (3, 5)]), (2, 550, [(12, 40), (6, 20), (3, 10), (2, 5)])):
             value, shapes, lsi, loc, w, go = _random_case(gather * 7 + fixed, B, 8, 32, Lq, levels, 4, np.float32)
             want, want64 = _oracle_want(value, shapes, lsi, loc, w, go)
@@ -283,11 +284,12 @@ def test_every_kernel_generation_computes_the_same_function(gather, fixed):
             out = MSDA.ms_deform_attn_forward(v, s, i, lc, ww, 64)
             gv, gl, gw = MSDA.ms_deform_attn_backward(v, s, i, lc, ww, g, 64)
             for got, ref, name in ((out, want[0], "out"), (gv, want[1], "grad_value"), (gl, want[2], "grad_loc"), (gw, want[3], "grad_attw")):
-                _close(got, ref, 1e-4, "%s (gather=%d fixed=%d)" % (name, gather, fixed))
+                _close(got, ref, 1e-4, "%s (gather=%d fixed=%d sorted=%d)" % (name, gather, fixed, sorted_))
             _close(gv, want64[1], 1e-4, "grad_value vs f64")
     finally:
         _lib.set_option("gather", 2)
         _lib.set_option("scatter_fixed", 1)
+        _lib.set_option("scatter_sorted", 0)
     with pytest.raises(RuntimeError):
         _lib.set_option("no_such_option", 1)
 
