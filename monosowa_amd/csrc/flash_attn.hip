@@ -1,0 +1,483 @@
+// fp32 multi-head attention with head_dim 32 for gfx950 (MI355X): softmax(Q K^T / sqrt(d)) V with dropout on the
+// attention probabilities, never materialising the [Lq, Lk] score matrix ("flash" formulation), on the exact-f32
+// matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the core of nn.MultiheadAttention in MonoDETR's depth encoder (depth_predictor/transformer.py:57-65,
+// 1920 x 1920 tokens) and the decoder's depth cross-attention (depthaware_transformer.py:417-423, 550 x 1920),
+// which PyTorch runs through a generic fp32 kernel at ~30 % of the f32 MFMA rate.
+//
+// Layout trick (all three kernels): scores are computed TRANSPOSED, S^T[key][query] = K Q^T, so that in the
+// 32x32 accumulator layout (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) a lane owns ONE
+// query and 16 keys.  Row statistics (max, sum, the rescale factor, dropout seed) are then per-lane scalars, the
+// only cross-lane step is one exchange between lanes l and l ^ 32, and P^T feeds the second product straight from
+// its accumulator registers: O^T[d][q] += sum_key V^T[d][key] P^T[key][q] takes B = P^T register t at MFMA step
+// t when A = V[key(t, half)][d = lane & 31] with key(t, half) = 8 (t >> 2) + 4 half + (t & 3).
+#include <hip/hip_runtime.h>
+
+#include "../../include/monosowa_attn.h"
+
+namespace attn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBlockQ = 128;     // queries per workgroup (4 waves x 32)
+constexpr int kTileK = 64;       // keys per LDS tile
+constexpr int kKStride = 36;     // floats per K row in LDS: 16-lane ds_read_b128 phases hit 64 distinct banks
+constexpr int kVStride = 40;     // floats per V row: rows r and r + 4 (the two lane halves) are 32 banks apart
+
+struct Strides { long long b, h, t; };   // in floats; the 32 channels of a head are contiguous
+
+struct Args {
+  const float *q, *k, *v;
+  float *o, *lse;                // lse: [B*H, Lq], log2 domain: row max + log2(row sum) of the scaled scores
+  const float *dout, *delta;     // backward only
+  float *dq, *dk, *dv;           // backward only
+  int H, Lq, Lk;
+  Strides sq, sk, sv, so;        // so also addresses dout
+  Strides sdq, sdk, sdv;
+  float scale_log2;              // softmax scale * log2(e)
+  float scale;                   // softmax scale
+  unsigned drop_thr16;           // drop when the element's 16 random bits < thr (0: no dropout)
+  float drop_scale;              // 1 / (1 - p)
+  unsigned seed_lo, seed_hi;
+};
+
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+// 32 random bits for the key pair (2 kp, 2 kp + 1) of query q; element (q, key) uses half key & 1.
+__device__ __forceinline__ unsigned drop_bits(unsigned head_seed, unsigned q, unsigned kp) {
+  return mix32(head_seed + q * 0x9E3779B1u + kp * 0x85EBCA77u);
+}
+__device__ __forceinline__ unsigned head_seed_of(const Args &a, unsigned bh) {
+  return mix32(a.seed_lo ^ (bh * 0xC2B2AE3Du)) ^ a.seed_hi;
+}
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }      // lane l <-> l ^ 32
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// ---------------------------------------------------------------------------------------------- forward
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void fwd_kernel(const Args a) {
+  __shared__ float Ks[2][kTileK * kKStride];
+  __shared__ float Vs[2][kTileK * kVStride];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
+  const int q = blockIdx.x * kBlockQ + wave * 32 + r;
+  const int qc = min(q, a.Lq - 1);
+  const float *qp = a.q + b * a.sq.b + hd * a.sq.h + (long long)qc * a.sq.t + 16 * h;
+  float qreg[16];                                       // Q[q][16 h + t], pre-scaled: scores come out in the log2 domain
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 t = ld4(qp + 4 * i);
+    qreg[4 * i] = t.x * a.scale_log2; qreg[4 * i + 1] = t.y * a.scale_log2;
+    qreg[4 * i + 2] = t.z * a.scale_log2; qreg[4 * i + 3] = t.w * a.scale_log2;
+  }
+  const float *kb = a.k + b * a.sk.b + hd * a.sk.h, *vb = a.v + b * a.sv.b + hd * a.sv.h;
+  const int n_tiles = (a.Lk + kTileK - 1) / kTileK;
+  float4 kr[2], vr[2];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = threadIdx.x + 256 * j, key = kt * kTileK + (idx >> 3), c = (idx & 7) * 4;
+      const bool ok = key < a.Lk;
+      kr[j] = ok ? ld4(kb + (long long)key * a.sk.t + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      vr[j] = ok ? ld4(vb + (long long)key * a.sv.t + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = threadIdx.x + 256 * j, row = idx >> 3, c = (idx & 7) * 4;
+      *reinterpret_cast<float4 *>(&Ks[buf][row * kKStride + c]) = kr[j];
+      *reinterpret_cast<float4 *>(&Vs[buf][row * kVStride + c]) = vr[j];
+    }
+  };
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const unsigned hseed = DROP ? head_seed_of(a, (unsigned)bh) : 0u;
+  f32x16 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, lsum = 0.f;
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < n_tiles) load_tile(kt + 1);            // in flight during the products below
+    // S^T = K Q^T for the two 32-key halves of the tile
+    f32x16 s0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    const float *k0 = &Ks[buf][r * kKStride + 16 * h], *k1 = k0 + 32 * kKStride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 a0 = ld4(k0 + 4 * i), a1 = ld4(k1 + 4 * i);
+      s0 = mfma(a0.x, qreg[4 * i], s0);     s1 = mfma(a1.x, qreg[4 * i], s1);
+      s0 = mfma(a0.y, qreg[4 * i + 1], s0); s1 = mfma(a1.y, qreg[4 * i + 1], s1);
+      s0 = mfma(a0.z, qreg[4 * i + 2], s0); s1 = mfma(a1.z, qreg[4 * i + 2], s1);
+      s0 = mfma(a0.w, qreg[4 * i + 3], s0); s1 = mfma(a1.w, qreg[4 * i + 3], s1);
+    }
+    const int key0 = kt * kTileK + 4 * h;                // + 8 (v >> 2) + (v & 3) (+ 32 for s1)
+    if (kt == n_tiles - 1 && (a.Lk & (kTileK - 1))) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int key = key0 + 8 * (v >> 2) + (v & 3);
+        if (key >= a.Lk) s0[v] = -INFINITY;
+        if (key + 32 >= a.Lk) s1[v] = -INFINITY;
+      }
+    }
+    float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int v = 1; v < 16; ++v) mx = fmaxf(mx, fmaxf(s0[v], s1[v]));
+    mx = fmaxf(mx, xhalf(mx));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      s0[v] = __builtin_amdgcn_exp2f(s0[v] - m_new);
+      s1[v] = __builtin_amdgcn_exp2f(s1[v] - m_new);
+      rs += s0[v] + s1[v];
+    }
+    lsum = lsum * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) o[v] *= alpha;
+    if (DROP) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const unsigned kp = (unsigned)(key0 + 8 * g + 2 * pr) >> 1;
+          const unsigned b0 = drop_bits(hseed, (unsigned)q, kp), b1 = drop_bits(hseed, (unsigned)q, kp + 16u);
+          s0[4 * g + 2 * pr] = (b0 & 0xFFFFu) >= a.drop_thr16 ? s0[4 * g + 2 * pr] * a.drop_scale : 0.f;
+          s0[4 * g + 2 * pr + 1] = (b0 >> 16) >= a.drop_thr16 ? s0[4 * g + 2 * pr + 1] * a.drop_scale : 0.f;
+          s1[4 * g + 2 * pr] = (b1 & 0xFFFFu) >= a.drop_thr16 ? s1[4 * g + 2 * pr] * a.drop_scale : 0.f;
+          s1[4 * g + 2 * pr + 1] = (b1 >> 16) >= a.drop_thr16 ? s1[4 * g + 2 * pr + 1] * a.drop_scale : 0.f;
+        }
+      }
+    }
+    // O^T += V^T P^T
+    const float *v0 = &Vs[buf][(4 * h) * kVStride + r], *v1 = v0 + 32 * kVStride;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int row = 8 * (t >> 2) + (t & 3);
+      o = mfma(v0[row * kVStride], s0[t], o);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int row = 8 * (t >> 2) + (t & 3);
+      o = mfma(v1[row * kVStride], s1[t], o);
+    }
+    if (kt + 1 < n_tiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  lsum += xhalf(lsum);
+  if (q < a.Lq) {
+    const float inv = 1.f / lsum;
+    float *op = a.o + b * a.so.b + hd * a.so.h + (long long)q * a.so.t + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4 *>(op + 8 * g) = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+    if (h == 0) a.lse[(long long)bh * a.Lq + q] = m + __builtin_amdgcn_logf(lsum);     // v_log_f32 = log2
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------- backward
+// delta[bh][q] = sum_d dO[q][d] * O[q][d]; 8 lanes x float4 per (batch, head, query), heads fastest so that the
+// [L, B, H*32] projections are read in contiguous runs.
+__global__ __launch_bounds__(256) void delta_kernel(const Args a, int B) {
+  const long long g = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int sub = threadIdx.x & 7;
+  const long long n = (long long)a.Lq * B * a.H;
+  if (g >= n) return;
+  const int hd = (int)(g % a.H), b = (int)((g / a.H) % B), q = (int)(g / ((long long)a.H * B));
+  const long long off = b * a.so.b + hd * a.so.h + (long long)q * a.so.t + sub * 4;
+  const float4 x = ld4(a.dout + off), y = ld4(a.o + off);
+  float d = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+  d += __shfl_xor(d, 4); d += __shfl_xor(d, 2); d += __shfl_xor(d, 1);
+  if (sub == 0) const_cast<float *>(a.delta)[((long long)b * a.H + hd) * a.Lq + q] = d;
+}
+
+// dQ: same decomposition as the forward (a lane owns one query); per 32-key half: S^T (recomputed), dP^T = V dO^T,
+// dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T -- 48 MFMAs.
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const Args a) {
+  __shared__ float Ks[2][kTileK * kKStride];
+  __shared__ float Vs[2][kTileK * kKStride];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
+  const int q = blockIdx.x * kBlockQ + wave * 32 + r;
+  const int qc = min(q, a.Lq - 1);
+  const float *qp = a.q + b * a.sq.b + hd * a.sq.h + (long long)qc * a.sq.t + 16 * h;
+  const float *dop = a.dout + b * a.so.b + hd * a.so.h + (long long)qc * a.so.t + 16 * h;
+  float qreg[16], doreg[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 t = ld4(qp + 4 * i), u = ld4(dop + 4 * i);
+    qreg[4 * i] = t.x * a.scale_log2; qreg[4 * i + 1] = t.y * a.scale_log2;
+    qreg[4 * i + 2] = t.z * a.scale_log2; qreg[4 * i + 3] = t.w * a.scale_log2;
+    doreg[4 * i] = u.x; doreg[4 * i + 1] = u.y; doreg[4 * i + 2] = u.z; doreg[4 * i + 3] = u.w;
+  }
+  const float lse = a.lse[(long long)bh * a.Lq + qc], delta = a.delta[(long long)bh * a.Lq + qc];
+  const float *kb = a.k + b * a.sk.b + hd * a.sk.h, *vb = a.v + b * a.sv.b + hd * a.sv.h;
+  const int n_tiles = (a.Lk + kTileK - 1) / kTileK;
+  float4 kr[2], vr[2];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = threadIdx.x + 256 * j, key = kt * kTileK + (idx >> 3), c = (idx & 7) * 4;
+      const bool ok = key < a.Lk;
+      kr[j] = ok ? ld4(kb + (long long)key * a.sk.t + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      vr[j] = ok ? ld4(vb + (long long)key * a.sv.t + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = threadIdx.x + 256 * j, row = idx >> 3, c = (idx & 7) * 4;
+      *reinterpret_cast<float4 *>(&Ks[buf][row * kKStride + c]) = kr[j];
+      *reinterpret_cast<float4 *>(&Vs[buf][row * kKStride + c]) = vr[j];
+    }
+  };
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const unsigned hseed = DROP ? head_seed_of(a, (unsigned)bh) : 0u;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 dq = zero;
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < n_tiles) load_tile(kt + 1);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x16 s = zero, dp = zero;
+      const float *k0 = &Ks[buf][(half * 32 + r) * kKStride + 16 * h], *v0 = &Vs[buf][(half * 32 + r) * kKStride + 16 * h];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 ka = ld4(k0 + 4 * i), va = ld4(v0 + 4 * i);
+        s = mfma(ka.x, qreg[4 * i], s);     dp = mfma(va.x, doreg[4 * i], dp);
+        s = mfma(ka.y, qreg[4 * i + 1], s); dp = mfma(va.y, doreg[4 * i + 1], dp);
+        s = mfma(ka.z, qreg[4 * i + 2], s); dp = mfma(va.z, doreg[4 * i + 2], dp);
+        s = mfma(ka.w, qreg[4 * i + 3], s); dp = mfma(va.w, doreg[4 * i + 3], dp);
+      }
+      const int key0 = kt * kTileK + half * 32 + 4 * h;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int key = key0 + 8 * (v >> 2) + (v & 3);
+        float p = __builtin_amdgcn_exp2f(s[v] - lse);
+        if (key >= a.Lk) p = 0.f;
+        float dpe = dp[v];
+        if (DROP) {
+          const unsigned bits = drop_bits(hseed, (unsigned)q, (unsigned)key >> 1);        // CSE'd across the pair
+          const unsigned mine = (key & 1) ? (bits >> 16) : (bits & 0xFFFFu);
+          dpe = mine >= a.drop_thr16 ? dpe * a.drop_scale : 0.f;
+        }
+        s[v] = p * (dpe - delta);                                                          // dS^T
+      }
+      // dQ^T += K^T dS^T : A = K[key(t, h)][d = r]
+      const float *kc = &Ks[buf][(half * 32 + 4 * h) * kKStride + r];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) dq = mfma(kc[(8 * (t >> 2) + (t & 3)) * kKStride], s[t], dq);
+    }
+    if (kt + 1 < n_tiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  if (q < a.Lq) {
+    float *dst = a.dq + b * a.sdq.b + hd * a.sdq.h + (long long)q * a.sdq.t + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4 *>(dst + 8 * g) = make_float4(dq[4 * g] * a.scale, dq[4 * g + 1] * a.scale, dq[4 * g + 2] * a.scale, dq[4 * g + 3] * a.scale);
+  }
+}
+
+// dK, dV: a lane owns one KEY (S = Q K^T untransposed: col = key, rows = 16 queries); per 32-query half:
+// S, dP = dO V^T, dV^T += dO^T P_drop, dK^T += Q^T dS -- 64 MFMAs.  Row statistics (lse, delta) come from LDS.
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void bwd_dkdv_kernel(const Args a) {
+  __shared__ float Qs[2][kTileK * kKStride];
+  __shared__ float Ds[2][kTileK * kKStride];
+  __shared__ float Ls[2][kTileK], Es[2][kTileK];          // lse, delta of the tile's queries
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
+  const int key = blockIdx.x * kBlockQ + wave * 32 + r;
+  const int kc_ = min(key, a.Lk - 1);
+  const float *kp = a.k + b * a.sk.b + hd * a.sk.h + (long long)kc_ * a.sk.t + 16 * h;
+  const float *vp = a.v + b * a.sv.b + hd * a.sv.h + (long long)kc_ * a.sv.t + 16 * h;
+  float kreg[16], vreg[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 t = ld4(kp + 4 * i), u = ld4(vp + 4 * i);
+    kreg[4 * i] = t.x * a.scale_log2; kreg[4 * i + 1] = t.y * a.scale_log2;
+    kreg[4 * i + 2] = t.z * a.scale_log2; kreg[4 * i + 3] = t.w * a.scale_log2;
+    vreg[4 * i] = u.x; vreg[4 * i + 1] = u.y; vreg[4 * i + 2] = u.z; vreg[4 * i + 3] = u.w;
+  }
+  const float *qb = a.q + b * a.sq.b + hd * a.sq.h, *dob = a.dout + b * a.so.b + hd * a.so.h;
+  const float *lb = a.lse + (long long)bh * a.Lq, *eb = a.delta + (long long)bh * a.Lq;
+  const int n_tiles = (a.Lq + kTileK - 1) / kTileK;
+  float4 qr[2], dr[2];
+  float lr = 0.f, er = 0.f;
+  auto load_tile = [&](int qt) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = threadIdx.x + 256 * j, qq = qt * kTileK + (idx >> 3), c = (idx & 7) * 4;
+      const bool ok = qq < a.Lq;
+      qr[j] = ok ? ld4(qb + (long long)qq * a.sq.t + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dr[j] = ok ? ld4(dob + (long long)qq * a.so.t + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (threadIdx.x < kTileK) {
+      const int qq = qt * kTileK + threadIdx.x;
+      lr = qq < a.Lq ? lb[qq] : INFINITY;               // exp2(s - inf) = 0: padded queries contribute nothing
+      er = qq < a.Lq ? eb[qq] : 0.f;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = threadIdx.x + 256 * j, row = idx >> 3, c = (idx & 7) * 4;
+      *reinterpret_cast<float4 *>(&Qs[buf][row * kKStride + c]) = qr[j];
+      *reinterpret_cast<float4 *>(&Ds[buf][row * kKStride + c]) = dr[j];
+    }
+    if (threadIdx.x < kTileK) { Ls[buf][threadIdx.x] = lr; Es[buf][threadIdx.x] = er; }
+  };
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const unsigned hseed = DROP ? head_seed_of(a, (unsigned)bh) : 0u;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 dk = zero, dv = zero;
+  for (int qt = 0; qt < n_tiles; ++qt) {
+    const int buf = qt & 1;
+    if (qt + 1 < n_tiles) load_tile(qt + 1);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x16 s = zero, dp = zero;
+      const float *q0 = &Qs[buf][(half * 32 + r) * kKStride + 16 * h], *d0 = &Ds[buf][(half * 32 + r) * kKStride + 16 * h];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 qa = ld4(q0 + 4 * i), da = ld4(d0 + 4 * i);
+        s = mfma(qa.x, kreg[4 * i], s);     dp = mfma(da.x, vreg[4 * i], dp);
+        s = mfma(qa.y, kreg[4 * i + 1], s); dp = mfma(da.y, vreg[4 * i + 1], dp);
+        s = mfma(qa.z, kreg[4 * i + 2], s); dp = mfma(da.z, vreg[4 * i + 2], dp);
+        s = mfma(qa.w, kreg[4 * i + 3], s); dp = mfma(da.w, vreg[4 * i + 3], dp);
+      }
+      const int q0i = qt * kTileK + half * 32 + 4 * h;       // query of register v: q0i + 8 (v >> 2) + (v & 3)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 l4 = ld4(&Ls[buf][half * 32 + 4 * h + 8 * g]), e4 = ld4(&Es[buf][half * 32 + 4 * h + 8 * g]);
+        const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, es[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int v = 4 * g + j;
+          const float p = __builtin_amdgcn_exp2f(s[v] - ls[j]);
+          float pd = p, dpe = dp[v];
+          if (DROP) {
+            const unsigned bits = drop_bits(hseed, (unsigned)(q0i + 8 * g + j), (unsigned)key >> 1);
+            const unsigned mine = (key & 1) ? (bits >> 16) : (bits & 0xFFFFu);
+            const bool keep = mine >= a.drop_thr16;
+            pd = keep ? p * a.drop_scale : 0.f;
+            dpe = keep ? dpe * a.drop_scale : 0.f;
+          }
+          dp[v] = pd;                                          // P_drop   (operand of dV)
+          s[v] = p * (dpe - es[j]);                            // dS       (operand of dK)
+        }
+      }
+      const float *dc = &Ds[buf][(half * 32 + 4 * h) * kKStride + r], *qc = &Qs[buf][(half * 32 + 4 * h) * kKStride + r];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = (8 * (t >> 2) + (t & 3)) * kKStride;
+        dv = mfma(dc[row], dp[t], dv);
+        dk = mfma(qc[row], s[t], dk);
+      }
+    }
+    if (qt + 1 < n_tiles) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  if (key < a.Lk) {
+    float *dkp = a.dk + b * a.sdk.b + hd * a.sdk.h + (long long)key * a.sdk.t + 4 * h;
+    float *dvp = a.dv + b * a.sdv.b + hd * a.sdv.h + (long long)key * a.sdv.t + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *reinterpret_cast<float4 *>(dkp + 8 * g) = make_float4(dk[4 * g] * a.scale, dk[4 * g + 1] * a.scale, dk[4 * g + 2] * a.scale, dk[4 * g + 3] * a.scale);
+      *reinterpret_cast<float4 *>(dvp + 8 * g) = make_float4(dv[4 * g], dv[4 * g + 1], dv[4 * g + 2], dv[4 * g + 3]);
+    }
+  }
+}
+
+}  // namespace attn
+
+namespace {
+
+inline attn::Strides cvt(mono_attn_strides s) { return attn::Strides{s.batch, s.head, s.token}; }
+
+inline void fill_common(attn::Args &a, int H, int Lq, int Lk, float scale, float p, unsigned long long seed) {
+  a.H = H; a.Lq = Lq; a.Lk = Lk;
+  a.scale = scale;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  a.drop_thr16 = (unsigned)(p * 65536.0f + 0.5f);
+  a.drop_scale = a.drop_thr16 ? 65536.0f / (65536.0f - (float)a.drop_thr16) : 1.f;     // exactly 1 / P(keep)
+  a.seed_lo = (unsigned)seed;
+  a.seed_hi = (unsigned)(seed >> 32);
+}
+
+inline bool aligned16(const void *p, mono_attn_strides s) {
+  return ((uintptr_t)p % 16 == 0) && s.batch % 4 == 0 && s.head % 4 == 0 && s.token % 4 == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mono_attn_forward_f32(const float *q, const float *k, const float *v, float *o, float *lse, int B, int H, int Lq,
+                          int Lk, int head_dim, mono_attn_strides sq, mono_attn_strides sk, mono_attn_strides sv,
+                          mono_attn_strides so, float softmax_scale, float dropout_p, unsigned long long seed,
+                          void *stream_) {
+  if (!q || !k || !v || !o || !lse) return MONO_ATTN_E_NULLPTR;
+  if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || head_dim != 32 || !(dropout_p >= 0.f && dropout_p < 1.f) ||
+      (long long)B * H > 65535)
+    return MONO_ATTN_E_SHAPE;
+  if (!aligned16(q, sq) || !aligned16(k, sk) || !aligned16(v, sv) || !aligned16(o, so)) return MONO_ATTN_E_SHAPE;
+  attn::Args a{};
+  a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse;
+  a.sq = cvt(sq); a.sk = cvt(sk); a.sv = cvt(sv); a.so = cvt(so);
+  fill_common(a, H, Lq, Lk, softmax_scale, dropout_p, seed);
+  const dim3 grid((Lq + attn::kBlockQ - 1) / attn::kBlockQ, B * H);
+  hipStream_t st = (hipStream_t)stream_;
+  if (a.drop_thr16) attn::fwd_kernel<true><<<grid, 256, 0, st>>>(a);
+  else attn::fwd_kernel<false><<<grid, 256, 0, st>>>(a);
+  return (int)hipGetLastError();
+}
+
+
+int mono_attn_backward_f32(const float *q, const float *k, const float *v, const float *o, const float *lse,
+                           const float *dout, float *dq, float *dk, float *dv, float *delta, int B, int H, int Lq,
+                           int Lk, int head_dim, mono_attn_strides sq, mono_attn_strides sk, mono_attn_strides sv,
+                           mono_attn_strides so, mono_attn_strides sdq, mono_attn_strides sdk, mono_attn_strides sdv,
+                           float softmax_scale, float dropout_p, unsigned long long seed, void *stream_) {
+  if (!q || !k || !v || !o || !lse || !dout || !dq || !dk || !dv || !delta) return MONO_ATTN_E_NULLPTR;
+  if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || head_dim != 32 || !(dropout_p >= 0.f && dropout_p < 1.f) ||
+      (long long)B * H > 65535)
+    return MONO_ATTN_E_SHAPE;
+  if (!aligned16(q, sq) || !aligned16(k, sk) || !aligned16(v, sv) || !aligned16(o, so) || !aligned16(dout, so) ||
+      !aligned16(dq, sdq) || !aligned16(dk, sdk) || !aligned16(dv, sdv))
+    return MONO_ATTN_E_SHAPE;
+  attn::Args a{};
+  a.q = q; a.k = k; a.v = v; a.o = const_cast<float *>(o); a.lse = const_cast<float *>(lse);
+  a.dout = dout; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
+  a.sq = cvt(sq); a.sk = cvt(sk); a.sv = cvt(sv); a.so = cvt(so);
+  a.sdq = cvt(sdq); a.sdk = cvt(sdk); a.sdv = cvt(sdv);
+  fill_common(a, H, Lq, Lk, softmax_scale, dropout_p, seed);
+  hipStream_t st = (hipStream_t)stream_;
+  const long long groups = (long long)Lq * B * H;
+  attn::delta_kernel<<<(unsigned)((groups + 31) / 32), 256, 0, st>>>(a, B);
+  const dim3 gq((Lq + attn::kBlockQ - 1) / attn::kBlockQ, B * H), gk((Lk + attn::kBlockQ - 1) / attn::kBlockQ, B * H);
+  if (a.drop_thr16) {
+    attn::bwd_dq_kernel<true><<<gq, 256, 0, st>>>(a);
+    attn::bwd_dkdv_kernel<true><<<gk, 256, 0, st>>>(a);
+  } else {
+    attn::bwd_dq_kernel<false><<<gq, 256, 0, st>>>(a);
+    attn::bwd_dkdv_kernel<false><<<gk, 256, 0, st>>>(a);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

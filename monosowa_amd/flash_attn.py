@@ -1,0 +1,155 @@
+"""fp32 head_dim-32 attention through the C-ABI library (include/monosowa_attn.h): the scaled-dot-product core of
+MonoDETR's depth-encoder self-attention and decoder depth cross-attention on the exact-f32 matrix cores."""
+import ctypes
+import math
+import os
+
+import torch
+
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_attn.so")
+SYMBOLS = ("mono_attn_forward_f32", "mono_attn_backward_f32")
+_lib = None
+
+
+class _Strides(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_longlong), ("head", ctypes.c_longlong), ("token", ctypes.c_longlong)]
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            raise RuntimeError("HIP extension %s is missing: run `python -m monosowa_amd.build`" % _PATH)
+        lib = ctypes.CDLL(_PATH)
+        P, I, F, U = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_ulonglong
+        lib.mono_attn_forward_f32.restype = I
+        lib.mono_attn_forward_f32.argtypes = [P] * 5 + [I] * 5 + [_Strides] * 4 + [F, F, U, P]
+        lib.mono_attn_backward_f32.restype = I
+        lib.mono_attn_backward_f32.argtypes = [P] * 10 + [I] * 5 + [_Strides] * 7 + [F, F, U, P]
+        _lib = lib
+    return _lib
+
+
+def _strides(t):
+    """t: [B, H, L, 32] view with a contiguous last dimension."""
+    assert t.stride(3) == 1
+    return _Strides(t.stride(0), t.stride(1), t.stride(2))
+
+
+def supported(q, k, v):
+    ok = lambda t: t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.size(3) == 32 and t.stride(3) == 1 \
+        and t.data_ptr() % 16 == 0 and all(s % 4 == 0 for s in t.stride()[:3])
+    return ok(q) and ok(k) and ok(v) and q.size(0) * q.size(1) <= 65535 and k.shape == v.shape \
+        and q.shape[:2] == k.shape[:2]
+
+
+_seed_counter = [0]
+
+
+def _next_seed():
+    _seed_counter[0] += 1
+    rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter[0] * 0xD1B54A32D192ED03 + rank * 0x94D049BB133111EB) & (2 ** 64 - 1)
+
+
+def forward(q, k, v, scale, p, seed):
+    B, H, Lq, _ = q.shape
+    o = torch.empty((B, H, Lq, 32), dtype=torch.float32, device=q.device)
+    lse = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        code = load().mono_attn_forward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Lq,
+                                            k.size(2), 32, _strides(q), _strides(k), _strides(v), _strides(o), float(scale),
+                                            float(p), seed, torch.cuda.current_stream().cuda_stream)
+    if code:
+        raise RuntimeError("mono_attn_forward_f32 failed with code %d" % code)
+    return o, lse
+
+
+def backward(q, k, v, o, lse, dout, scale, p, seed):
+    """dq, dk, dv as [B, H, L, 32] views of fresh [L, B, H*32] buffers (the layout of the MHA projections)."""
+    B, H, Lq, _ = q.shape
+    Lk = k.size(2)
+    mk = lambda L: torch.empty((L, B, H * 32), dtype=torch.float32, device=q.device).view(L, B, H, 32).permute(1, 2, 0, 3)
+    dq, dk, dv = mk(Lq), mk(Lk), mk(Lk)
+    delta = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
+    assert dout.stride() == o.stride()
+    with torch.cuda.device(q.device):
+        code = load().mono_attn_backward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), dout.data_ptr(),
+                                             dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Lq, Lk, 32,
+                                             _strides(q), _strides(k), _strides(v), _strides(o), _strides(dq), _strides(dk),
+                                             _strides(dv), float(scale), float(p), seed, torch.cuda.current_stream().cuda_stream)
+    if code:
+        raise RuntimeError("mono_attn_backward_f32 failed with code %d" % code)
+    return dq, dk, dv
+
+
+class _Attention(torch.autograd.Function):
+    """q, k, v: [B, H, L, 32] (strided views are fine); returns O as a [B, H, Lq, 32] view of an [Lq, B, H*32] buffer."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale, p, seed):
+        B, H, Lq, _ = q.shape
+        obuf = torch.empty((Lq, B, H * 32), dtype=torch.float32, device=q.device)
+        o = obuf.view(Lq, B, H, 32).permute(1, 2, 0, 3)
+        lse = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            code = load().mono_attn_forward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Lq,
+                                                k.size(2), 32, _strides(q), _strides(k), _strides(v), _strides(o), float(scale),
+                                                float(p), seed, torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_attn_forward_f32 failed with code %d" % code)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.scale, ctx.p, ctx.seed = scale, p, seed
+        return o
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, o, lse = ctx.saved_tensors
+        if dout.stride() != o.stride():
+            buf = torch.empty((o.size(2), o.size(0), o.size(1) * 32), dtype=torch.float32, device=o.device)
+            d2 = buf.view(o.size(2), o.size(0), o.size(1), 32).permute(1, 2, 0, 3)
+            d2.copy_(dout)
+            dout = d2
+        dq, dk, dv = backward(q, k, v, o, lse, dout, ctx.scale, ctx.p, ctx.seed)
+        return dq, dk, dv, None, None, None
+
+
+def attention(q, k, v, dropout_p=0.0, scale=None, seed=None):
+    """softmax(q k^T * scale) with dropout, times v, per (batch, head); q/k/v [B, H, L, 32] float32 on the GPU."""
+    if not supported(q, k, v):
+        raise RuntimeError("flash_attn.attention: unsupported tensors (need float32 GPU [B,H,L,32], 16-byte aligned strides)")
+    scale = 1.0 / math.sqrt(q.size(-1)) if scale is None else scale
+    if dropout_p > 0 and seed is None:
+        seed = _next_seed()
+    return _Attention.apply(q, k, v, scale, float(dropout_p), int(seed or 0))
+
+
+def mha_forward(mha, query, key, value):
+    """``mha(query, key, value, need_weights=False)[0]`` for an ``nn.MultiheadAttention`` with 32-channel heads, no
+    masks, [L, B, E] inputs: packed input projections, the HIP attention core on strided views (no head-major
+    copies), output projection.  (torch.nn.functional.multi_head_attention_forward, as called at
+    depth_predictor/transformer.py:59 and depthaware_transformer.py:417.)"""
+    E, H = mha.embed_dim, mha.num_heads
+    w, bias = mha.in_proj_weight, mha.in_proj_bias
+    Lq, B, _ = query.shape
+    Lk = key.size(0)
+    lin = torch.nn.functional.linear
+    if query is key:                                    # depth encoder: q = k = src + pos, v = src
+        qk = lin(query, w[:2 * E], bias[:2 * E])
+        q, k = qk[..., :E], qk[..., E:]
+        v = lin(value, w[2 * E:], bias[2 * E:])
+    elif key is value:                                  # decoder: k = v = depth-aware tokens
+        q = lin(query, w[:E], bias[:E])
+        kv = lin(key, w[E:], bias[E:])
+        k, v = kv[..., :E], kv[..., E:]
+    else:
+        q, k, v = lin(query, w[:E], bias[:E]), lin(key, w[E:2 * E], bias[E:2 * E]), lin(value, w[2 * E:], bias[2 * E:])
+    heads = lambda t, L: t.unflatten(-1, (H, 32)).permute(1, 2, 0, 3)           # [L,B,E] -> [B,H,L,32] view
+    o = attention(heads(q, Lq), heads(k, Lk), heads(v, Lk), mha.dropout if mha.training else 0.0)
+    return mha.out_proj(o.permute(2, 0, 1, 3).reshape(Lq, B, E))
+
+
+def mha_supported(mha, query, key, value):
+    return (query.is_cuda and query.dtype == torch.float32 and mha.embed_dim == mha.num_heads * 32 and not mha.batch_first
+            and mha._qkv_same_embed_dim and mha.in_proj_bias is not None and mha.bias_k is None and not mha.add_zero_attn
+            and query.dim() == 3 and key.shape == value.shape and query.size(1) * mha.num_heads <= 65535)

@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..flash_attn import mha_forward, mha_supported
 from ..pointwise import dropout_add_layernorm, group_norm
 from ..token_linear import token_linear
 
@@ -31,7 +32,10 @@ class DepthEncoderLayer(nn.Module):
 
     def forward(self, src, src_key_padding_mask, pos):
         qk = src if pos is None else src + pos
-        attn = self.self_attn(qk, qk, value=src, key_padding_mask=src_key_padding_mask, need_weights=False)[0]
+        if src_key_padding_mask is None and mha_supported(self.self_attn, qk, qk, src):
+            attn = mha_forward(self.self_attn, qk, qk, src)          # HIP fp32 attention core
+        else:
+            attn = self.self_attn(qk, qk, value=src, key_padding_mask=src_key_padding_mask, need_weights=False)[0]
         src = dropout_add_layernorm(src, attn, self.norm1, self.dropout1)
         ff = token_linear(self.dropout(F.relu(token_linear(src, self.linear1))), self.linear2)
         return dropout_add_layernorm(src, ff, self.norm2, self.dropout2)

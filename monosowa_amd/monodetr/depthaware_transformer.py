@@ -19,6 +19,7 @@ from torch.nn.init import constant_, normal_, xavier_uniform_
 from .misc import inverse_sigmoid
 from .. import MultiScaleDeformableAttention as _MSDA
 from ..ms_deform_attn import MSDeformAttn
+from ..flash_attn import mha_forward, mha_supported
 from ..pointwise import dropout_add_layernorm
 from ..token_linear import token_linear
 
@@ -160,8 +161,12 @@ class DepthAwareDecoderLayer(nn.Module):
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                 src_padding_mask, depth_pos_embed, mask_depth):
         # depth cross attention over the stride-16 depth-aware tokens
-        tgt2 = self.cross_attn_depth(tgt.transpose(0, 1), depth_pos_embed, depth_pos_embed,
-                                     key_padding_mask=mask_depth, need_weights=False)[0].transpose(0, 1)
+        tq = tgt.transpose(0, 1)
+        if mask_depth is None and mha_supported(self.cross_attn_depth, tq, depth_pos_embed, depth_pos_embed):
+            tgt2 = mha_forward(self.cross_attn_depth, tq, depth_pos_embed, depth_pos_embed).transpose(0, 1)
+        else:
+            tgt2 = self.cross_attn_depth(tq, depth_pos_embed, depth_pos_embed,
+                                         key_padding_mask=mask_depth, need_weights=False)[0].transpose(0, 1)
         tgt = dropout_add_layernorm(tgt, tgt2, self.norm_depth, self.dropout_depth)
         # self attention
         tgt = dropout_add_layernorm(tgt, self._self_attention(tgt, query_pos), self.norm2, self.dropout2)

@@ -80,3 +80,21 @@ def test_pointwise_library_exports_declared_symbols():
     # CPU tensors take the plain PyTorch formulation
     y, b, r = torch.randn(2, 8, 3, 5), torch.randn(8), torch.randn(2, 8, 3, 5)
     assert torch.allclose(pointwise.bias_act(y.clone(), b, r), torch.relu(y + b.view(1, -1, 1, 1) + r))
+
+
+def test_attention_library_exports_declared_symbols():
+    from monosowa_amd import flash_attn
+    text = open(os.path.join(ROOT, "include", "monosowa_attn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(mono_attn_[a-z0-9_]+)\s*\(", text)))
+    assert names == sorted(flash_attn.SYMBOLS)
+    lib = ctypes.CDLL(flash_attn._PATH)
+    for n in names:
+        assert hasattr(lib, n)
+    # the product path refuses CPU tensors instead of falling back
+    q = torch.randn(1, 2, 5, 32)
+    assert not flash_attn.supported(q, q, q)
+    with pytest.raises(RuntimeError):
+        flash_attn.attention(q, q, q)
+    mha = torch.nn.MultiheadAttention(64, 2)
+    assert not flash_attn.mha_supported(mha, torch.randn(5, 1, 64), torch.randn(5, 1, 64), torch.randn(5, 1, 64))

@@ -486,3 +486,80 @@ def test_colsum_matches_torch(rows, C):
     got = colsum(g)
     assert got.shape == (C,)
     assert (got.double() - ref).abs().max() <= 2e-6 * g.abs().double().sum(0).max()
+
+
+# ---- fp32 attention (libmonosowa_attn.so) ------------------------------------------------------------------
+def _heads(L, B, H):
+    return torch.randn(L, B, H * 32, device="cuda").view(L, B, H, 32).permute(1, 2, 0, 3)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk", [(2, 8, 100, 200), (1, 3, 33, 64), (2, 8, 550, 1920), (1, 8, 1920, 1920), (3, 2, 1, 5)])
+def test_attention_matches_fp64_softmax_attention(B, H, Lq, Lk):
+    """mono_attn_*: O, dQ, dK, dV against softmax(QK^T/sqrt(32))V evaluated in float64 (ragged Lq / Lk included)."""
+    import math
+    from monosowa_amd import flash_attn as FA
+    torch.manual_seed(Lq + Lk)
+    q, k, v = _heads(Lq, B, H), _heads(Lk, B, H), _heads(Lk, B, H)
+    go = _heads(Lq, B, H)
+    qg, kg, vg = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+    o = FA.attention(qg, kg, vg)
+    o.backward(go)
+    qd, kd, vd = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    ref = torch.softmax((qd @ kd.transpose(-1, -2)) / math.sqrt(32), -1) @ vd
+    ref.backward(go.double())
+    for name, a, b in (("o", o, ref), ("dq", qg.grad, qd.grad), ("dk", kg.grad, kd.grad), ("dv", vg.grad, vd.grad)):
+        assert (a.double() - b).abs().max() <= 1e-5 * max(b.abs().max().item(), 1e-3), name
+
+
+def test_attention_dropout_uses_one_mask_forward_and_backward():
+    """The dropped probabilities are recovered with one-hot V; the kernel gradients must equal float64 autograd through
+    exactly that mask, the kept fraction must match p, and a different seed must give a different mask."""
+    import math
+    from monosowa_amd import flash_attn as FA
+    torch.manual_seed(1)
+    B, H, Lq, Lk, p, seed = 2, 3, 70, 64, 0.3, 99
+    q, k, v, go = _heads(Lq, B, H), _heads(Lk, B, H), _heads(Lk, B, H), _heads(Lq, B, H)
+    scale = 1 / math.sqrt(32)
+    eye = torch.eye(64, device="cuda")
+    recover = lambda sd: torch.cat([FA.forward(q, k, eye[:, i * 32:(i + 1) * 32].expand(B, H, 64, 32).contiguous(), scale, p, sd)[0]
+                                    for i in range(2)], -1)
+    pd = recover(seed)
+    mask = (pd != 0).double()
+    assert abs(mask.mean().item() - (1 - p)) < 0.02
+    assert not torch.equal(recover(seed + 1) != 0, pd != 0)
+    qd, kd, vd = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    keep_scale = 65536.0 / (65536.0 - round(p * 65536))
+    pr = torch.softmax((qd @ kd.transpose(-1, -2)) * scale, -1) * mask * keep_scale
+    assert (pd.double() - pr).abs().max() < 1e-6
+    (pr @ vd).backward(go.double())
+    qg, kg, vg = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+    FA.attention(qg, kg, vg, dropout_p=p, seed=seed).backward(go)
+    for name, a, b in (("dq", qg.grad, qd.grad), ("dk", kg.grad, kd.grad), ("dv", vg.grad, vd.grad)):
+        assert (a.double() - b).abs().max() <= 1e-5 * b.abs().max(), name
+
+
+@pytest.mark.parametrize("same_qk", [True, False])
+def test_mha_forward_equals_nn_multiheadattention(same_qk):
+    """mha_forward (packed projections + HIP core) against nn.MultiheadAttention in eval mode: output and all
+    parameter / input gradients, for the depth-encoder (q is k) and decoder (k is v) call patterns."""
+    from monosowa_amd.flash_attn import mha_forward, mha_supported
+    torch.manual_seed(3)
+    mha = torch.nn.MultiheadAttention(256, 8, dropout=0.1).cuda().eval()
+    x = torch.randn(96, 2, 256, device="cuda", requires_grad=True)
+    y = torch.randn(40, 2, 256, device="cuda", requires_grad=True)
+    args = (x, x, (x.detach() * 0.5).clone().requires_grad_(True)) if same_qk else (y, x, x)
+    assert mha_supported(mha, *args)
+    go = torch.randn(args[0].shape, device="cuda")
+
+    def run(fn):
+        for t in set(args):
+            t.grad = None
+        mha.zero_grad()
+        out = fn()
+        out.backward(go)
+        return [out.detach().clone()] + [t.grad.clone() for t in args if t.grad is not None] + [p_.grad.clone() for p_ in mha.parameters()]
+    ours = run(lambda: mha_forward(mha, *args))
+    ref = run(lambda: mha(*args, need_weights=False)[0])
+    assert len(ours) == len(ref)
+    for a, b in zip(ours, ref):
+        assert (a - b).abs().max() <= 2e-5 * max(b.abs().max().item(), 1e-3)
