@@ -34,6 +34,13 @@ def _paired_giou(a, b):
     return inter / union - (area_c - union) / area_c
 
 
+def _dev(values, dtype, device):
+    """Small host values -> device WITHOUT blocking the host: on ROCm ``torch.tensor(list, device=cuda)`` and
+    ``torch.as_tensor(list, device=cuda)`` wait for every queued kernel (214 ms behind a 214 ms queue,
+    tools/h2d_probe.py), a staged ``.to(device, non_blocking=True)`` of a CPU tensor returns in 70 us."""
+    return torch.as_tensor(np.asarray(values)).to(dtype).to(device, non_blocking=True)
+
+
 class SetCriterion(nn.Module):
     def __init__(self, num_classes, matcher, weight_dict, focal_alpha, losses, group_num=11, cfg=None,
                  depth_map_size=(80, 24), fast=True):
@@ -176,7 +183,7 @@ class SetCriterion(nn.Module):
     def _num_boxes(self, targets, group_num, device):
         n = float(sum(len(t["labels"]) for t in targets) * group_num)
         if is_dist_avail_and_initialized():       # stays on the device: dividing by a tensor needs no sync
-            t = torch.as_tensor([n], dtype=torch.float, device=device)
+            t = _dev([n], torch.float, device)
             torch.distributed.all_reduce(t)
             return torch.clamp(t / get_world_size(), min=1)[0]
         return max(n / get_world_size(), 1.0)
@@ -201,8 +208,29 @@ class SetCriterion(nn.Module):
                 for k in ("labels", "boxes_3d", "boxes", "depth", "size_3d", "heading_bin", "heading_res")}
         num_boxes = self._num_boxes(targets, group_num, dev)
 
-        matches = self.matcher.match_layers(logits, boxes, flat, sizes, group_num)
+        pending = self.matcher.match_layers_begin(logits, boxes, flat, sizes, group_num)      # cost pass + async D2H
+
+        # depth map (final layer only): padded per-image boxes, rasterised on the device.  Independent of the matching,
+        # so it is enqueued between the two halves of the matcher: the GPU works on it while the host waits for the
+        # cost blocks and solves the assignments.
         offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        maxn = max(sizes) if sizes else 0
+        w, h = self.depth_map_size
+        if maxn:
+            slot = np.minimum(offs[:, None] + np.arange(maxn)[None, :], max(T - 1, 0))
+            valid = np.arange(maxn)[None, :] < np.asarray(sizes)[:, None]
+            slot_t = torch.as_tensor(slot, dtype=torch.int64).to(dev, non_blocking=True)
+            valid_t = torch.as_tensor(valid).to(dev, non_blocking=True)
+            scale = _dev([w, h, w, h], logits.dtype, dev)
+            boxes2d = box_ops.box_cxcywh_to_xyxy(flat["boxes"] * scale)[slot_t]
+            depth2d = flat["depth"].squeeze(1)[slot_t]
+        else:
+            valid_t = torch.zeros((B, 1), dtype=torch.bool, device=dev)
+            boxes2d = torch.zeros((B, 1, 4), device=dev, dtype=logits.dtype)
+            depth2d = torch.zeros((B, 1), device=dev, dtype=logits.dtype)
+        loss_depth_map = self.ddn_loss.forward_padded(outputs["pred_depth_map_logits"], boxes2d, depth2d, valid_t)
+
+        matches = self.matcher.match_layers_end(pending)
         b_idx = np.stack([np.concatenate([np.full(len(s), b, np.int64) for b, (s, _) in enumerate(layer)]) for layer in matches])
         q_idx = np.stack([np.concatenate([s for s, _ in layer]) for layer in matches])
         t_idx = np.stack([np.concatenate([t + offs[b] for b, (_, t) in enumerate(layer)]) for layer in matches])
@@ -231,7 +259,7 @@ class SetCriterion(nn.Module):
         else:
             correct = torch.zeros(NL, device=dev)
         per_layer["class_error"] = 100 - correct
-        tgt_lengths = torch.as_tensor(sizes, dtype=torch.float, device=dev)
+        tgt_lengths = _dev(sizes, torch.float, dev)
         card_pred = (logits.argmax(-1) != C - 1).sum(2).float()
         per_layer["cardinality_error"] = (card_pred - tgt_lengths).abs().mean(1)
 
@@ -268,22 +296,7 @@ class SetCriterion(nn.Module):
             losses["loss_tfl" + suffix] = zero()
             losses["loss_mask" + suffix] = zero()
 
-        # depth map (final layer only): padded per-image boxes, rasterised on the device
-        maxn = max(sizes) if sizes else 0
-        w, h = self.depth_map_size
-        if maxn:
-            slot = np.minimum(offs[:, None] + np.arange(maxn)[None, :], max(T - 1, 0))
-            valid = np.arange(maxn)[None, :] < np.asarray(sizes)[:, None]
-            slot_t = torch.as_tensor(slot, dtype=torch.int64).to(dev, non_blocking=True)
-            valid_t = torch.as_tensor(valid).to(dev, non_blocking=True)
-            scale = torch.tensor([w, h, w, h], device=dev, dtype=logits.dtype)
-            boxes2d = box_ops.box_cxcywh_to_xyxy(flat["boxes"] * scale)[slot_t]
-            depth2d = flat["depth"].squeeze(1)[slot_t]
-        else:
-            valid_t = torch.zeros((B, 1), dtype=torch.bool, device=dev)
-            boxes2d = torch.zeros((B, 1, 4), device=dev, dtype=logits.dtype)
-            depth2d = torch.zeros((B, 1), device=dev, dtype=logits.dtype)
-        losses["loss_depth_map"] = self.ddn_loss.forward_padded(outputs["pred_depth_map_logits"], boxes2d, depth2d, valid_t)
+        losses["loss_depth_map"] = loss_depth_map
         return losses
 
     # ------------------------------------------------------------------ reference formulation

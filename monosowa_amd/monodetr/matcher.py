@@ -77,12 +77,18 @@ class HungarianMatcher(nn.Module):
         One cost pass (same ops as ``cost_matrix``, so the same floats), one device->host copy of the
         per-image diagonal blocks, one native call for every (layer, image, group) assignment.
         -> list over layers of list over images of (query_idx, target_idx) int64 numpy arrays."""
-        from .. import lsap
+        handle = self.match_layers_begin(pred_logits, pred_boxes, flat_targets, sizes, group_num)
+        return self.match_layers_end(handle)
+
+    @torch.no_grad()
+    def match_layers_begin(self, pred_logits, pred_boxes, flat_targets, sizes, group_num):
+        """First half of ``match_layers``: enqueues the cost pass and the device->host copy of the per-image blocks
+        (pinned buffer, asynchronous) and returns a handle.  GPU work enqueued between this call and
+        ``match_layers_end`` overlaps the host's wait and the assignment solve."""
         NL, B, Q, _ = pred_logits.shape
         T = int(sum(sizes))
         if T == 0:
-            e = np.empty(0, np.int64)
-            return [[(e, e) for _ in range(B)] for _ in range(NL)]
+            return None, NL, B, Q, sizes, group_num
         C = self.cost_matrix({"pred_logits": pred_logits.flatten(0, 1), "pred_boxes": pred_boxes.flatten(0, 1)},
                              [flat_targets]).view(NL, B, Q, T)
         maxn = max(sizes)
@@ -90,7 +96,27 @@ class HungarianMatcher(nn.Module):
         cols = np.minimum(offs[:, None] + np.arange(maxn)[None, :], T - 1)            # [B, maxn], clamped padding
         cols = torch.as_tensor(cols, dtype=torch.int64).to(C.device, non_blocking=True)
         blocks = torch.gather(C, 3, cols.view(1, B, 1, maxn).expand(NL, B, Q, maxn))
-        host = blocks.cpu().numpy()
+        if blocks.is_cuda:
+            key = (tuple(blocks.shape), blocks.dtype)
+            if getattr(self, "_pinned_key", None) != key:
+                self._pinned, self._pinned_key = torch.empty(blocks.shape, dtype=blocks.dtype).pin_memory(), key
+            self._pinned.copy_(blocks, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            return (self._pinned, done), NL, B, Q, sizes, group_num
+        return (blocks, None), NL, B, Q, sizes, group_num
+
+    @torch.no_grad()
+    def match_layers_end(self, handle):
+        from .. import lsap
+        payload, NL, B, Q, sizes, group_num = handle
+        if payload is None:
+            e = np.empty(0, np.int64)
+            return [[(e, e) for _ in range(B)] for _ in range(NL)]
+        blocks, done = payload
+        if done is not None:
+            done.synchronize()                                                        # the step's one host sync
+        host = blocks.numpy()
         if lsap.available():
             return lsap.match_groups(host, np.asarray(sizes, np.int64), group_num, padded=True)
         g_q = Q // group_num

@@ -43,8 +43,20 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
+    if "--cached-match" in sys.argv:          # upper bound of what hiding the matcher's host round trip could give
+        from monosowa_amd.monodetr.matcher import HungarianMatcher
+        real = HungarianMatcher.match_layers
+        cache = {}
+
+        def cached(self, *a, **k):
+            if "m" not in cache:
+                cache["m"] = real(self, *a, **k)
+            return cache["m"]
+        HungarianMatcher.match_layers = cached
+        step()
+        torch.cuda.synchronize()
     marks.clear()
-    n = 5
+    n = 10
     t0 = time.perf_counter()
     for _ in range(n):
         step()

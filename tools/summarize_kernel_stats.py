@@ -1,4 +1,6 @@
-"""Category summary of a rocprofv3 *_kernel_stats.csv of a bench.py run:  python tools/summarize_kernel_stats.py <csv> <steps>"""
+"""Category summary of a rocprofv3 run of bench.py:
+    python tools/summarize_kernel_stats.py <..._kernel_stats.csv> <steps in the run>
+    python tools/summarize_kernel_stats.py <..._kernel_trace.csv> <last K steps to summarise>"""
 import csv
 import sys
 
@@ -12,6 +14,10 @@ def cat(n):
         return "MIOpen layout transpose"
     if any(k in n for k in ("igemm", "Conv", "conv", "miopen", "gtc", "Sp3Asm", "xdlops")):
         return "conv (MIOpen/CK)"
+    if "attn::" in n:
+        return "attention (this repo)"
+    if "mono::" in n:
+        return "pointwise / norms (this repo)"
     if "attn_fwd" in n or "bwd_kernel" in n:
         return "attention (aotriton)"
     if "layer_norm" in n or "GammaBeta" in n or "GradInput" in n or "roupNorm" in n or "RowwiseMoments" in n or "group_norm" in n:
@@ -33,9 +39,35 @@ def cat(n):
     return "other"
 
 
+def rows_from_trace(path, steps):
+    """Per-kernel totals over the LAST `steps` train steps of a rocprofv3 *_kernel_trace.csv (steps are delimited by
+    the backbone's single max-pool forward), i.e. without warm-up, MIOpen's find phase and JIT effects."""
+    trace = list(csv.DictReader(open(path)))
+    trace.sort(key=lambda r: int(r["Start_Timestamp"]))
+    marks = [i for i, r in enumerate(trace) if "max_pool_forward" in r["Kernel_Name"]]
+    if len(marks) < steps:
+        raise SystemExit("only %d steps in the trace" % len(marks))
+    first = marks[-int(steps)]
+    acc = {}
+    for r in trace[first:]:
+        d = acc.setdefault(r["Kernel_Name"], [0, 0])
+        d[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        d[1] += 1
+    tot = sum(v[0] for v in acc.values())
+    rows = [{"Name": k, "TotalDurationNs": v[0], "Calls": v[1], "AverageNs": v[0] / v[1], "Percentage": 100.0 * v[0] / tot}
+            for k, v in acc.items()]
+    rows.sort(key=lambda r: -r["TotalDurationNs"])
+    span = int(trace[-1]["End_Timestamp"]) - int(trace[first]["Start_Timestamp"])
+    print("window: last %d steps, %.1f ms/step wall on the GPU timeline" % (steps, span / 1e6 / steps))
+    return rows
+
+
 def main():
-    rows = list(csv.DictReader(open(sys.argv[1])))
     steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+    if sys.argv[1].endswith("kernel_trace.csv"):
+        rows = rows_from_trace(sys.argv[1], steps)
+    else:
+        rows = list(csv.DictReader(open(sys.argv[1])))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     print("kernel time %.1f ms/step over %.0f launches/step" % (tot / 1e6 / steps, sum(int(r["Calls"]) for r in rows) / steps))
     cats = {}
