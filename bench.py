@@ -275,6 +275,9 @@ def main():
                        "queries": 550 if train else 50},
             "roofline": roofline,
         }
+        if dist.is_initialized():          # the CPU leg below must not meet an RCCL-only process group
+            dist.barrier()
+            dist.destroy_process_group()
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
             log("cpu_baseline leg (bounded sample)")
