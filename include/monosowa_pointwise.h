@@ -24,6 +24,12 @@ int mono_dropout_add_layernorm_fwd_f32(const float *x, const float *z, const flo
                                        float *s, float *mean, float *rstd, long long rows, int C, float p,
                                        unsigned long long seed, float eps, void *stream);
 
+/* One step of the reference's AdamW variant (lib/helpers/optimizer_helper.py:69-129: eps added to sqrt(v) before the
+ * bias correction, decay scaled by the corrected step size) over all parameters in one launch.
+ * table (device): p[n_chunks], g[n_chunks], m[n_chunks], v[n_chunks] as 64-bit device addresses, then n[n_chunks]
+ * (int32 elements per chunk, any size), then wd[n_chunks] (float weight decay). */
+int mono_adamw_step_f32(const void *table, int n_chunks, double beta1, double beta2, double eps, double step_size, void *stream);
+
 /* Number of workgroups, = rows of scratch the two row reductions below need, for `rows` input rows. */
 int mono_reduce_blocks(long long rows);
 

@@ -200,6 +200,46 @@ __global__ __launch_bounds__(1024) void partial_sum_kernel(const float *__restri
   }
 }
 
+// ---- the reference's AdamW variant (lib/helpers/optimizer_helper.py:69-129) over every parameter in ONE launch ------
+//   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g g;  p -= step_size * (wd p + m / (sqrt(v) + eps))
+// One workgroup per chunk (<= 32768 elements of one tensor); the chunk table (four pointer arrays, lengths, decay) is
+// rebuilt by the host each step (gradient buffers move).  float4 path when all four pointers are 16-byte aligned
+// (DDP's bucket-view gradients need not be).
+__device__ __forceinline__ void adamw_one(float &p, float g, float &m, float &v, float wd, float b1, float omb1, float b2,
+                                          float omb2, float eps, float neg_step) {
+  m = __fmaf_rn(omb1, g, __fmul_rn(m, b1));
+  v = __fmaf_rn(__fmul_rn(omb2, g), g, __fmul_rn(v, b2));
+  const float denom = __fadd_rn(__fsqrt_rn(v), eps);
+  const float upd = __fadd_rn(__fmul_rn(p, wd), __fdiv_rn(m, denom));
+  p = __fmaf_rn(neg_step, upd, p);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(const unsigned long long *__restrict__ pp, const unsigned long long *__restrict__ gp,
+                                                    const unsigned long long *__restrict__ mp, const unsigned long long *__restrict__ vp,
+                                                    const int *__restrict__ ns, const float *__restrict__ wds, float b1, float omb1,
+                                                    float b2, float omb2, float eps, float step_size) {
+  const int c = blockIdx.x;
+  float *p = reinterpret_cast<float *>(pp[c]), *m = reinterpret_cast<float *>(mp[c]), *v = reinterpret_cast<float *>(vp[c]);
+  const float *g = reinterpret_cast<const float *>(gp[c]);
+  const int n = ns[c];
+  const float wd = wds[c], neg = -step_size;
+  if (((pp[c] | gp[c] | mp[c] | vp[c]) & 15ull) == 0) {
+    const int n4 = n >> 2;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      float4 P = reinterpret_cast<float4 *>(p)[i], M = reinterpret_cast<float4 *>(m)[i], V = reinterpret_cast<float4 *>(v)[i];
+      const float4 G = reinterpret_cast<const float4 *>(g)[i];
+      adamw_one(P.x, G.x, M.x, V.x, wd, b1, omb1, b2, omb2, eps, neg);
+      adamw_one(P.y, G.y, M.y, V.y, wd, b1, omb1, b2, omb2, eps, neg);
+      adamw_one(P.z, G.z, M.z, V.z, wd, b1, omb1, b2, omb2, eps, neg);
+      adamw_one(P.w, G.w, M.w, V.w, wd, b1, omb1, b2, omb2, eps, neg);
+      reinterpret_cast<float4 *>(p)[i] = P; reinterpret_cast<float4 *>(m)[i] = M; reinterpret_cast<float4 *>(v)[i] = V;
+    }
+    for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) adamw_one(p[i], g[i], m[i], v[i], wd, b1, omb1, b2, omb2, eps, neg);
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) adamw_one(p[i], g[i], m[i], v[i], wd, b1, omb1, b2, omb2, eps, neg);
+  }
+}
+
 inline int grid_for_vec(long long n_vec) {
   long long g = (n_vec + 255) / 256;
   if (g > 256LL * 32) g = 256LL * 32;
@@ -263,6 +303,22 @@ int mono_dropout_add_layernorm_bwd_f32(const float *gy, const float *s, const fl
   hipStream_t st = (hipStream_t)stream_;
   mono::dropout_add_ln_bwd_kernel<<<g, 256, 0, st>>>(gy, s, mean, rstd, gamma, gx, gz, partials, rows, threshold, scale, seed);
   mono::partial_sum_kernel<<<2, 1024, 0, st>>>(partials, ggamma_gbeta, g, 512);
+  return (int)hipGetLastError();
+}
+
+// One AdamW step (the reference's variant, see adamw_kernel) for n_chunks chunks.  table: device buffer holding, back to
+// back, p[n_chunks], g[n_chunks], m[n_chunks], v[n_chunks] (64-bit device addresses), n[n_chunks] (int32, elements
+// per chunk), wd[n_chunks] (float).  step_size = lr * sqrt(1 - b2^t) / (1 - b1^t).  Scalars arrive as doubles so that
+// 1 - beta is rounded to float once, like the Python scalars of the reference.
+int mono_adamw_step_f32(const void *table, int n_chunks, double beta1, double beta2, double eps, double step_size, void *stream_) {
+  if (!table) return -1;
+  if (n_chunks <= 0) return -2;
+  const unsigned long long *pp = reinterpret_cast<const unsigned long long *>(table);
+  const int *ns = reinterpret_cast<const int *>(pp + 4 * (size_t)n_chunks);
+  const float *wds = reinterpret_cast<const float *>(ns + n_chunks);
+  mono::adamw_kernel<<<n_chunks, 256, 0, (hipStream_t)stream_>>>(pp, pp + n_chunks, pp + 2 * (size_t)n_chunks, pp + 3 * (size_t)n_chunks,
+                                                               ns, wds, (float)beta1, (float)(1.0 - beta1), (float)beta2,
+                                                               (float)(1.0 - beta2), (float)eps, (float)step_size);
   return (int)hipGetLastError();
 }
 

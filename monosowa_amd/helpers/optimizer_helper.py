@@ -50,6 +50,23 @@ class AdamW(Optimizer):
         for group in self.param_groups:
             group.setdefault("amsgrad", False)
 
+    def _fused_step(self, group, step, params, grads, exp_avgs, exp_avg_sqs):
+        """All parameters of the group in one HIP launch (monosowa_amd/csrc/pointwise.hip adamw_kernel) when they are
+        dense contiguous float32 GPU tensors; same operations in the same order as the foreach formulation below."""
+        if group["amsgrad"] or not params or not all(
+                t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for ts in (params, grads, exp_avgs, exp_avg_sqs) for t in ts):
+            return False
+        from ..pointwise import FusedAdamWPlan
+        plans = self.__dict__.setdefault("_fused_plans", {})
+        key = id(group["params"])
+        plan = plans.get(key)
+        if plan is None or len(plan.keys[0]) != len(params) or not plan.matches(params, exp_avgs, exp_avg_sqs):
+            plan = plans[key] = FusedAdamWPlan(params, exp_avgs, exp_avg_sqs, group["weight_decay"])
+        beta1, beta2 = group["betas"]
+        step_size = group["lr"] * math.sqrt(1 - beta2 ** step) / (1 - beta1 ** step)
+        plan.step(grads, beta1, beta2, group["eps"], step_size)
+        return True
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -80,6 +97,8 @@ class AdamW(Optimizer):
                 if group["amsgrad"]:
                     b[4].append(state["max_exp_avg_sq"])
             for step, (params, grads, exp_avgs, exp_avg_sqs, max_sqs) in buckets.items():
+                if self._fused_step(group, step, params, grads, exp_avgs, exp_avg_sqs):
+                    continue
                 torch._foreach_mul_(exp_avgs, beta1)
                 torch._foreach_add_(exp_avgs, grads, alpha=1 - beta1)
                 torch._foreach_mul_(exp_avg_sqs, beta2)

@@ -7,7 +7,7 @@ import torch
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
-           "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_colsum_f32", "mono_reduce_blocks")
+           "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_colsum_f32", "mono_reduce_blocks", "mono_adamw_step_f32")
 _lib = None
 
 
@@ -33,6 +33,8 @@ def load():
         lib.mono_groupnorm_nhwc_fwd_f32.argtypes = [P] * 6 + [I, I, I, I, F, I, P]
         lib.mono_groupnorm_nhwc_bwd_f32.restype = I
         lib.mono_groupnorm_nhwc_bwd_f32.argtypes = [P] * 7 + [I, I, I, I, I, P]
+        lib.mono_adamw_step_f32.restype = I
+        lib.mono_adamw_step_f32.argtypes = [P, I] + [ctypes.c_double] * 4 + [P]
         lib.mono_colsum_f32.restype = I
         lib.mono_colsum_f32.argtypes = [P, P, P, LL, I, P]
         _lib = lib
@@ -205,3 +207,57 @@ def colsum(g2):
             raise RuntimeError("mono_colsum_f32 failed with code %d" % code)
         return out
     return g2.sum(0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+ADAM_CHUNK = 32768
+
+
+class FusedAdamWPlan:
+    """Chunk table of one parameter group for ``mono_adamw_step_f32``: the split into chunks is fixed, the four
+    address columns are refreshed every step (gradients are re-allocated) and shipped with one non-blocking copy."""
+
+    def __init__(self, params, exp_avgs, exp_avg_sqs, weight_decay):
+        import numpy as np
+        sizes = np.array([p.numel() for p in params], dtype=np.int64)
+        per = (sizes + ADAM_CHUNK - 1) // ADAM_CHUNK
+        self.tensor = np.repeat(np.arange(len(params)), per)
+        first = np.cumsum(per) - per
+        self.offset = (np.arange(per.sum()) - np.repeat(first, per)) * ADAM_CHUNK
+        self.n = np.minimum(sizes[self.tensor] - self.offset, ADAM_CHUNK).astype(np.int32)
+        self.n_chunks = int(per.sum())
+        self.device = params[0].device
+        ptr = lambda ts: np.array([t.data_ptr() for t in ts], dtype=np.uint64)
+        self.fixed = [ptr(params)[self.tensor] + (self.offset * 4).astype(np.uint64),
+                      ptr(exp_avgs)[self.tensor] + (self.offset * 4).astype(np.uint64),
+                      ptr(exp_avg_sqs)[self.tensor] + (self.offset * 4).astype(np.uint64)]
+        self.keys = (ptr(params), ptr(exp_avgs), ptr(exp_avg_sqs))
+        nbytes = self.n_chunks * (4 * 8 + 4 + 4)
+        self.host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self.dev = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.view = self.host.numpy()
+        u64 = self.view[:self.n_chunks * 32].view(np.uint64).reshape(4, self.n_chunks)
+        u64[0], u64[2], u64[3] = self.fixed
+        self.g_col = u64[1]
+        self.view[self.n_chunks * 32:self.n_chunks * 36].view(np.int32)[:] = self.n
+        self.view[self.n_chunks * 36:].view(np.float32)[:] = weight_decay
+        self.np = np
+
+    def matches(self, params, exp_avgs, exp_avg_sqs):
+        ptr = lambda ts: self.np.array([t.data_ptr() for t in ts], dtype=self.np.uint64)
+        return all(self.np.array_equal(a, ptr(b)) for a, b in zip(self.keys, (params, exp_avgs, exp_avg_sqs)))
+
+    def step(self, grads, beta1, beta2, eps, step_size):
+        np = self.np
+        g = np.array([t.data_ptr() for t in grads], dtype=np.uint64)
+        if getattr(self, "copied", None) is not None:
+            self.copied.synchronize()                     # the previous step's table copy has left the pinned buffer
+        self.g_col[:] = g[self.tensor] + (self.offset * 4).astype(np.uint64)
+        self.dev.copy_(self.host, non_blocking=True)
+        self.copied = torch.cuda.Event()
+        self.copied.record()
+        with torch.cuda.device(self.device):
+            code = load().mono_adamw_step_f32(self.dev.data_ptr(), self.n_chunks, beta1, beta2, eps, step_size,
+                                              torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_adamw_step_f32 failed with code %d" % code)
