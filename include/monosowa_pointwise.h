@@ -17,6 +17,10 @@ int mono_bias_act_f32(float *y, const float *bias, const float *residual, long l
 /* grad_in[i] = y[i] > 0 ? grad_out[i] : 0   (n % 4 == 0; grad_in may alias grad_out). */
 int mono_relu_grad_f32(const float *grad_out, const float *y, float *grad_in, long long n, void *stream);
 
+/* grad_in = (grad_a + grad_b) * (y > 0): ReLU backward of a tensor with two consumers (ResNet block output -> next
+ * convolution and identity branch, backbone.py:64-82 of the reference's torchvision ResNet) in one pass. */
+int mono_relu_grad2_f32(const float *grad_a, const float *grad_b, const float *y, float *grad_in, long long n, void *stream);
+
 /* y = LayerNorm_256(x + dropout_p(z)) over rows of C = 256 channels (reference: the post-norm residual blocks of
  * depthaware_transformer.py:339-354,500-515).  The keep mask is a hash of (seed, element index): the backward
  * recomputes it from the same seed.  Saves s = x + dropout(z), mean, rstd [rows] for the backward. */

@@ -40,6 +40,19 @@ __global__ __launch_bounds__(256) void relu_grad_kernel(const float *__restrict_
   }
 }
 
+// grad_in = (grad_a + grad_b) * (y > 0): the two consumers of a block output (next conv and the identity branch) and
+// the ReLU backward in one pass (autograd would run an accumulation add and then the ReLU backward)
+__global__ __launch_bounds__(256) void relu_grad2_kernel(const float *__restrict__ ga, const float *__restrict__ gb,
+                                                         const float *__restrict__ y, float *__restrict__ grad_in, long long n_vec) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    const float4 a = reinterpret_cast<const float4 *>(ga)[i], b = reinterpret_cast<const float4 *>(gb)[i];
+    const float4 v = reinterpret_cast<const float4 *>(y)[i];
+    reinterpret_cast<float4 *>(grad_in)[i] = make_float4(v.x > 0.f ? a.x + b.x : 0.f, v.y > 0.f ? a.y + b.y : 0.f,
+                                                         v.z > 0.f ? a.z + b.z : 0.f, v.w > 0.f ? a.w + b.w : 0.f);
+  }
+}
+
 // ---- LayerNorm(x + dropout(z)) over rows of 256 channels: one wave per row, float4 per lane -----------------
 // (reference: `src = self.norm1(src + self.dropout1(src2))`, depthaware_transformer.py:339-354,500-515).
 // The keep mask is a counter-based hash of (seed, element index), recomputed in the backward: no mask tensor.
@@ -263,6 +276,13 @@ int mono_bias_act_f32(float *y, const float *bias, const float *residual, long l
   else if (relu) mono::bias_act_kernel<true, false><<<g, 256, 0, stream>>>(y, bias, nullptr, n_vec, C / 4);
   else if (residual) mono::bias_act_kernel<false, true><<<g, 256, 0, stream>>>(y, bias, residual, n_vec, C / 4);
   else mono::bias_act_kernel<false, false><<<g, 256, 0, stream>>>(y, bias, nullptr, n_vec, C / 4);
+  return (int)hipGetLastError();
+}
+
+int mono_relu_grad2_f32(const float *grad_a, const float *grad_b, const float *y, float *grad_in, long long n, void *stream_) {
+  if (!grad_a || !grad_b || !y || !grad_in) return -1;
+  if (n <= 0 || (n & 3) || ((uintptr_t)grad_a & 15) || ((uintptr_t)grad_b & 15) || ((uintptr_t)y & 15) || ((uintptr_t)grad_in & 15)) return -2;
+  mono::relu_grad2_kernel<<<mono::grid_for_vec(n / 4), 256, 0, (hipStream_t)stream_>>>(grad_a, grad_b, y, grad_in, n / 4);
   return (int)hipGetLastError();
 }
 

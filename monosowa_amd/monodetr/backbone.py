@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..pointwise import bias_act
+from ..pointwise import bias_act, bias_act_fork
 from .misc import NestedTensor
 from .position_encoding import build_position_encoding
 
@@ -45,6 +45,17 @@ class FrozenBatchNorm2d(nn.Module):
     def forward(self, x):
         scale, shift = self.scale_shift()
         return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+
+
+def conv_bn_fork(x, conv, bn, residual):
+    """``conv_bn(x, conv, bn, residual)`` returned as a pair for its two consumers (next block's first convolution and
+    identity branch): their gradients are added inside the fused ReLU backward (``pointwise.bias_act_fork``)."""
+    if isinstance(bn, FrozenBatchNorm2d):
+        scale, shift = bn.scale_shift()
+        y = F.conv2d(x, conv.weight * scale.view(-1, 1, 1, 1), None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        return bias_act_fork(y, shift, residual)
+    out = conv_bn(x, conv, bn, residual)
+    return out, out
 
 
 def conv_bn(x, conv, bn, residual=None, relu=True):
@@ -76,10 +87,12 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        out = conv_bn(x, self.conv1, self.bn1)
+        """x: a tensor, or the (a, b) pair a previous block returned (same values; one per consumer).  Returns a pair."""
+        xa, xb = x if isinstance(x, tuple) else (x, x)
+        out = conv_bn(xa, self.conv1, self.bn1)
         out = conv_bn(out, self.conv2, self.bn2)
-        identity = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], relu=False)
-        return conv_bn(out, self.conv3, self.bn3, residual=identity)
+        identity = xb if self.downsample is None else conv_bn(xb, self.downsample[0], self.downsample[1], relu=False)
+        return conv_bn_fork(out, self.conv3, self.bn3, identity)
 
 
 _DEPTHS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}
@@ -121,10 +134,13 @@ class ResNetBody(nn.Module):
     def forward(self, x):
         x = conv_bn(x, self.conv1, self.bn1)
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        # blocks hand (a, b) pairs to each other (one tensor object per consumer, see Bottleneck.forward); the stage
+        # outputs that leave the body are the first members
         x = self.layer1(x)
         c3 = self.layer2(x)
         c4 = self.layer3(c3)
         c5 = self.layer4(c4)
+        c3, c4, c5 = c3[0], c4[0], c5[0]
         return {"0": c3, "1": c4, "2": c5} if self.return_interm_layers else {"0": c5}
 
 

@@ -6,7 +6,7 @@ import os
 import torch
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
-SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
+SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_colsum_f32", "mono_reduce_blocks", "mono_adamw_step_f32")
 _lib = None
 
@@ -22,6 +22,8 @@ def load():
         lib.mono_bias_act_f32.argtypes = [P, P, P, LL, I, I, P]
         lib.mono_relu_grad_f32.restype = I
         lib.mono_relu_grad_f32.argtypes = [P, P, P, LL, P]
+        lib.mono_relu_grad2_f32.restype = I
+        lib.mono_relu_grad2_f32.argtypes = [P, P, P, P, LL, P]
         U, F = ctypes.c_ulonglong, ctypes.c_float
         lib.mono_dropout_add_layernorm_fwd_f32.restype = I
         lib.mono_dropout_add_layernorm_fwd_f32.argtypes = [P] * 8 + [LL, I, F, U, F, P]
@@ -78,6 +80,52 @@ class _BiasAct(torch.autograd.Function):
             g = grad
         gb = g.sum((0, 2, 3)) if ctx.bias_grad else None
         return g, gb, (g if ctx.has_res else None), None
+
+
+class _BiasActFork(torch.autograd.Function):
+    """relu(y + bias + residual) in place, returned TWICE (two tensor objects on one storage) for the two consumers of
+    a ResNet block output; the backward adds their gradients and applies the ReLU mask in one pass."""
+
+    @staticmethod
+    def forward(ctx, y, bias, residual):
+        rows = y.numel() // y.size(1)
+        with torch.cuda.device(y.device):
+            code = load().mono_bias_act_f32(y.data_ptr(), bias.data_ptr(), residual.data_ptr(), rows, y.size(1), 1,
+                                            torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_bias_act_f32 failed with code %d" % code)
+        ctx.mark_dirty(y)
+        ctx.save_for_backward(y)
+        ctx.bias_grad = bias.requires_grad
+        return y, y.detach()
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        (y,) = ctx.saved_tensors
+        cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+        lib = load()
+        g = torch.empty_like(y, memory_format=torch.channels_last)
+        with torch.cuda.device(y.device):
+            st = torch.cuda.current_stream().cuda_stream
+            if ga is not None and gb is not None:
+                ga, gb = cl(ga), cl(gb)
+                code = lib.mono_relu_grad2_f32(ga.data_ptr(), gb.data_ptr(), y.data_ptr(), g.data_ptr(), y.numel(), st)
+            else:
+                one = cl(ga if ga is not None else gb)
+                code = lib.mono_relu_grad_f32(one.data_ptr(), y.data_ptr(), g.data_ptr(), y.numel(), st)
+        if code:
+            raise RuntimeError("mono_relu_grad(2)_f32 failed with code %d" % code)
+        return g, (g.sum((0, 2, 3)) if ctx.bias_grad else None), g
+
+
+def bias_act_fork(y, bias, residual):
+    """``relu(y + bias + residual)`` twice -- ``(a, b)`` with ``a is b`` semantically, meant for exactly two
+    consumers (see ``_BiasActFork``); plain PyTorch (the same tensor twice) off the HIP path."""
+    if _nhwc_ok(y) and bias.is_cuda and bias.dtype == torch.float32 and bias.data_ptr() % 16 == 0 \
+            and _nhwc_ok(residual) and residual.shape == y.shape and torch.is_grad_enabled() and y.requires_grad:
+        return _BiasActFork.apply(y, bias.contiguous(), residual)
+    out = bias_act(y, bias, residual, True)
+    return out, out
 
 
 def bias_act(y, bias, residual=None, relu=True):

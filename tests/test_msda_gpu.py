@@ -592,3 +592,45 @@ def test_fused_adamw_matches_the_foreach_formulation():
             assert (a - b).abs().max() <= 1e-6 * b.abs().max()
             assert (fused.state[a]["exp_avg_sq"] - plain.state[b]["exp_avg_sq"]).abs().max() <= 1e-6 * plain.state[b]["exp_avg_sq"].abs().max()
     assert getattr(fused, "_fused_plans", None), "the fused path did not run"
+
+
+def test_resnet_stage_with_forked_relu_backward_matches_plain_autograd():
+    """Two bottleneck blocks through the product path (folded frozen BN, in-place bias+residual+ReLU, the block
+    output handed on as a pair whose gradients meet in mono_relu_grad2_f32) against the same blocks written with
+    plain PyTorch ops: output, input gradient and every convolution weight gradient."""
+    import torch.nn.functional as F
+    from monosowa_amd.monodetr.backbone import Bottleneck, FrozenBatchNorm2d
+    torch.manual_seed(5)
+    ds = torch.nn.Sequential(torch.nn.Conv2d(64, 128, 1, stride=2, bias=False), FrozenBatchNorm2d(128))
+    blocks = torch.nn.Sequential(Bottleneck(64, 32, stride=2, downsample=ds), Bottleneck(128, 32), Bottleneck(128, 32)).cuda()
+    for m in blocks.modules():
+        if isinstance(m, FrozenBatchNorm2d):
+            m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3); m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5)
+    blocks = blocks.to(memory_format=torch.channels_last)
+    x = torch.randn(2, 64, 24, 40, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    go = torch.randn(2, 128, 12, 20, device="cuda").contiguous(memory_format=torch.channels_last)
+    params = [p for p in blocks.parameters() if p.requires_grad]
+
+    def plain(x):
+        def cb(x, conv, bn, res=None, relu=True):
+            y = bn(conv(x))
+            y = y if res is None else y + res
+            return F.relu(y) if relu else y
+        for b in blocks:
+            out = cb(cb(x, b.conv1, b.bn1), b.conv2, b.bn2)
+            idt = x if b.downsample is None else cb(x, b.downsample[0], b.downsample[1], relu=False)
+            x = cb(out, b.conv3, b.bn3, idt)
+        return x
+
+    def run(fn):
+        x.grad = None
+        for p in params:
+            p.grad = None
+        y = fn(x)
+        (y * go).sum().backward()
+        return [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in params]
+    ours = run(lambda t: blocks(t)[0])
+    ref = run(plain)
+    assert len(ours) == len(ref) and len(ours) > 10
+    for a, b in zip(ours, ref):
+        assert (a - b).abs().max() <= 2e-5 * max(b.abs().max().item(), 1e-3)
