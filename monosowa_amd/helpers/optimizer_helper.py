@@ -53,8 +53,13 @@ class AdamW(Optimizer):
     def _fused_step(self, group, step, params, grads, exp_avgs, exp_avg_sqs):
         """All parameters of the group in one HIP launch (monosowa_amd/csrc/pointwise.hip adamw_kernel) when they are
         dense contiguous float32 GPU tensors; same operations in the same order as the foreach formulation below."""
+        # element-wise over storage order: any dense layout works (channels_last convolution weights included) as long
+        # as the parameter, its gradient and both moments share it
+        def dense(t):
+            return t.is_cuda and t.dtype == torch.float32 and (t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)))
         if group["amsgrad"] or not params or not all(
-                t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for ts in (params, grads, exp_avgs, exp_avg_sqs) for t in ts):
+                dense(p) and p.stride() == g.stride() == m.stride() == v.stride() and g.dtype == torch.float32 and g.is_cuda
+                for p, g, m, v in zip(params, grads, exp_avgs, exp_avg_sqs)):
             return False
         from ..pointwise import FusedAdamWPlan
         plans = self.__dict__.setdefault("_fused_plans", {})

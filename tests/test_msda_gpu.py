@@ -573,6 +573,7 @@ def test_fused_adamw_matches_the_foreach_formulation():
     torch.manual_seed(0)
     shapes = [(7,), (256, 256, 3, 3), (33, 5), (1,), (70001,), (128,)]
     pa = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    pa[1] = torch.nn.Parameter(pa[1].detach().contiguous(memory_format=torch.channels_last))      # like a conv weight
     pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
     mk = lambda ps: AdamW([{"params": ps[:2], "weight_decay": 0}, {"params": ps[2:], "weight_decay": 1e-4}], lr=2e-4)
     fused, plain = mk(pa), mk(pb)
@@ -583,7 +584,8 @@ def test_fused_adamw_matches_the_foreach_formulation():
         for a, b in zip(pa, pb):
             g = torch.randn(a.shape, device="cuda") * (10.0 ** (it - 2))
             pool[off:off + a.numel()] = g.flatten()
-            a.grad = pool[off:off + a.numel()].view(a.shape) if it % 2 else g.clone()
+            g = g.contiguous(memory_format=torch.channels_last) if g.dim() == 4 else g
+            a.grad = pool[off:off + a.numel()].view(a.shape) if (it % 2 and g.dim() != 4) else g.clone()
             b.grad = g.clone()
             off += a.numel()
         fused.step()
