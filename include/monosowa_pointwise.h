@@ -28,6 +28,12 @@ int mono_dropout_add_layernorm_fwd_f32(const float *x, const float *z, const flo
                                        float *s, float *mean, float *rstd, long long rows, int C, float p,
                                        unsigned long long seed, float eps, void *stream);
 
+/* y = dropout_p(relu(h)) over n contiguous floats (n % 4 == 0), hash mask from (seed, element index); the FFN hidden
+ * activation `self.dropout2(F.relu(self.linear1(src)))` (depthaware_transformer.py:352,513, transformer.py:63). */
+int mono_relu_dropout_fwd_f32(const float *h, float *y, long long n, float p, unsigned long long seed, void *stream);
+/* grad_h = grad_y / (1 - p) where y > 0 (kept and h > 0), else 0. */
+int mono_relu_dropout_bwd_f32(const float *grad_y, const float *y, float *grad_h, long long n, float p, void *stream);
+
 /* One step of the reference's AdamW variant (lib/helpers/optimizer_helper.py:69-129: eps added to sqrt(v) before the
  * bias correction, decay scaled by the corrected step size) over all parameters in one launch.
  * table (device): p[n_chunks], g[n_chunks], m[n_chunks], v[n_chunks] as 64-bit device addresses, then n[n_chunks]
@@ -50,15 +56,21 @@ int mono_colsum_f32(const float *g, float *out, float *partials, long long rows,
 
 /* GroupNorm(32 groups, 256 channels) (+ ReLU when relu != 0) on a channels-last tensor x [B, HW, 256]
  * (reference: nn.GroupNorm(32, hidden_dim) in monodetr.py:68-88 input_proj and depth_predictor.py:27-52).
- * stats: f64 [B, 32, 2] scratch, ZERO on entry.  mean_rstd: f32 [B, 32, 2], saved for the backward. */
-int mono_groupnorm_nhwc_fwd_f32(const float *x, const float *gamma, const float *beta, float *y, double *stats,
-                                float *mean_rstd, int B, int HW, int C, int G, float eps, int relu, void *stream);
+ * pre_bias [256] or NULL: added to x first -- the bias of the convolution in front (nn.Sequential(Conv2d, GroupNorm)),
+ * so that convolution can run bias-free.  stats: f64 [B, 32, 2] scratch, ZERO on entry.  mean_rstd: f32 [B, 32, 2]. */
+int mono_groupnorm_nhwc_fwd_f32(const float *x, const float *pre_bias, const float *gamma, const float *beta, float *y,
+                                double *stats, float *mean_rstd, int B, int HW, int C, int G, float eps, int relu,
+                                void *stream);
+
+/* Workgroups of the backward = rows (of 256 floats) of gbias_partials it needs. */
+int mono_groupnorm_blocks(int B, int HW);
 
 /* gx [B, HW, 256].  part: f64 [B, 256, 2], ZERO on entry; on return part[b][c] = {sum gy'*xhat, sum gy'} so that
- * ggamma[c] = sum_b part[b][c][0], gbeta[c] = sum_b part[b][c][1].  y = forward output (ReLU mask), NULL if relu == 0. */
-int mono_groupnorm_nhwc_bwd_f32(const float *gy, const float *x, const float *y, const float *mean_rstd,
-                                const float *gamma, float *gx, double *part, int B, int HW, int C, int G, int relu,
-                                void *stream);
+ * ggamma[c] = sum_b part[b][c][0], gbeta[c] = sum_b part[b][c][1].  y = forward output (ReLU mask), NULL if relu == 0.
+ * With pre_bias != NULL: gbias [256] = gradient of pre_bias, gbias_partials = scratch. */
+int mono_groupnorm_nhwc_bwd_f32(const float *gy, const float *x, const float *pre_bias, const float *y,
+                                const float *mean_rstd, const float *gamma, float *gx, double *part, float *gbias,
+                                float *gbias_partials, int B, int HW, int C, int G, int relu, void *stream);
 
 #ifdef __cplusplus
 }

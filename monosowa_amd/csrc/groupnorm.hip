@@ -25,15 +25,24 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, double *__restrict__ stats, int HW) {
+// pre_bias (nullable): a per-channel bias added to x before the normalisation (the preceding convolution's bias, so
+// that the convolution runs without its bias pass and the bias gradient falls out of the backward below).
+__device__ __forceinline__ float4 load_bias(const float *pre_bias, int lane) {
+  return pre_bias ? reinterpret_cast<const float4 *>(pre_bias)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, const float *__restrict__ pre_bias,
+                                                       double *__restrict__ stats, int HW) {
   __shared__ double red[4][kGnG][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
   const int p0 = blockIdx.x * kGnPix, p1 = min(p0 + kGnPix, HW);
   const float *xb = x + ((long long)b * HW) * kGnC + lane * 4;
   double s = 0.0, ss = 0.0;
+  const float4 pb = load_bias(pre_bias, lane);
 #pragma unroll 4
   for (int p = p0 + wave; p < p1; p += 4) {
-    const float4 v = *reinterpret_cast<const float4 *>(xb + (long long)p * kGnC);
+    float4 v = *reinterpret_cast<const float4 *>(xb + (long long)p * kGnC);
+    v.x += pb.x; v.y += pb.y; v.z += pb.z; v.w += pb.w;
     s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
     ss = fma((double)v.x, (double)v.x, ss); ss = fma((double)v.y, (double)v.y, ss);
     ss = fma((double)v.z, (double)v.z, ss); ss = fma((double)v.w, (double)v.w, ss);
@@ -50,7 +59,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
 }
 
 template <bool RELU>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const double *__restrict__ stats,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ pre_bias,
+                                                       const double *__restrict__ stats,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
                                                        float *__restrict__ y, float *__restrict__ mean_rstd, int HW, float eps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y, g = lane >> 1;
@@ -64,13 +74,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
   }
   const float4 ga = reinterpret_cast<const float4 *>(gamma)[lane], be = reinterpret_cast<const float4 *>(beta)[lane];
   const float4 sc = make_float4(rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w);
+  const float4 pb = load_bias(pre_bias, lane);
   const int p0 = blockIdx.x * kGnPix, p1 = min(p0 + kGnPix, HW);
   const long long base = ((long long)b * HW) * kGnC + lane * 4;
 #pragma unroll 4
   for (int p = p0 + wave; p < p1; p += 4) {
     const float4 v = *reinterpret_cast<const float4 *>(x + base + (long long)p * kGnC);
-    float4 o = make_float4((v.x - mean) * sc.x + be.x, (v.y - mean) * sc.y + be.y, (v.z - mean) * sc.z + be.z,
-                           (v.w - mean) * sc.w + be.w);
+    float4 o = make_float4((v.x + pb.x - mean) * sc.x + be.x, (v.y + pb.y - mean) * sc.y + be.y,
+                           (v.z + pb.z - mean) * sc.z + be.z, (v.w + pb.w - mean) * sc.w + be.w);
     if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     *reinterpret_cast<float4 *>(y + base + (long long)p * kGnC) = o;
   }
@@ -79,18 +90,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
 // y is the saved forward output when RELU (its sign is the ReLU mask), unused otherwise.
 template <bool RELU>
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float *__restrict__ gy, const float *__restrict__ x,
-                                                           const float *__restrict__ y, const float *__restrict__ mean_rstd,
-                                                           double *__restrict__ part, int HW) {
+                                                           const float *__restrict__ pre_bias, const float *__restrict__ y,
+                                                           const float *__restrict__ mean_rstd, double *__restrict__ part, int HW) {
   __shared__ double red[3][64][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y, g = lane >> 1;
   const float mean = mean_rstd[((long long)b * kGnG + g) * 2], rstd = mean_rstd[((long long)b * kGnG + g) * 2 + 1];
   const int p0 = blockIdx.x * kGnPix, p1 = min(p0 + kGnPix, HW);
   const long long base = ((long long)b * HW) * kGnC + lane * 4;
   double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const float4 pb = load_bias(pre_bias, lane);
 #pragma unroll 2
   for (int p = p0 + wave; p < p1; p += 4) {
     float4 gv = *reinterpret_cast<const float4 *>(gy + base + (long long)p * kGnC);
-    const float4 v = *reinterpret_cast<const float4 *>(x + base + (long long)p * kGnC);
+    float4 v = *reinterpret_cast<const float4 *>(x + base + (long long)p * kGnC);
+    v.x += pb.x; v.y += pb.y; v.z += pb.z; v.w += pb.w;
     if (RELU) {
       const float4 yo = *reinterpret_cast<const float4 *>(y + base + (long long)p * kGnC);
       gv.x = yo.x > 0.f ? gv.x : 0.f; gv.y = yo.y > 0.f ? gv.y : 0.f;
@@ -113,11 +126,15 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float *__restri
   }
 }
 
+// gbias_partials (with pre_bias): one row of 256 per workgroup = sum of gx over the workgroup's pixels (the bias gradient
+// is the sum of gx over batch and pixels; partial_sum_kernel adds the rows).
 template <bool RELU>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restrict__ gy, const float *__restrict__ x,
-                                                           const float *__restrict__ y, const float *__restrict__ mean_rstd,
-                                                           const float *__restrict__ gamma, const double *__restrict__ part,
-                                                           float *__restrict__ gx, int HW) {
+                                                           const float *__restrict__ pre_bias, const float *__restrict__ y,
+                                                           const float *__restrict__ mean_rstd, const float *__restrict__ gamma,
+                                                           const double *__restrict__ part, float *__restrict__ gx,
+                                                           float *__restrict__ gbias_partials, int HW) {
+  __shared__ float4 red[3][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y, g = lane >> 1;
   const float mean = mean_rstd[((long long)b * kGnG + g) * 2], rstd = mean_rstd[((long long)b * kGnG + g) * 2 + 1];
   const float4 ga = reinterpret_cast<const float4 *>(gamma)[lane];
@@ -130,10 +147,13 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restri
   const float a = (float)(A * inv_n), bs = (float)(Bs * inv_n);
   const int p0 = blockIdx.x * kGnPix, p1 = min(p0 + kGnPix, HW);
   const long long base = ((long long)b * HW) * kGnC + lane * 4;
+  const float4 pb = load_bias(pre_bias, lane);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 2
   for (int p = p0 + wave; p < p1; p += 4) {
     float4 gv = *reinterpret_cast<const float4 *>(gy + base + (long long)p * kGnC);
-    const float4 v = *reinterpret_cast<const float4 *>(x + base + (long long)p * kGnC);
+    float4 v = *reinterpret_cast<const float4 *>(x + base + (long long)p * kGnC);
+    v.x += pb.x; v.y += pb.y; v.z += pb.z; v.w += pb.w;
     if (RELU) {
       const float4 yo = *reinterpret_cast<const float4 *>(y + base + (long long)p * kGnC);
       gv.x = yo.x > 0.f ? gv.x : 0.f; gv.y = yo.y > 0.f ? gv.y : 0.f;
@@ -145,6 +165,17 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restri
     o.z = rstd * (gv.z * ga.z - bs - (v.z - mean) * rstd * a);
     o.w = rstd * (gv.w * ga.w - bs - (v.w - mean) * rstd * a);
     *reinterpret_cast<float4 *>(gx + base + (long long)p * kGnC) = o;
+    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+  }
+  if (gbias_partials) {
+    if (wave) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (!wave) {
+      const float4 r0 = red[0][lane], r1 = red[1][lane], r2 = red[2][lane];
+      float *dst = gbias_partials + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * kGnC + lane * 4;
+      *reinterpret_cast<float4 *>(dst) = make_float4(acc.x + r0.x + r1.x + r2.x, acc.y + r0.y + r1.y + r2.y,
+                                                     acc.z + r0.z + r1.z + r2.z, acc.w + r0.w + r1.w + r2.w);
+    }
   }
 }
 

@@ -146,6 +146,31 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
   }
 }
 
+// ---- y = dropout(relu(h)) (FFN hidden activation, depthaware_transformer.py:352 `self.dropout2(F.relu(self.linear1(src)))`)
+// forward: one pass, hash mask; backward: grad_h = grad_y * scale where y > 0 (y > 0 <=> kept and h > 0), zero elsewhere
+__global__ __launch_bounds__(256) void relu_dropout_fwd_kernel(const float *__restrict__ h, float *__restrict__ y, long long n_vec,
+                                                               unsigned threshold, float scale, unsigned long long seed) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    float4 v = reinterpret_cast<const float4 *>(h)[i];
+    const long long e = i * 4;
+    v.x = v.x > 0.f ? v.x * keep_scale(seed, e, threshold, scale) : 0.f;
+    v.y = v.y > 0.f ? v.y * keep_scale(seed, e + 1, threshold, scale) : 0.f;
+    v.z = v.z > 0.f ? v.z * keep_scale(seed, e + 2, threshold, scale) : 0.f;
+    v.w = v.w > 0.f ? v.w * keep_scale(seed, e + 3, threshold, scale) : 0.f;
+    reinterpret_cast<float4 *>(y)[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ y,
+                                                               float *__restrict__ gh, long long n_vec, float scale) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    const float4 g = reinterpret_cast<const float4 *>(gy)[i], v = reinterpret_cast<const float4 *>(y)[i];
+    reinterpret_cast<float4 *>(gh)[i] = make_float4(v.x > 0.f ? g.x * scale : 0.f, v.y > 0.f ? g.y * scale : 0.f,
+                                                    v.z > 0.f ? g.z * scale : 0.f, v.w > 0.f ? g.w * scale : 0.f);
+  }
+}
+
 // ---- column sums of a row-major [rows, C] matrix (bias gradients): out[c] += sum_r g[r][c] --------------------
 // PyTorch's reduce kernel takes 26 us for [8800, 256] (few workgroups); here a wave walks rows with float4 lanes,
 // the 4 waves of a workgroup combine through LDS into one partial row; partial_sum_kernel adds the partial rows.
@@ -326,6 +351,23 @@ int mono_dropout_add_layernorm_bwd_f32(const float *gy, const float *s, const fl
   return (int)hipGetLastError();
 }
 
+// y = dropout_p(relu(h)), n contiguous floats (n % 4 == 0); the mask is a hash of (seed, element index).
+int mono_relu_dropout_fwd_f32(const float *h, float *y, long long n, float p, unsigned long long seed, void *stream_) {
+  if (!h || !y) return -1;
+  if (n <= 0 || (n & 3) || !(p >= 0.f && p < 1.f) || ((uintptr_t)h & 15) || ((uintptr_t)y & 15)) return -2;
+  const unsigned threshold = (unsigned)((double)p * 4294967296.0);
+  mono::relu_dropout_fwd_kernel<<<mono::grid_for_vec(n / 4), 256, 0, (hipStream_t)stream_>>>(h, y, n / 4, threshold, 1.f / (1.f - p), seed);
+  return (int)hipGetLastError();
+}
+
+// grad_h = grad_y / (1 - p) where y > 0, else 0  (y = the forward output).
+int mono_relu_dropout_bwd_f32(const float *grad_y, const float *y, float *grad_h, long long n, float p, void *stream_) {
+  if (!grad_y || !y || !grad_h) return -1;
+  if (n <= 0 || (n & 3) || !(p >= 0.f && p < 1.f) || ((uintptr_t)grad_y & 15) || ((uintptr_t)y & 15) || ((uintptr_t)grad_h & 15)) return -2;
+  mono::relu_dropout_bwd_kernel<<<mono::grid_for_vec(n / 4), 256, 0, (hipStream_t)stream_>>>(grad_y, y, grad_h, n / 4, 1.f / (1.f - p));
+  return (int)hipGetLastError();
+}
+
 // One AdamW step (the reference's variant, see adamw_kernel) for n_chunks chunks.  table: device buffer holding, back to
 // back, p[n_chunks], g[n_chunks], m[n_chunks], v[n_chunks] (64-bit device addresses), n[n_chunks] (int32, elements
 // per chunk), wd[n_chunks] (float).  step_size = lr * sqrt(1 - b2^t) / (1 - b1^t).  Scalars arrive as doubles so that
@@ -364,36 +406,43 @@ int mono_colsum_f32(const float *g, float *out, float *partials, long long rows,
   return (int)hipGetLastError();
 }
 
-// GroupNorm(G = 32, C = 256) (+ ReLU) on channels-last x [B, HW, 256].  stats [B, 32, 2] f64 must be zero on entry;
-// mean_rstd [B, 32, 2] f32 is written for the backward.
-int mono_groupnorm_nhwc_fwd_f32(const float *x, const float *gamma, const float *beta, float *y, double *stats,
-                                float *mean_rstd, int B, int HW, int C, int G, float eps, int relu, void *stream_) {
+// GroupNorm(G = 32, C = 256) (+ ReLU) on channels-last x [B, HW, 256] (+ pre_bias[256] when not NULL: the preceding
+// convolution's bias).  stats [B, 32, 2] f64 must be zero on entry; mean_rstd [B, 32, 2] f32 is written for the backward.
+int mono_groupnorm_nhwc_fwd_f32(const float *x, const float *pre_bias, const float *gamma, const float *beta, float *y,
+                                double *stats, float *mean_rstd, int B, int HW, int C, int G, float eps, int relu,
+                                void *stream_) {
   if (!x || !gamma || !beta || !y || !stats || !mean_rstd) return -1;
   if (B <= 0 || HW <= 0 || C != mono::kGnC || G != mono::kGnG || B > 65535) return -2;
   hipStream_t st = (hipStream_t)stream_;
   const dim3 grid((HW + mono::kGnPix - 1) / mono::kGnPix, B);
-  mono::gn_stats_kernel<<<grid, 256, 0, st>>>(x, stats, HW);
-  if (relu) mono::gn_apply_kernel<true><<<grid, 256, 0, st>>>(x, stats, gamma, beta, y, mean_rstd, HW, eps);
-  else mono::gn_apply_kernel<false><<<grid, 256, 0, st>>>(x, stats, gamma, beta, y, mean_rstd, HW, eps);
+  mono::gn_stats_kernel<<<grid, 256, 0, st>>>(x, pre_bias, stats, HW);
+  if (relu) mono::gn_apply_kernel<true><<<grid, 256, 0, st>>>(x, pre_bias, stats, gamma, beta, y, mean_rstd, HW, eps);
+  else mono::gn_apply_kernel<false><<<grid, 256, 0, st>>>(x, pre_bias, stats, gamma, beta, y, mean_rstd, HW, eps);
   return (int)hipGetLastError();
 }
 
+// Rows of gbias scratch the backward needs: one per workgroup.
+int mono_groupnorm_blocks(int B, int HW) { return B * ((HW + mono::kGnPix - 1) / mono::kGnPix); }
+
 // part [B, 256, 2] f64 must be zero on entry; on return part[b][c] = {sum gy' xhat, sum gy'} (ggamma / gbeta are its
-// sums over b).  y (the forward output) is read only when relu != 0.
-int mono_groupnorm_nhwc_bwd_f32(const float *gy, const float *x, const float *y, const float *mean_rstd,
-                                const float *gamma, float *gx, double *part, int B, int HW, int C, int G, int relu,
-                                void *stream_) {
-  if (!gy || !x || !mean_rstd || !gamma || !gx || !part || (relu && !y)) return -1;
+// sums over b).  y (the forward output) is read only when relu != 0.  With pre_bias: gbias [256] receives the bias
+// gradient (= sum of gx over batch and pixels), gbias_partials is scratch of mono_groupnorm_blocks(B, HW) * 256 floats.
+int mono_groupnorm_nhwc_bwd_f32(const float *gy, const float *x, const float *pre_bias, const float *y,
+                                const float *mean_rstd, const float *gamma, float *gx, double *part, float *gbias,
+                                float *gbias_partials, int B, int HW, int C, int G, int relu, void *stream_) {
+  if (!gy || !x || !mean_rstd || !gamma || !gx || !part || (relu && !y) || (pre_bias && (!gbias || !gbias_partials))) return -1;
   if (B <= 0 || HW <= 0 || C != mono::kGnC || G != mono::kGnG || B > 65535) return -2;
   hipStream_t st = (hipStream_t)stream_;
   const dim3 grid((HW + mono::kGnPix - 1) / mono::kGnPix, B);
+  float *gp = pre_bias ? gbias_partials : nullptr;
   if (relu) {
-    mono::gn_bwd_stats_kernel<true><<<grid, 256, 0, st>>>(gy, x, y, mean_rstd, part, HW);
-    mono::gn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(gy, x, y, mean_rstd, gamma, part, gx, HW);
+    mono::gn_bwd_stats_kernel<true><<<grid, 256, 0, st>>>(gy, x, pre_bias, y, mean_rstd, part, HW);
+    mono::gn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(gy, x, pre_bias, y, mean_rstd, gamma, part, gx, gp, HW);
   } else {
-    mono::gn_bwd_stats_kernel<false><<<grid, 256, 0, st>>>(gy, x, y, mean_rstd, part, HW);
-    mono::gn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(gy, x, y, mean_rstd, gamma, part, gx, HW);
+    mono::gn_bwd_stats_kernel<false><<<grid, 256, 0, st>>>(gy, x, pre_bias, y, mean_rstd, part, HW);
+    mono::gn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(gy, x, pre_bias, y, mean_rstd, gamma, part, gx, gp, HW);
   }
+  if (pre_bias) mono::partial_sum_kernel<<<1, 1024, 0, st>>>(gbias_partials, gbias, (int)(grid.x * grid.y), mono::kGnC);
   return (int)hipGetLastError();
 }
 

@@ -49,7 +49,7 @@ _seed_counter = [0]
 def _next_seed():
     _seed_counter[0] += 1
     rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
-    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter[0] * 0xD1B54A32D192ED03 + rank * 0x94D049BB133111EB) & (2 ** 64 - 1)
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter[0] * 0xD1B54A32D192ED03 + rank * 0x94D049BB133111EB) & (2 ** 63 - 1)   # fits int64: autograd / profiler argument records
 
 
 def forward(q, k, v, scale, p, seed):

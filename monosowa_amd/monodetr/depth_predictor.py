@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..flash_attn import mha_forward, mha_supported
-from ..pointwise import dropout_add_layernorm, group_norm
+from ..pointwise import conv_group_norm, dropout_add_layernorm, relu_dropout
 from ..token_linear import token_linear
 
 
@@ -37,7 +37,7 @@ class DepthEncoderLayer(nn.Module):
         else:
             attn = self.self_attn(qk, qk, value=src, key_padding_mask=src_key_padding_mask, need_weights=False)[0]
         src = dropout_add_layernorm(src, attn, self.norm1, self.dropout1)
-        ff = token_linear(self.dropout(F.relu(token_linear(src, self.linear1))), self.linear2)
+        ff = token_linear(relu_dropout(token_linear(src, self.linear1), self.dropout), self.linear2)
         return dropout_add_layernorm(src, ff, self.norm2, self.dropout2)
 
 
@@ -87,12 +87,12 @@ class DepthPredictor(nn.Module):
            depth_pos_embed_ip [B,256,H,W]."""
         assert len(feature) == 4
         # Conv2d + GroupNorm(32, d) (+ ReLU) blocks: the norms run through the channels-last HIP kernels
-        src_16 = group_norm(self.proj[0](feature[1]), self.proj[1])
-        src_32 = group_norm(self.upsample[0](F.interpolate(feature[2], size=src_16.shape[-2:], mode="bilinear")), self.upsample[1])
-        src_8 = group_norm(self.downsample[0](feature[0]), self.downsample[1])
+        src_16 = conv_group_norm(feature[1], self.proj[0], self.proj[1])
+        src_32 = conv_group_norm(F.interpolate(feature[2], size=src_16.shape[-2:], mode="bilinear"), self.upsample[0], self.upsample[1])
+        src_8 = conv_group_norm(feature[0], self.downsample[0], self.downsample[1])
         src = (src_8 + src_16 + src_32) / 3
-        src = group_norm(self.depth_head[0](src), self.depth_head[1], relu=True)
-        src = group_norm(self.depth_head[3](src), self.depth_head[4], relu=True)
+        src = conv_group_norm(src, self.depth_head[0], self.depth_head[1], relu=True)
+        src = conv_group_norm(src, self.depth_head[3], self.depth_head[4], relu=True)
         depth_logits = self.depth_classifier(src)
 
         depth_probs = F.softmax(depth_logits, dim=1)

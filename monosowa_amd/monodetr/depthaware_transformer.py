@@ -20,7 +20,7 @@ from .misc import inverse_sigmoid
 from .. import MultiScaleDeformableAttention as _MSDA
 from ..ms_deform_attn import MSDeformAttn
 from ..flash_attn import mha_forward, mha_supported
-from ..pointwise import dropout_add_layernorm
+from ..pointwise import dropout_add_layernorm, relu_dropout
 from ..token_linear import token_linear
 
 
@@ -68,7 +68,7 @@ class VisualEncoderLayer(nn.Module):
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         attn = self.self_attn(_add_pos(src, pos), reference_points, src, spatial_shapes, level_start_index, padding_mask)
         src = dropout_add_layernorm(src, attn, self.norm1, self.dropout1)
-        ff = token_linear(self.dropout2(F.relu(token_linear(src, self.linear1))), self.linear2)
+        ff = token_linear(relu_dropout(token_linear(src, self.linear1), self.dropout2), self.linear2)
         return dropout_add_layernorm(src, ff, self.norm2, self.dropout3)
 
 

@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..pointwise import group_norm
+from ..pointwise import conv_group_norm
 from .depthaware_transformer import MLP
 from .misc import NestedTensor, inverse_sigmoid
 
@@ -111,7 +111,7 @@ class MonoDETR(nn.Module):
     def _project(self, l, x):
         """input_proj[l] = Conv2d + GroupNorm(32, hidden_dim) (monodetr.py:68-88), the norm through the NHWC kernel."""
         conv, gn = self.input_proj[l]
-        return group_norm(conv(x), gn)
+        return conv_group_norm(x, conv, gn)
 
     def project_features(self, features, pos):
         srcs, masks = [], []

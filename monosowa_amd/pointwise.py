@@ -7,7 +7,8 @@ import torch
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_dropout_add_layernorm_fwd_f32",
-           "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_colsum_f32", "mono_reduce_blocks", "mono_adamw_step_f32")
+           "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
+           "mono_relu_dropout_bwd_f32")
 _lib = None
 
 
@@ -32,9 +33,15 @@ def load():
         lib.mono_reduce_blocks.restype = I
         lib.mono_reduce_blocks.argtypes = [LL]
         lib.mono_groupnorm_nhwc_fwd_f32.restype = I
-        lib.mono_groupnorm_nhwc_fwd_f32.argtypes = [P] * 6 + [I, I, I, I, F, I, P]
+        lib.mono_groupnorm_nhwc_fwd_f32.argtypes = [P] * 7 + [I, I, I, I, F, I, P]
         lib.mono_groupnorm_nhwc_bwd_f32.restype = I
-        lib.mono_groupnorm_nhwc_bwd_f32.argtypes = [P] * 7 + [I, I, I, I, I, P]
+        lib.mono_groupnorm_nhwc_bwd_f32.argtypes = [P] * 10 + [I, I, I, I, I, P]
+        lib.mono_groupnorm_blocks.restype = I
+        lib.mono_groupnorm_blocks.argtypes = [I, I]
+        lib.mono_relu_dropout_fwd_f32.restype = I
+        lib.mono_relu_dropout_fwd_f32.argtypes = [P, P, LL, F, U, P]
+        lib.mono_relu_dropout_bwd_f32.restype = I
+        lib.mono_relu_dropout_bwd_f32.argtypes = [P, P, P, LL, F, P]
         lib.mono_adamw_step_f32.restype = I
         lib.mono_adamw_step_f32.argtypes = [P, I] + [ctypes.c_double] * 4 + [P]
         lib.mono_colsum_f32.restype = I
@@ -200,45 +207,68 @@ def dropout_add_layernorm(x, z, norm, dropout):
 # ---------------------------------------------------------------------------------------------------------
 class _GroupNormNHWC(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, relu):
+    def forward(ctx, x, pre_bias, weight, bias, eps, relu):
         B, C, H, W = x.shape
         y = torch.empty_like(x)                                       # keeps the channels_last strides
         stats = torch.zeros(B, 32, 2, dtype=torch.float64, device=x.device)
         mean_rstd = torch.empty(B, 32, 2, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            code = load().mono_groupnorm_nhwc_fwd_f32(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
-                                                      stats.data_ptr(), mean_rstd.data_ptr(), B, H * W, C, 32, float(eps),
-                                                      int(relu), torch.cuda.current_stream().cuda_stream)
+            code = load().mono_groupnorm_nhwc_fwd_f32(x.data_ptr(), pre_bias.data_ptr() if pre_bias is not None else None,
+                                                      weight.data_ptr(), bias.data_ptr(), y.data_ptr(), stats.data_ptr(),
+                                                      mean_rstd.data_ptr(), B, H * W, C, 32, float(eps), int(relu),
+                                                      torch.cuda.current_stream().cuda_stream)
         if code:
             raise RuntimeError("mono_groupnorm_nhwc_fwd_f32 failed with code %d" % code)
         ctx.relu = relu
-        ctx.save_for_backward(x, y if relu else None, mean_rstd, weight)
+        ctx.save_for_backward(x, pre_bias, y if relu else None, mean_rstd, weight)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, y, mean_rstd, weight = ctx.saved_tensors
+        x, pre_bias, y, mean_rstd, weight = ctx.saved_tensors
         B, C, H, W = x.shape
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = torch.empty_like(x)
         part = torch.zeros(B, C, 2, dtype=torch.float64, device=x.device)
+        lib = load()
+        gbias = partials = None
+        if pre_bias is not None:
+            gbias = torch.empty(C, dtype=torch.float32, device=x.device)
+            partials = torch.empty(lib.mono_groupnorm_blocks(B, H * W) * C, dtype=torch.float32, device=x.device)
+        ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(x.device):
-            code = load().mono_groupnorm_nhwc_bwd_f32(gy.data_ptr(), x.data_ptr(), y.data_ptr() if ctx.relu else None,
-                                                      mean_rstd.data_ptr(), weight.data_ptr(), gx.data_ptr(), part.data_ptr(),
-                                                      B, H * W, C, 32, int(ctx.relu), torch.cuda.current_stream().cuda_stream)
+            code = lib.mono_groupnorm_nhwc_bwd_f32(gy.data_ptr(), x.data_ptr(), ptr(pre_bias), ptr(y if ctx.relu else None),
+                                                   mean_rstd.data_ptr(), weight.data_ptr(), gx.data_ptr(), part.data_ptr(),
+                                                   ptr(gbias), ptr(partials), B, H * W, C, 32, int(ctx.relu),
+                                                   torch.cuda.current_stream().cuda_stream)
         if code:
             raise RuntimeError("mono_groupnorm_nhwc_bwd_f32 failed with code %d" % code)
         gwb = part.sum(0).float()
-        return gx, gwb[:, 0].contiguous(), gwb[:, 1].contiguous(), None, None
+        return gx, gbias, gwb[:, 0].contiguous(), gwb[:, 1].contiguous(), None, None
 
 
-def group_norm(x, gn, relu=False):
-    """``gn(x)`` (+ ReLU) for an ``nn.GroupNorm(32, 256)`` on a channels-last float32 GPU tensor: two HIP kernels
-    forward, two backward, no layout copies; the PyTorch formulation for anything else."""
+def group_norm(x, gn, relu=False, pre_bias=None):
+    """``gn(x + pre_bias[None, :, None, None])`` (+ ReLU) for an ``nn.GroupNorm(32, 256)`` on a channels-last float32 GPU
+    tensor: two HIP kernels forward, two backward, no layout copies; the PyTorch formulation for anything else.
+    ``pre_bias``: the bias of the convolution in front, see ``conv_group_norm``."""
     if _nhwc_ok(x) and x.size(1) == 256 and gn.num_groups == 32 and gn.affine and x.size(0) <= 65535:
-        return _GroupNormNHWC.apply(x, gn.weight, gn.bias, gn.eps, relu)
+        return _GroupNormNHWC.apply(x, pre_bias, gn.weight, gn.bias, gn.eps, relu)
+    if pre_bias is not None:
+        x = x + pre_bias.view(1, -1, 1, 1)
     y = gn(x)
     return torch.relu(y) if relu else y
+
+
+def conv_group_norm(x, conv, gn, relu=False):
+    """``gn(conv(x))`` (+ ReLU) for ``nn.Sequential(Conv2d, GroupNorm(32, 256))``: the convolution runs without its bias,
+    which is added inside the normalisation kernels; its gradient is the per-channel sum of the kernels' grad_input
+    (PyTorch: a bias pass after the convolution and a 0.5 TB/s reduction for its gradient)."""
+    if conv.bias is not None and x.is_cuda and x.dtype == torch.float32 and conv.out_channels == 256 and gn.num_groups == 32:
+        y = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if _nhwc_ok(y):
+            return group_norm(y, gn, relu, pre_bias=conv.bias)
+        return group_norm(y + conv.bias.view(1, -1, 1, 1), gn, relu)
+    return group_norm(conv(x), gn, relu)
 
 
 def colsum(g2):
@@ -309,3 +339,39 @@ class FusedAdamWPlan:
                                               torch.cuda.current_stream().cuda_stream)
         if code:
             raise RuntimeError("mono_adamw_step_f32 failed with code %d" % code)
+
+
+# ---------------------------------------------------------------------------------------------------------
+class _ReluDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, p):
+        h = h.contiguous()
+        y = torch.empty_like(h)
+        seed = _next_seed()
+        with torch.cuda.device(h.device):
+            code = load().mono_relu_dropout_fwd_f32(h.data_ptr(), y.data_ptr(), h.numel(), float(p), seed, torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_relu_dropout_fwd_f32 failed with code %d" % code)
+        ctx.save_for_backward(y)
+        ctx.p = p
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gh = torch.empty_like(y)
+        with torch.cuda.device(y.device):
+            code = load().mono_relu_dropout_bwd_f32(gy.data_ptr(), y.data_ptr(), gh.data_ptr(), y.numel(), float(ctx.p), torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_relu_dropout_bwd_f32 failed with code %d" % code)
+        return gh, None
+
+
+def relu_dropout(h, dropout):
+    """``dropout(relu(h))`` for an ``nn.Dropout``: one HIP pass forward and one backward on large float32 GPU tensors in
+    training (PyTorch: ReLU, dropout + mask, masked-scale, threshold-backward passes); PyTorch ops otherwise."""
+    if h.is_cuda and h.dtype == torch.float32 and dropout.training and 0.0 < dropout.p < 1.0 and h.numel() % 4 == 0 \
+            and h.numel() >= (1 << 22) and torch.is_grad_enabled():
+        return _ReluDropout.apply(h, dropout.p)
+    return dropout(torch.relu(h))

@@ -636,3 +636,51 @@ def test_resnet_stage_with_forked_relu_backward_matches_plain_autograd():
     assert len(ours) == len(ref) and len(ours) > 10
     for a, b in zip(ours, ref):
         assert (a - b).abs().max() <= 2e-5 * max(b.abs().max().item(), 1e-3)
+
+
+def test_fused_relu_dropout():
+    """mono_relu_dropout_*: kept fraction, 1/(1-p) scaling of the kept positives, zeros for negatives, and a backward
+    that uses exactly the forward's mask."""
+    from monosowa_amd.pointwise import relu_dropout
+    torch.manual_seed(0)
+    drop = torch.nn.Dropout(0.1).cuda().train()
+    h = torch.randn(16, 1024, 256, device="cuda", requires_grad=True)
+    go = torch.randn_like(h)
+    y = relu_dropout(h, drop)
+    assert "ReluDropout" in type(y.grad_fn).__name__
+    y.backward(go)
+    pos = h.detach() > 0
+    kept = y.detach() != 0
+    assert not (kept & ~pos).any()
+    assert abs((kept & pos).float().sum().item() / pos.float().sum().item() - 0.9) < 0.003
+    assert torch.allclose(y.detach()[kept], h.detach()[kept] / 0.9, rtol=1e-6)
+    assert torch.allclose(h.grad[kept], go[kept] / 0.9, rtol=1e-6) and (h.grad[~kept] == 0).all()
+    drop.eval()
+    assert torch.equal(relu_dropout(h, drop), torch.relu(h))
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv_group_norm_with_folded_bias_matches_sequential(relu):
+    """conv_group_norm: bias-free convolution + GroupNorm kernels carrying the convolution bias, against
+    nn.Sequential(Conv2d, GroupNorm) (+ ReLU): output, input gradient, conv weight / bias and norm weight / bias gradients."""
+    from monosowa_amd.pointwise import conv_group_norm
+    torch.manual_seed(2)
+    conv = torch.nn.Conv2d(64, 256, 3, padding=1).cuda().to(memory_format=torch.channels_last)
+    gn = torch.nn.GroupNorm(32, 256).cuda()
+    with torch.no_grad():
+        conv.bias.uniform_(-1, 1); gn.weight.uniform_(0.5, 1.5); gn.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(3, 64, 13, 21, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    go = torch.randn(3, 256, 13, 21, device="cuda").contiguous(memory_format=torch.channels_last)
+    params = list(conv.parameters()) + list(gn.parameters())
+
+    def run(fn):
+        x.grad = None
+        for p_ in params:
+            p_.grad = None
+        y = fn()
+        y.backward(go)
+        return [y.detach().clone(), x.grad.clone()] + [p_.grad.clone() for p_ in params]
+    ours = run(lambda: conv_group_norm(x, conv, gn, relu=relu))
+    ref = run(lambda: torch.relu(gn(conv(x))) if relu else gn(conv(x)))
+    for a, b, n in zip(ours, ref, ("y", "gx", "gw_conv", "gb_conv", "gw_gn", "gb_gn")):
+        assert (a - b).abs().max() <= 5e-5 * max(b.abs().max().item(), 1e-3), n
