@@ -90,6 +90,7 @@ def build_everything(args, device):
 
 
 def train_step_fn(model, criterion, optimizer):
+    from monosowa_amd.monodetr.criterion import weighted_total
     from monosowa_amd.synthetic import prepare_targets
 
     def step(batch):
@@ -98,8 +99,7 @@ def train_step_fn(model, criterion, optimizer):
         optimizer.zero_grad(set_to_none=True)
         outputs = model(inputs, calibs, tl, targets["img_size"])
         loss_dict = criterion(outputs, tl)
-        wd = criterion.weight_dict
-        total = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+        total = weighted_total(loss_dict, criterion.weight_dict)
         total.backward()
         optimizer.step()
         return total

@@ -14,6 +14,7 @@ import torch
 import tqdm
 
 from ..monodetr import misc
+from ..monodetr.criterion import weighted_total
 from ..synthetic import prepare_targets as _prepare_targets
 from .save_helper import get_checkpoint_state, load_checkpoint, save_checkpoint, unwrap
 
@@ -115,7 +116,7 @@ class Trainer(object):
         outputs = self.model(inputs, calibs, target_list, img_sizes, dn_args=None)
         loss_dict = self.detr_loss(outputs, target_list, None, info)
         weight_dict = self.detr_loss.weight_dict
-        total = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
+        total = weighted_total(loss_dict, weight_dict)
         total.backward()
         self.optimizer.step()
         return total, loss_dict

@@ -41,6 +41,19 @@ def _dev(values, dtype, device):
     return torch.as_tensor(np.asarray(values)).to(dtype).to(device, non_blocking=True)
 
 
+def weighted_total(loss_dict, weight_dict):
+    """``sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict)`` (trainer_helper.py:140-141) as one
+    stack and one dot product: two launches forward and two backward instead of ~60 + ~60 scalar kernels, which sit
+    right behind the matcher's host sync where the GPU queue is empty."""
+    keys = [k for k in loss_dict if k in weight_dict]
+    if not keys:
+        return 0
+    vals = torch.stack([loss_dict[k].reshape(()) for k in keys])
+    w = _dev([float(weight_dict[k]) for k in keys], vals.dtype, vals.device) if vals.is_cuda else \
+        torch.tensor([float(weight_dict[k]) for k in keys], dtype=vals.dtype)
+    return torch.dot(vals, w)
+
+
 class SetCriterion(nn.Module):
     def __init__(self, num_classes, matcher, weight_dict, focal_alpha, losses, group_num=11, cfg=None,
                  depth_map_size=(80, 24), fast=True):

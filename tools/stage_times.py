@@ -9,6 +9,7 @@ import yaml
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from monosowa_amd.helpers.model_helper import build_model        # noqa: E402
 from monosowa_amd.helpers.optimizer_helper import build_optimizer  # noqa: E402
+from monosowa_amd.monodetr.criterion import weighted_total   # noqa: E402
 from monosowa_amd.synthetic import make_batch, prepare_targets    # noqa: E402
 
 T0 = time.time()
@@ -66,7 +67,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         o = model(inputs, calibs, tl, targets["img_size"])
         ld = crit(o, tl)
-        tot = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+        tot = weighted_total(ld, crit.weight_dict)
         tot.backward()
         opt.step()
     timed("full train step", step, n=5)
