@@ -189,7 +189,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=device)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.backends.cudnn.benchmark = bool(args.miopen_find or tuned)
+    # with the shipped find-db MIOpen's immediate mode (benchmark off) already returns the measured winners: no search,
+    # no 25 s start-up; --miopen-find runs a fresh search
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     log("MIOpen: %s" % ("shipped find-db " + tuned if tuned else "search" if args.miopen_find else "heuristics"))
     log("torch %s on %s, world %d" % (torch.__version__, torch.cuda.get_device_name(local_rank), world))
 

@@ -8,6 +8,8 @@ MI355X by `python bench.py --miopen-find` with MIOPEN_USER_DB_PATH pointing here
 JIT-compiled winners when present), so a fresh process gets the measured choices without searching.
 
 `use_shipped_db()` must run before the first convolution (MIOpen reads the variables when its handle is created).
+`torch.backends.cudnn.benchmark` can stay False: MIOpen's immediate mode consults the find-db first, so the measured
+winners are used without any search at start-up (with benchmark = True PyTorch re-runs a 25 s find per process).
 Each rank works on its own copy: MIOpen appends to these files.
 """
 import glob
