@@ -13,11 +13,16 @@ import os
 import shutil
 import sys
 
-import torch
-import yaml
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+# measured MIOpen / GEMM kernel choices for the shipped workload (harmless for other shapes: misses fall back to the
+# libraries' heuristics); must be set before torch loads MIOpen
+from monosowa_amd import miopen_tuning                                    # noqa: E402
+miopen_tuning.use_shipped_db(int(os.environ.get("RANK", "0")))
+
+import torch                                                               # noqa: E402
+import yaml                                                                # noqa: E402
 
 from monosowa_amd.helpers.dataloader_helper import build_dataloader      # noqa: E402
 from monosowa_amd.helpers.model_helper import build_model                 # noqa: E402
