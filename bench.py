@@ -92,6 +92,9 @@ def build_everything(args, device):
     return cfg, model, criterion, optimizer, (W, H)
 
 
+_PROBE_SLEEP = float(os.environ.get("MONOSOWA_PROBE_SLEEP_MS", "0")) * 1e-3     # host-slack probe (tools only)
+
+
 def train_step_fn(model, criterion, optimizer):
     from monosowa_amd.monodetr.criterion import weighted_total
     from monosowa_amd.synthetic import prepare_targets
@@ -103,6 +106,8 @@ def train_step_fn(model, criterion, optimizer):
         outputs = model(inputs, calibs, tl, targets["img_size"])
         loss_dict = criterion(outputs, tl)
         total = weighted_total(loss_dict, criterion.weight_dict)
+        if _PROBE_SLEEP:
+            time.sleep(_PROBE_SLEEP)
         total.backward()
         optimizer.step()
         return total

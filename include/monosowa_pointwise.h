@@ -34,6 +34,22 @@ int mono_relu_dropout_fwd_f32(const float *h, float *y, long long n, float p, un
 /* grad_h = grad_y / (1 - p) where y > 0 (kept and h > 0), else 0. */
 int mono_relu_dropout_bwd_f32(const float *grad_y, const float *y, float *grad_h, long long n, float p, void *stream);
 
+/* The matched-pair losses of SetCriterion (monodetr.py:1010-1103: 3D-centre and l/r/t/b L1, GIoU, Laplacian depth,
+ * dimension-aware size L1, 12-bin heading cross entropy + residual L1) for all decoder layers in one launch.
+ * boxes/depth/dims/angle: [NL, B, Q, 6|2|3|24] contiguous predictions; idx: int64 [3, NL, K] = (image, query, flat target
+ * index) of the K matched pairs per layer; t_*: targets concatenated over the batch.  out: [NL, 6] per-layer sums
+ * {center, bbox, giou, depth, dim, angle} (divide by num_boxes); comp: [NL] (size compensation weights, for the backward). */
+int mono_matched_losses_fwd_f32(const float *boxes, const float *depth, const float *dims, const float *angle,
+                                const long long *idx, const float *t_box, const float *t_depth, const float *t_size,
+                                const long long *t_bin, const float *t_res, float *out, float *comp, int NL, int B, int Q,
+                                int K, void *stream);
+/* g_boxes / g_depth / g_dims / g_angle: gradients of the predictions for grad_out [NL, 6]; ZERO on entry. */
+int mono_matched_losses_bwd_f32(const float *boxes, const float *depth, const float *dims, const float *angle,
+                                const long long *idx, const float *t_box, const float *t_depth, const float *t_size,
+                                const long long *t_bin, const float *t_res, const float *comp, const float *grad_out,
+                                float *g_boxes, float *g_depth, float *g_dims, float *g_angle, int NL, int B, int Q, int K,
+                                void *stream);
+
 /* One step of the reference's AdamW variant (lib/helpers/optimizer_helper.py:69-129: eps added to sqrt(v) before the
  * bias correction, decay scaled by the corrected step size) over all parameters in one launch.
  * table (device): p[n_chunks], g[n_chunks], m[n_chunks], v[n_chunks] as 64-bit device addresses, then n[n_chunks]

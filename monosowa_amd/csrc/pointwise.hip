@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "groupnorm.hip"
+#include "matched_losses.hip"
 #include <stdint.h>
 
 namespace mono {
@@ -365,6 +366,35 @@ int mono_relu_dropout_bwd_f32(const float *grad_y, const float *y, float *grad_h
   if (!grad_y || !y || !grad_h) return -1;
   if (n <= 0 || (n & 3) || !(p >= 0.f && p < 1.f) || ((uintptr_t)grad_y & 15) || ((uintptr_t)y & 15) || ((uintptr_t)grad_h & 15)) return -2;
   mono::relu_dropout_bwd_kernel<<<mono::grid_for_vec(n / 4), 256, 0, (hipStream_t)stream_>>>(grad_y, y, grad_h, n / 4, 1.f / (1.f - p));
+  return (int)hipGetLastError();
+}
+
+// Matched-pair losses of SetCriterion for all decoder layers (see matched_losses.hip).  Predictions [NL, B, Q, 6|2|3|24]
+// contiguous; idx [3, NL, K] int64 = (image, query, flat target); targets flat over the batch.  out [NL, 6] = per-layer
+// sums {center, bbox, giou, depth, dim, angle}; comp [NL] is saved for the backward.
+int mono_matched_losses_fwd_f32(const float *boxes, const float *depth, const float *dims, const float *angle,
+                                const long long *idx, const float *t_box, const float *t_depth, const float *t_size,
+                                const long long *t_bin, const float *t_res, float *out, float *comp, int NL, int B, int Q,
+                                int K, void *stream_) {
+  if (!boxes || !depth || !dims || !angle || !idx || !t_box || !t_depth || !t_size || !t_bin || !t_res || !out || !comp) return -1;
+  if (NL <= 0 || B <= 0 || Q <= 0 || K <= 0) return -2;
+  const mono::MatchedArgs a{boxes, depth, dims, angle, idx, t_box, t_depth, t_size, t_res, t_bin, NL, B, Q, K};
+  mono::matched_fwd_kernel<<<NL, 256, 0, (hipStream_t)stream_>>>(a, out, comp);
+  return (int)hipGetLastError();
+}
+
+// grad_out [NL, 6]; g_* are the gradients of the four prediction tensors, ZERO on entry (only matched rows are written).
+int mono_matched_losses_bwd_f32(const float *boxes, const float *depth, const float *dims, const float *angle,
+                                const long long *idx, const float *t_box, const float *t_depth, const float *t_size,
+                                const long long *t_bin, const float *t_res, const float *comp, const float *grad_out,
+                                float *g_boxes, float *g_depth, float *g_dims, float *g_angle, int NL, int B, int Q, int K,
+                                void *stream_) {
+  if (!boxes || !depth || !dims || !angle || !idx || !t_box || !t_depth || !t_size || !t_bin || !t_res || !comp || !grad_out ||
+      !g_boxes || !g_depth || !g_dims || !g_angle)
+    return -1;
+  if (NL <= 0 || B <= 0 || Q <= 0 || K <= 0) return -2;
+  const mono::MatchedArgs a{boxes, depth, dims, angle, idx, t_box, t_depth, t_size, t_res, t_bin, NL, B, Q, K};
+  mono::matched_bwd_kernel<<<NL, 256, 0, (hipStream_t)stream_>>>(a, comp, grad_out, g_boxes, g_depth, g_dims, g_angle);
   return (int)hipGetLastError();
 }
 

@@ -20,6 +20,7 @@ from torch import nn
 from . import box_ops
 from .losses import DDNLoss, sigmoid_focal_loss
 from .misc import accuracy, get_world_size, is_dist_avail_and_initialized
+from ..pointwise import matched_losses, matched_losses_supported
 
 
 def _paired_giou(a, b):
@@ -39,6 +40,9 @@ def _dev(values, dtype, device):
     ``torch.as_tensor(list, device=cuda)`` wait for every queued kernel (214 ms behind a 214 ms queue,
     tools/h2d_probe.py), a staged ``.to(device, non_blocking=True)`` of a CPU tensor returns in 70 us."""
     return torch.as_tensor(np.asarray(values)).to(dtype).to(device, non_blocking=True)
+
+
+FUSED_MATCHED = True     # matched-pair losses through the HIP kernels on the GPU (False: the PyTorch formulation below)
 
 
 def weighted_total(loss_dict, weight_dict):
@@ -276,6 +280,13 @@ class SetCriterion(nn.Module):
         card_pred = (logits.argmax(-1) != C - 1).sum(2).float()
         per_layer["cardinality_error"] = (card_pred - tgt_lengths).abs().mean(1)
 
+        if FUSED_MATCHED and matched_losses_supported(boxes, idx):
+            # all six matched-pair losses of all layers: one HIP launch forward, one backward (csrc/matched_losses.hip)
+            sums = matched_losses(boxes, depth, dims, angle, idx, flat["boxes_3d"], flat["depth"], flat["size_3d"],
+                                  flat["heading_bin"], flat["heading_res"]) / num_boxes
+            for j, k in enumerate(("loss_center", "loss_bbox", "loss_giou", "loss_depth", "loss_dim", "loss_angle")):
+                per_layer[k] = sums[:, j]
+            return self._finish(per_layer, NL, dev, loss_depth_map)
         # boxes: 3D-centre L1, l/r/t/b L1, GIoU of matched pairs
         src_box, tgt_box = take(boxes), flat["boxes_3d"][t_idx]
         per_layer["loss_center"] = (src_box[..., 0:2] - tgt_box[..., 0:2]).abs().sum((1, 2)) / num_boxes
@@ -300,6 +311,10 @@ class SetCriterion(nn.Module):
         res_pred = torch.gather(heading[..., 12:24], 2, cls_t.unsqueeze(-1)).squeeze(-1)
         per_layer["loss_angle"] = (cls_loss + (res_pred - res_t).abs()).sum(1) / num_boxes
 
+        return self._finish(per_layer, NL, dev, loss_depth_map)
+
+    @staticmethod
+    def _finish(per_layer, NL, dev, loss_depth_map):
         losses = {}
         zero = lambda: torch.zeros((), device=dev, dtype=torch.float32, requires_grad=True)
         for l in range(NL):

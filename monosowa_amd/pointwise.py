@@ -8,7 +8,7 @@ import torch
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
-           "mono_relu_dropout_bwd_f32")
+           "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32")
 _lib = None
 
 
@@ -42,6 +42,10 @@ def load():
         lib.mono_relu_dropout_fwd_f32.argtypes = [P, P, LL, F, U, P]
         lib.mono_relu_dropout_bwd_f32.restype = I
         lib.mono_relu_dropout_bwd_f32.argtypes = [P, P, P, LL, F, P]
+        lib.mono_matched_losses_fwd_f32.restype = I
+        lib.mono_matched_losses_fwd_f32.argtypes = [P] * 12 + [I] * 4 + [P]
+        lib.mono_matched_losses_bwd_f32.restype = I
+        lib.mono_matched_losses_bwd_f32.argtypes = [P] * 16 + [I] * 4 + [P]
         lib.mono_adamw_step_f32.restype = I
         lib.mono_adamw_step_f32.argtypes = [P, I] + [ctypes.c_double] * 4 + [P]
         lib.mono_colsum_f32.restype = I
@@ -158,6 +162,9 @@ def _next_seed():
     return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter[0] * 0xD1B54A32D192ED03 + rank * 0x94D049BB133111EB) & (2 ** 64 - 1)
 
 
+LN_MIN_ROWS = int(os.environ.get('MONOSOWA_LN_MIN_ROWS', '1'))
+
+
 class _DropoutAddLayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, z, weight, bias, p, eps):
@@ -198,6 +205,10 @@ def dropout_add_layernorm(x, z, norm, dropout):
     """``norm(x + dropout(z))`` for an ``nn.LayerNorm(256)`` and an ``nn.Dropout``: one HIP kernel forward, one
     backward, on float32 GPU tensors; the PyTorch formulation otherwise."""
     p = dropout.p if dropout.training else 0.0
+    # A/B switch (tools/ab_step.py): even for the 8,800-token decoder, where the step is host-bound behind the matcher's
+    # sync and a Python autograd node costs more host time than three ATen ops, the fused kernels win by 0.47 ms/step
+    if x.numel() < LN_MIN_ROWS * 256 and torch.is_grad_enabled():
+        return norm(x + dropout(z))
     if x.is_cuda and x.dtype == torch.float32 and z.dtype == torch.float32 and x.shape == z.shape and x.shape[-1] == 256 \
             and tuple(norm.normalized_shape) == (256,) and norm.elementwise_affine and norm.bias is not None and p < 1.0:
         return _DropoutAddLayerNorm.apply(x, z, norm.weight, norm.bias, p, norm.eps)
@@ -375,3 +386,53 @@ def relu_dropout(h, dropout):
             and h.numel() >= (1 << 22) and torch.is_grad_enabled():
         return _ReluDropout.apply(h, dropout.p)
     return dropout(torch.relu(h))
+
+
+# ---------------------------------------------------------------------------------------------------------
+class _MatchedLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, boxes, depth, dims, angle, idx, t_box, t_depth, t_size, t_bin, t_res):
+        NL, B, Q, _ = boxes.shape
+        K = idx.size(2)
+        out = torch.empty((NL, 6), dtype=torch.float32, device=boxes.device)
+        comp = torch.empty(NL, dtype=torch.float32, device=boxes.device)
+        tensors = (boxes, depth, dims, angle, idx, t_box, t_depth, t_size, t_bin, t_res)
+        with torch.cuda.device(boxes.device):
+            code = load().mono_matched_losses_fwd_f32(*[t.data_ptr() for t in tensors], out.data_ptr(), comp.data_ptr(), NL, B, Q, K,
+                                                      torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_matched_losses_fwd_f32 failed with code %d" % code)
+        ctx.save_for_backward(*tensors, comp)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        *tensors, comp = ctx.saved_tensors
+        boxes, depth, dims, angle = tensors[:4]
+        NL, B, Q, _ = boxes.shape
+        K = tensors[4].size(2)
+        buf = torch.zeros((NL, B, Q, 35), dtype=torch.float32, device=boxes.device)       # one memset for the four gradients
+        flat = buf.view(-1)
+        n = NL * B * Q
+        g_boxes, g_depth = flat[:n * 6].view(NL, B, Q, 6), flat[n * 6:n * 8].view(NL, B, Q, 2)
+        g_dims, g_angle = flat[n * 8:n * 11].view(NL, B, Q, 3), flat[n * 11:].view(NL, B, Q, 24)
+        go = go.contiguous()
+        with torch.cuda.device(boxes.device):
+            code = load().mono_matched_losses_bwd_f32(*[t.data_ptr() for t in tensors], comp.data_ptr(), go.data_ptr(),
+                                                      g_boxes.data_ptr(), g_depth.data_ptr(), g_dims.data_ptr(), g_angle.data_ptr(),
+                                                      NL, B, Q, K, torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_matched_losses_bwd_f32 failed with code %d" % code)
+        return (g_boxes, g_depth, g_dims, g_angle) + (None,) * 6
+
+
+def matched_losses_supported(boxes, idx):
+    return boxes.is_cuda and boxes.dtype == torch.float32 and idx.size(2) > 0
+
+
+def matched_losses(boxes, depth, dims, angle, idx, t_box, t_depth, t_size, t_bin, t_res):
+    """Per-layer sums [NL, 6] of {center, bbox, giou, depth, dim, angle} over the matched pairs ``idx`` [3, NL, K]."""
+    c = lambda t, dt: t.to(dt).contiguous()
+    f = torch.float32
+    return _MatchedLosses.apply(c(boxes, f), c(depth, f), c(dims, f), c(angle, f), c(idx, torch.int64), c(t_box, f),
+                                c(t_depth.reshape(-1), f), c(t_size, f), c(t_bin.reshape(-1), torch.int64), c(t_res.reshape(-1), f))

@@ -684,3 +684,52 @@ def test_conv_group_norm_with_folded_bias_matches_sequential(relu):
     ref = run(lambda: torch.relu(gn(conv(x))) if relu else gn(conv(x)))
     for a, b, n in zip(ours, ref, ("y", "gx", "gw_conv", "gb_conv", "gw_gn", "gb_gn")):
         assert (a - b).abs().max() <= 5e-5 * max(b.abs().max().item(), 1e-3), n
+
+
+def test_fused_matched_losses_equal_the_pytorch_formulation():
+    """mono_matched_losses_*: every loss of the criterion and every gradient with the fused matched-pair kernels against
+    the PyTorch formulation of the same criterion (itself checked against the layer-wise reference formulation on the CPU)."""
+    import yaml
+    from monosowa_amd.helpers.model_helper import build_model
+    from monosowa_amd.monodetr import criterion as C
+    from monosowa_amd.synthetic import make_batch, prepare_targets
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "configs", "monodetr.yaml")))
+    torch.manual_seed(0)
+    _, crit = build_model(dict(cfg["model"], device="cuda"))
+    crit = crit.cuda().train()
+    B, Q = 4, 550
+    _, _, targets, _ = make_batch(B, "cuda", seed=5, resolution=(320, 96))
+    tl = prepare_targets(targets, B)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    mk = lambda *s: torch.randn(*s, device="cuda", generator=g)
+
+    def outputs():
+        layer = lambda: {"pred_logits": mk(B, Q, 3).requires_grad_(True), "pred_boxes": (mk(B, Q, 6) * 0.5).sigmoid().requires_grad_(True),
+                         "pred_3d_dim": (mk(B, Q, 3) * 0.2 + 2).requires_grad_(True), "pred_depth": mk(B, Q, 2).requires_grad_(True),
+                         "pred_angle": mk(B, Q, 24).requires_grad_(True)}
+        o = layer()
+        o["aux_outputs"] = [layer(), layer()]
+        o["pred_depth_map_logits"] = mk(B, 81, 6, 20).requires_grad_(True)
+        return o
+    out = outputs()
+    leaves = [v for d in [out] + out["aux_outputs"] for k, v in d.items() if torch.is_tensor(v)]
+
+    def run(fused):
+        C.FUSED_MATCHED = fused
+        for t in leaves:
+            t.grad = None
+        losses = crit(out, tl)
+        C.weighted_total(losses, crit.weight_dict).backward()
+        return {k: v.detach().clone() for k, v in losses.items()}, [t.grad.clone() if t.grad is not None else None for t in leaves]
+    try:
+        l1, g1 = run(True)
+        l0, g0 = run(False)
+    finally:
+        C.FUSED_MATCHED = True
+    assert set(l1) == set(l0)
+    for k in l0:
+        assert abs(l1[k].item() - l0[k].item()) <= 2e-5 * max(abs(l0[k].item()), 1.0), k
+    for a, b in zip(g1, g0):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert (a - b).abs().max() <= 2e-5 * max(b.abs().max().item(), 1e-6)
