@@ -45,7 +45,7 @@ def build_host_libs(force=False, verbose=False):
     out = os.path.join(LIBDIR, "libmonosowa_lsap.so")
     src = os.path.join(CSRC, "lsap.cpp")
     if force or _stale(out, [src]):
-        cmd = [shutil.which("g++") or "g++", "-O3", "-fPIC", "-shared", "-std=c++17", "-Wall", "-o", out, src]
+        cmd = [shutil.which("g++") or "g++", "-O3", "-fPIC", "-shared", "-std=c++17", "-Wall", "-pthread", "-o", out, src]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -173,6 +175,54 @@ int64_t lsap_match_groups_f32(const float *cost, int64_t NL, int64_t B, int64_t 
     }
   }
   return n_out;
+}
+
+
+// Same assignments as lsap_match_groups_f32, written as the flat index tensor the criterion consumes:
+// out_idx [3, NL, K] = (image, query, target offset by the images before it), K = sum_b G * min(Q / G, sizes[b]) pairs per
+// layer in (image, group) order.  Output positions are known up front, so the (layer, image) problems are independent:
+// they are dealt to n_threads host threads (the call sits on the train step's critical path, right behind its one host
+// sync).  Returns K, or -1 for an infeasible matrix.
+int64_t lsap_match_flat_f32(const float *cost, int64_t NL, int64_t B, int64_t Q, int64_t T, const int64_t *sizes,
+                            int64_t G, int64_t padded, int64_t *out_idx, int64_t n_threads) {
+  const int64_t gq = Q / G;
+  std::vector<int64_t> first(B + 1, 0), toff(B + 1, 0);
+  for (int64_t b = 0; b < B; ++b) {
+    first[b + 1] = first[b] + G * (gq < sizes[b] ? gq : sizes[b]);
+    toff[b + 1] = toff[b] + sizes[b];
+  }
+  const int64_t K = first[B];
+  if (K == 0) return 0;
+  int64_t *ob = out_idx, *oq = out_idx + NL * K, *ot = out_idx + 2 * NL * K;
+  std::atomic<int64_t> next(0);
+  std::atomic<int> failed(0);
+  auto worker = [&]() {
+    Workspace w;
+    std::vector<int64_t> rows(gq > T ? gq : T), cols(gq > T ? gq : T);
+    for (;;) {
+      const int64_t task = next.fetch_add(1);
+      if (task >= NL * B) break;
+      const int64_t l = task / B, b = task % B, n = sizes[b];
+      int64_t pos = l * K + first[b];
+      for (int64_t g = 0; g < G; ++g) {
+        const float *c = cost + ((l * B + b) * Q + g * gq) * T + (padded ? 0 : toff[b]);
+        const int64_t k = solve_strided(c, gq, n, T, 1, rows.data(), cols.data(), w);
+        if (k < 0) { failed.store(1); return; }
+        for (int64_t i = 0; i < k; ++i, ++pos) {
+          ob[pos] = b;
+          oq[pos] = rows[i] + g * gq;
+          ot[pos] = cols[i] + toff[b];
+        }
+      }
+    }
+  };
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > NL * B) n_threads = NL * B;
+  std::vector<std::thread> pool;
+  for (int64_t i = 1; i < n_threads; ++i) pool.emplace_back(worker);
+  worker();
+  for (auto &t : pool) t.join();
+  return failed.load() ? -1 : K;
 }
 
 }  // extern "C"

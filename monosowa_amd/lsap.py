@@ -21,6 +21,8 @@ def _load():
         lib.lsap_solve_f64.argtypes = [P, I, I, P, P]
         lib.lsap_match_groups_f32.restype = I
         lib.lsap_match_groups_f32.argtypes = [P, I, I, I, I, P, I, I, P, P, P]
+        lib.lsap_match_flat_f32.restype = I
+        lib.lsap_match_flat_f32.argtypes = [P, I, I, I, I, P, I, I, P, I]
         assert lib.lsap_abi_version() == 1
         _lib = lib
     return _lib
@@ -64,3 +66,26 @@ def match_groups(cost, sizes, group_num, padded=False):
             pos += c
         out.append(layer)
     return out
+
+
+N_THREADS = max(1, min(4, (os.cpu_count() or 1) // 2))
+
+
+def match_flat(cost, sizes, group_num, padded=False, n_threads=None):
+    """Same assignments as ``match_groups`` as one int64 array [3, NL, K]: (image, query, target index offset by the
+    targets of the images before it), K pairs per layer in (image, group) order -- the index tensor of the criterion's
+    flat losses; solved on ``n_threads`` host threads."""
+    cost = np.ascontiguousarray(cost, dtype=np.float32)
+    NL, B, Q, T = cost.shape
+    sizes = np.ascontiguousarray(sizes, dtype=np.int64)
+    assert sizes.shape == (B,) and Q % group_num == 0
+    assert (int(sizes.max(initial=0)) <= T) if padded else (int(sizes.sum()) == T)
+    gq = Q // group_num
+    K = int(sum(group_num * min(gq, int(n)) for n in sizes))
+    idx = np.empty((3, NL, K), np.int64)
+    got = _load().lsap_match_flat_f32(cost.ctypes.data, NL, B, Q, T, sizes.ctypes.data, group_num, int(padded),
+                                      idx.ctypes.data, N_THREADS if n_threads is None else n_threads)
+    if got < 0:
+        raise ValueError("cost matrix is infeasible")
+    assert got == K
+    return idx

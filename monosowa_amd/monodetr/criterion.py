@@ -247,12 +247,9 @@ class SetCriterion(nn.Module):
             depth2d = torch.zeros((B, 1), device=dev, dtype=logits.dtype)
         loss_depth_map = self.ddn_loss.forward_padded(outputs["pred_depth_map_logits"], boxes2d, depth2d, valid_t)
 
-        matches = self.matcher.match_layers_end(pending)
-        b_idx = np.stack([np.concatenate([np.full(len(s), b, np.int64) for b, (s, _) in enumerate(layer)]) for layer in matches])
-        q_idx = np.stack([np.concatenate([s for s, _ in layer]) for layer in matches])
-        t_idx = np.stack([np.concatenate([t + offs[b] for b, (_, t) in enumerate(layer)]) for layer in matches])
-        K = b_idx.shape[1]
-        idx = torch.as_tensor(np.stack([b_idx, q_idx, t_idx]), dtype=torch.int64).to(dev, non_blocking=True)   # [3,NL,K]
+        idx_host = self.matcher.match_layers_end_flat(pending)                 # [3, NL, K] int64 (host)
+        K = idx_host.shape[2]
+        idx = torch.from_numpy(idx_host).to(dev, non_blocking=True)
         b_idx, q_idx, t_idx = idx[0], idx[1], idx[2]
         l_idx = torch.arange(NL, device=dev).view(NL, 1).expand(NL, K)
         take = lambda t: t[l_idx, b_idx, q_idx]                             # [NL,K,...] matched predictions

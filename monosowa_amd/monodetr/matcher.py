@@ -107,6 +107,23 @@ class HungarianMatcher(nn.Module):
         return (blocks, None), NL, B, Q, sizes, group_num
 
     @torch.no_grad()
+    def match_layers_end_flat(self, handle):
+        """Second half of ``match_layers`` returning the flat int64 index array [3, NL, K] (image, query, flat target)."""
+        from .. import lsap
+        payload, NL, B, Q, sizes, group_num = handle
+        if payload is not None and lsap.available():
+            blocks, done = payload
+            if done is not None:
+                done.synchronize()                                                    # the step's one host sync
+            return lsap.match_flat(blocks.numpy(), np.asarray(sizes, np.int64), group_num, padded=True)
+        matches = self.match_layers_end(handle)
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        b_idx = np.stack([np.concatenate([np.full(len(s), b, np.int64) for b, (s, _) in enumerate(layer)]) for layer in matches])
+        q_idx = np.stack([np.concatenate([s for s, _ in layer]) for layer in matches])
+        t_idx = np.stack([np.concatenate([t + offs[b] for b, (_, t) in enumerate(layer)]) for layer in matches])
+        return np.stack([b_idx, q_idx, t_idx]).astype(np.int64)
+
+    @torch.no_grad()
     def match_layers_end(self, handle):
         from .. import lsap
         payload, NL, B, Q, sizes, group_num = handle
