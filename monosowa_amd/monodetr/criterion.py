@@ -45,10 +45,36 @@ def _dev(values, dtype, device):
 FUSED_MATCHED = True     # matched-pair losses through the HIP kernels on the GPU (False: the PyTorch formulation below)
 
 
+class LossDict(dict):
+    """The criterion's loss dictionary (same keys as the reference) that also remembers the [n_keys, n_layers] matrix its
+    per-layer entries are views of, so that ``weighted_total`` is one multiply-and-sum instead of ~60 scalar kernels."""
+    mat = None          # [n_keys, NL] tensor; entry (i, l) is self[keys[i] + suffix(l)]
+    keys_ = ()
+    extras = ()         # names of the remaining differentiable scalars (loss_depth_map)
+
+
+_WEIGHT_CACHE = {}
+
+
 def weighted_total(loss_dict, weight_dict):
-    """``sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict)`` (trainer_helper.py:140-141) as one
-    stack and one dot product: two launches forward and two backward instead of ~60 + ~60 scalar kernels, which sit
-    right behind the matcher's host sync where the GPU queue is empty."""
+    """``sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict)`` (trainer_helper.py:140-141).
+    For the criterion's own LossDict: one [n_keys, n_layers] multiply-and-sum plus the depth-map term; the ~60 scalar
+    multiplies and adds of the literal expression (and their ~60 backward kernels) sit right behind the matcher's host
+    sync, where the GPU queue is empty and every launch is exposed."""
+    mat = getattr(loss_dict, "mat", None)
+    if mat is not None:
+        NL = mat.shape[1]
+        suffix = lambda l: "" if l == 0 else "_%d" % (l - 1)
+        w_host = [[float(weight_dict.get(k + suffix(l), 0.0)) for l in range(NL)] for k in loss_dict.keys_]
+        key = (loss_dict.keys_, NL, str(mat.device), tuple(map(tuple, w_host)))
+        w = _WEIGHT_CACHE.get(key)
+        if w is None:
+            w = _WEIGHT_CACHE[key] = torch.tensor(w_host, dtype=mat.dtype).to(mat.device)
+        total = (mat * w).sum()
+        for k in loss_dict.extras:
+            if k in weight_dict:
+                total = total + loss_dict[k] * float(weight_dict[k])
+        return total
     keys = [k for k in loss_dict if k in weight_dict]
     if not keys:
         return 0
@@ -312,16 +338,19 @@ class SetCriterion(nn.Module):
 
     @staticmethod
     def _finish(per_layer, NL, dev, loss_depth_map):
-        losses = {}
-        zero = lambda: torch.zeros((), device=dev, dtype=torch.float32, requires_grad=True)
+        losses = LossDict()
+        keys = tuple(per_layer)
+        mat = torch.stack([per_layer[k] for k in keys])                      # [n_keys, NL]
+        zero = torch.zeros((), device=dev, dtype=torch.float32, requires_grad=True)    # loss_tfl / loss_mask: disabled losses
+        rows = mat.unbind(0)
         for l in range(NL):
             suffix = "" if l == 0 else "_%d" % (l - 1)
-            for k, v in per_layer.items():
-                losses[k + suffix] = v[l]
-            losses["loss_tfl" + suffix] = zero()
-            losses["loss_mask" + suffix] = zero()
-
+            for i, k in enumerate(keys):
+                losses[k + suffix] = rows[i][l]
+            losses["loss_tfl" + suffix] = zero
+            losses["loss_mask" + suffix] = zero
         losses["loss_depth_map"] = loss_depth_map
+        losses.mat, losses.keys_, losses.extras = mat, keys, ("loss_depth_map",)
         return losses
 
     # ------------------------------------------------------------------ reference formulation

@@ -267,7 +267,10 @@ def test_fast_criterion_equals_layerwise_formulation():
                                 cfg=cfg, depth_map_size=(20, 6), fast=fast).train(training)
             out = outputs(Q, 3)
             ld = crit(out, tl)
-            total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+            literal = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+            from monosowa_amd.monodetr.criterion import weighted_total
+            total = weighted_total(ld, crit.weight_dict)          # LossDict fast path for fast=True, stack + dot otherwise
+            assert torch.allclose(total, literal, rtol=1e-5), (total, literal)
             total.backward()
             res[fast] = (ld, out)
         slow, fastd = res[False][0], res[True][0]
@@ -311,6 +314,17 @@ def test_native_lsap_equals_scipy_including_ties():
         assert np.array_equal(a, x) and np.array_equal(b, y)
     with pytest.raises(ValueError):
         lsap.linear_sum_assignment(np.full((2, 2), np.nan))
+    # the flat, threaded entry point returns the same assignments as the per-image lists
+    NL, B, Q, G = 3, 5, 44, 11
+    sizes = np.array([3, 0, 7, 1, 6])
+    cost = rng.standard_normal((NL, B, Q, 7)).astype(np.float32)
+    lists = lsap.match_groups(cost, sizes, G, padded=True)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    want = np.stack([np.stack([np.concatenate([np.full(len(s_), b) for b, (s_, _) in enumerate(layer)]) for layer in lists]),
+                     np.stack([np.concatenate([s_ for s_, _ in layer]) for layer in lists]),
+                     np.stack([np.concatenate([t_ + offs[b] for b, (_, t_) in enumerate(layer)]) for layer in lists])])
+    for threads in (1, 3):
+        assert np.array_equal(lsap.match_flat(cost, sizes, G, padded=True, n_threads=threads), want)
 
 
 def test_vectorised_decode_equals_loop_form():
