@@ -24,6 +24,9 @@ from ..pointwise import dropout_add_layernorm, relu_dropout
 from ..token_linear import token_linear
 
 
+SELF_ATTN_HIP = True      # decoder self-attention (50 queries per group) through the HIP attention core (-0.27 ms/step, tools/ab_step.py)
+
+
 class MLP(nn.Module):
     """Linear-ReLU stack, ReLU on all but the last layer."""
 
@@ -153,10 +156,14 @@ class DepthAwareDecoderLayer(nn.Module):
                 raise NotImplementedError("denoising (extra noise queries) is off in every shipped config; "
                                           "expected %d x %d queries, got %d" % (G, n, Lq))
             fold = lambda t: t.reshape(B * G, n, C).transpose(0, 1)
-            out = self.self_attn(fold(q), fold(k), fold(v), need_weights=False)[0]
-            return out.transpose(0, 1).reshape(B, Lq, C)
-        out = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), need_weights=False)[0]
-        return out.transpose(0, 1)
+            return self._mha(self.self_attn, fold(q), fold(k), fold(v)).transpose(0, 1).reshape(B, Lq, C)
+        return self._mha(self.self_attn, q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1)).transpose(0, 1)
+
+    @staticmethod
+    def _mha(mha, q, k, v):
+        if SELF_ATTN_HIP and mha_supported(mha, q, k, v):
+            return mha_forward(mha, q, k, v)
+        return mha(q, k, v, need_weights=False)[0]
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                 src_padding_mask, depth_pos_embed, mask_depth):

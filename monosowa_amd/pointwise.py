@@ -379,11 +379,14 @@ class _ReluDropout(torch.autograd.Function):
         return gh, None
 
 
+RELU_DROPOUT_MIN_NUMEL = 1 << 22
+
+
 def relu_dropout(h, dropout):
     """``dropout(relu(h))`` for an ``nn.Dropout``: one HIP pass forward and one backward on large float32 GPU tensors in
     training (PyTorch: ReLU, dropout + mask, masked-scale, threshold-backward passes); PyTorch ops otherwise."""
     if h.is_cuda and h.dtype == torch.float32 and dropout.training and 0.0 < dropout.p < 1.0 and h.numel() % 4 == 0 \
-            and h.numel() >= (1 << 22) and torch.is_grad_enabled():
+            and h.numel() >= RELU_DROPOUT_MIN_NUMEL and torch.is_grad_enabled():
         return _ReluDropout.apply(h, dropout.p)
     return dropout(torch.relu(h))
 

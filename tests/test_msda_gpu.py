@@ -538,7 +538,7 @@ def test_attention_dropout_uses_one_mask_forward_and_backward():
         assert (a.double() - b).abs().max() <= 1e-5 * b.abs().max(), name
 
 
-@pytest.mark.parametrize("same_qk", [True, False])
+@pytest.mark.parametrize("same_qk", [True, False, None])
 def test_mha_forward_equals_nn_multiheadattention(same_qk):
     """mha_forward (packed projections + HIP core) against nn.MultiheadAttention in eval mode: output and all
     parameter / input gradients, for the depth-encoder (q is k) and decoder (k is v) call patterns."""
@@ -547,17 +547,23 @@ def test_mha_forward_equals_nn_multiheadattention(same_qk):
     mha = torch.nn.MultiheadAttention(256, 8, dropout=0.1).cuda().eval()
     x = torch.randn(96, 2, 256, device="cuda", requires_grad=True)
     y = torch.randn(40, 2, 256, device="cuda", requires_grad=True)
-    args = (x, x, (x.detach() * 0.5).clone().requires_grad_(True)) if same_qk else (y, x, x)
+    if same_qk is None:            # decoder self-attention: three different tensors, folded groups (non-contiguous views)
+        z = torch.randn(2, 96, 256, device="cuda", requires_grad=True)
+        args = (z.transpose(0, 1), (x * 1.5), (x.detach() * 0.5).clone().requires_grad_(True))
+        args = (args[0], args[1].detach().requires_grad_(True), args[2])
+    else:
+        args = (x, x, (x.detach() * 0.5).clone().requires_grad_(True)) if same_qk else (y, x, x)
     assert mha_supported(mha, *args)
     go = torch.randn(args[0].shape, device="cuda")
 
     def run(fn):
         for t in set(args):
-            t.grad = None
+            (t if t.is_leaf else t._base).grad = None
         mha.zero_grad()
         out = fn()
         out.backward(go)
-        return [out.detach().clone()] + [t.grad.clone() for t in args if t.grad is not None] + [p_.grad.clone() for p_ in mha.parameters()]
+        leaves = [t if t.is_leaf else t._base for t in args]
+        return [out.detach().clone()] + [t.grad.clone() for t in leaves if t.grad is not None] + [p_.grad.clone() for p_ in mha.parameters()]
     ours = run(lambda: mha_forward(mha, *args))
     ref = run(lambda: mha(*args, need_weights=False)[0])
     assert len(ours) == len(ref)

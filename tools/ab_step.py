@@ -3,6 +3,7 @@
 (+-2 %) cancels; differences of 0.3 % become visible.
 
     python tools/ab_step.py monosowa_amd.pointwise.LN_MIN_ROWS 1 16384 [--steps 60]
+    python tools/ab_step.py option:scatter_sorted 0 2          (msda_set_option switches)
 """
 import importlib
 import os
@@ -26,10 +27,18 @@ from monosowa_amd.synthetic import make_batch, prepare_targets    # noqa: E402
 def main():
     path, a, b = sys.argv[1], sys.argv[2], sys.argv[3]
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 60
-    mod_name, attr = path.rsplit(".", 1)
-    mod = importlib.import_module(mod_name)
-    cast = type(getattr(mod, attr))
-    values = [cast(a) if cast is not bool else a == "1", cast(b) if cast is not bool else b == "1"]
+    if path.startswith("option:"):            # a kernel-generation switch of the MSDA library: option:scatter_sorted 0 2
+        from monosowa_amd import _lib
+
+        class _Opt:
+            pass
+        mod, attr, values = _Opt(), path.split(":", 1)[1], [int(a), int(b)]
+        _Opt.__setattr__ = lambda self, k, v: _lib.set_option(k, v)
+    else:
+        mod_name, attr = path.rsplit(".", 1)
+        mod = importlib.import_module(mod_name)
+        cast = type(getattr(mod, attr))
+        values = [cast(a) if cast is not bool else a == "1", cast(b) if cast is not bool else b == "1"]
     dev = torch.device("cuda:0")
     cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "configs", "monodetr.yaml")))
     model, crit = build_model(cfg["model"])
