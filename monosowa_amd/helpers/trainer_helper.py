@@ -15,6 +15,7 @@ import tqdm
 
 from ..monodetr import misc
 from ..monodetr.criterion import weighted_total
+from ..synthetic import attach_host_mask
 from ..synthetic import prepare_targets as _prepare_targets
 from .save_helper import get_checkpoint_state, load_checkpoint, save_checkpoint, unwrap
 
@@ -134,7 +135,10 @@ class Trainer(object):
             if inputs.is_cuda:
                 inputs = inputs.contiguous(memory_format=torch.channels_last)
             calibs = calibs.to(self.device, non_blocking=True)
+            host_mask = targets["mask_2d"].numpy() if not targets["mask_2d"].is_cuda else None
             targets = {k: v.to(self.device, non_blocking=True) for k, v in targets.items()}
+            if host_mask is not None:
+                attach_host_mask(targets["mask_2d"], host_mask)      # prepare_targets then needs no device sync
             total, loss_dict = self.train_step(inputs, calibs, targets, info)
             if batch_idx % self.log_interval == 0:
                 self._log(batch_idx, loss_dict)

@@ -91,8 +91,19 @@ def make_batch(batch_size, device, seed=444, resolution=(1280, 384)):
     inputs = torch.from_numpy(np.stack([s[0] for s in samples])).to(device)
     calibs = torch.from_numpy(np.stack([s[1] for s in samples])).to(device)
     targets = {k: torch.from_numpy(np.stack([s[2][k] for s in samples])).to(device) for k in samples[0][2]}
+    attach_host_mask(targets["mask_2d"], np.stack([s[2]["mask_2d"] for s in samples]))
     info = {k: np.stack([np.asarray(s[3][k]) for s in samples]) for k in samples[0][3]}
     return inputs, calibs, targets, info
+
+
+USE_HOST_MASK = True
+
+
+def attach_host_mask(mask_device, mask_host):
+    """The loader knows the object mask on the host before it ships the batch; keeping that copy next to the device
+    tensor lets ``prepare_targets`` build its gather indices without a device->host sync."""
+    mask_device._host_mask = np.asarray(mask_host).astype(bool)
+    return mask_device
 
 
 def prepare_targets(targets, batch_size):
@@ -100,8 +111,16 @@ def prepare_targets(targets, batch_size):
     The reference indexes every key of every image with a boolean mask (8 x B device->host syncs); here the
     mask is resolved once and each key is gathered once for the whole batch, then split into views."""
     keys = ("labels", "boxes", "calibs", "depth", "size_3d", "heading_bin", "heading_res", "boxes_3d")
-    mask = targets["mask_2d"][:batch_size]
-    b_idx, s_idx = mask.nonzero(as_tuple=True)                     # one sync; row-major = per image, slot order
-    counts = torch.bincount(b_idx, minlength=batch_size).tolist() if b_idx.numel() else [0] * batch_size
+    host = getattr(targets["mask_2d"], "_host_mask", None)
+    if host is not None and USE_HOST_MASK:
+        hb, hs = np.nonzero(host[:batch_size])                     # row-major = per image, slot order; no device sync
+        counts = np.bincount(hb, minlength=batch_size).tolist()
+        dev = targets["mask_2d"].device
+        b_idx = torch.from_numpy(hb).to(dev, non_blocking=True)
+        s_idx = torch.from_numpy(hs).to(dev, non_blocking=True)
+    else:
+        mask = targets["mask_2d"][:batch_size]
+        b_idx, s_idx = mask.nonzero(as_tuple=True)                 # one sync
+        counts = torch.bincount(b_idx, minlength=batch_size).tolist() if b_idx.numel() else [0] * batch_size
     per_key = {k: v[b_idx, s_idx].split(counts) for k, v in targets.items() if k in keys}
     return [{k: per_key[k][b] for k in per_key} for b in range(batch_size)]

@@ -58,15 +58,17 @@ def main():
         setattr(mod, attr, v)
         step()
     torch.cuda.synchronize()
+    block = int(sys.argv[sys.argv.index("--block") + 1]) if "--block" in sys.argv else 1
     times = {0: [], 1: []}
-    for i in range(steps):
+    for i in range(steps // block):
         k = i & 1
         setattr(mod, attr, values[k])
         torch.cuda.synchronize()
         t = time.perf_counter()
-        step()
+        for _ in range(block):           # block > 1: no sync between steps, as in bench.py (cross-step overlap counts)
+            step()
         torch.cuda.synchronize()
-        times[k].append((time.perf_counter() - t) * 1e3)
+        times[k].append((time.perf_counter() - t) * 1e3 / block)
     for k in (0, 1):
         ts = sorted(times[k])
         print("%s = %-8r median %.3f ms  mean %.3f  min %.3f  (n=%d)" % (attr, values[k], statistics.median(ts), statistics.mean(ts), ts[0], len(ts)), flush=True)
