@@ -203,6 +203,7 @@ class DepthAwareDecoder(nn.Module):
                 query_pos=None, src_padding_mask=None, depth_pos_embed=None, mask_depth=None):
         output = tgt
         inter, inter_refs, inter_dims = [], [], []
+        self.bbox_raw = []          # bbox_embed[lid](output) of every layer: MonoDETR.forward needs exactly these again
         for lid, layer in enumerate(self.layers):
             if reference_points.shape[-1] == 6:
                 ratios = torch.cat([src_valid_ratios, src_valid_ratios, src_valid_ratios], -1)
@@ -214,6 +215,7 @@ class DepthAwareDecoder(nn.Module):
                            src_level_start_index, src_padding_mask, depth_pos_embed, mask_depth)
             if self.bbox_embed is not None:   # iterative refinement, detached between layers (:602-613)
                 tmp = self.bbox_embed[lid](output)
+                self.bbox_raw.append(tmp)
                 if reference_points.shape[-1] == 6:
                     new_ref = tmp + inverse_sigmoid(reference_points)
                 else:

@@ -24,6 +24,9 @@ def _clones(module, n):
     return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
 
 
+REUSE_BBOX_RAW = True
+
+
 class MonoDETR(nn.Module):
     def __init__(self, backbone, depthaware_transformer, depth_predictor, num_classes, num_queries,
                  num_feature_levels, aux_loss=True, with_box_refine=False, two_stage=False, init_box=False,
@@ -149,7 +152,11 @@ class MonoDETR(nn.Module):
         img_h = img_sizes[:, 1:2]
         for lvl in range(hs.shape[0]):
             reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
-            tmp = self.bbox_embed[lvl](hs[lvl])
+            # the decoder evaluated bbox_embed[lvl] on the same hs[lvl] for its reference refinement (whose result it
+            # detaches); the reference evaluates it a second time here (monodetr.py:222) -- same values, so reuse the
+            # tensor (its graph carries the gradient the recomputation would have produced)
+            raw = getattr(self.depthaware_transformer.decoder, "bbox_raw", None)
+            tmp = raw[lvl] if raw and len(raw) == hs.shape[0] and REUSE_BBOX_RAW else self.bbox_embed[lvl](hs[lvl])
             if reference.shape[-1] == 6:
                 tmp = tmp + reference
             else:
