@@ -379,3 +379,37 @@ def test_all_valid_shortcut_equals_masked_path(monkeypatch):
         b = t(srcs, masks, pos, qe, dpe, dpe, all_valid=True)
     for x, y in zip(a[:4], b[:4]):
         assert torch.allclose(x, y, rtol=1e-5, atol=1e-6)
+
+
+def test_block_cost_pass_is_bitwise_the_gathered_cross_matrix():
+    """HungarianMatcher.cost_blocks (per-image blocks only) must produce exactly the floats of the reference's full
+    cross matrix at those positions: the assignments are index bookkeeping."""
+    from monosowa_amd.monodetr import matcher as M
+    cfg = _cfg()["model"]
+    m = M.build_matcher(cfg)
+    g = torch.Generator().manual_seed(4)
+    NL, B, Q = 3, 4, 44
+    logits = torch.randn(NL, B, Q, 3, generator=g)
+    boxes = torch.rand(NL, B, Q, 6, generator=g) * 0.4 + 0.1
+    sizes = [3, 0, 5, 2]
+    T = sum(sizes)
+    flat = {"labels": torch.randint(0, 3, (T,), generator=g), "boxes_3d": torch.rand(T, 6, generator=g) * 0.4 + 0.1}
+    res = {}
+    for flag in (False, True):
+        M.BLOCK_COST = flag
+        try:
+            (blocks, _), *_ = m.match_layers_begin(logits, boxes, flat, sizes, 11)
+        finally:
+            M.BLOCK_COST = True
+        res[flag] = blocks.clone()
+    for b, n in enumerate(sizes):                                   # padding columns are never read by the solver
+        assert torch.equal(res[True][:, b, :, :n], res[False][:, b, :, :n])
+    a = m.match_layers(logits, boxes, flat, sizes, 11)
+    M.BLOCK_COST = False
+    try:
+        ref = m.match_layers(logits, boxes, flat, sizes, 11)
+    finally:
+        M.BLOCK_COST = True
+    for la, lr in zip(a, ref):
+        for (s1, t1), (s2, t2) in zip(la, lr):
+            assert np.array_equal(s1, s2) and np.array_equal(t1, t2)

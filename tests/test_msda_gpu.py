@@ -739,3 +739,25 @@ def test_fused_matched_losses_equal_the_pytorch_formulation():
         assert (a is None) == (b is None)
         if a is not None:
             assert (a - b).abs().max() <= 2e-5 * max(b.abs().max().item(), 1e-6)
+
+
+def test_block_cost_pass_is_bitwise_on_the_gpu_too():
+    from monosowa_amd.monodetr import matcher as M
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "configs", "monodetr.yaml")))["model"]
+    m = M.build_matcher(cfg)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    NL, B, Q = 3, 16, 550
+    logits = torch.randn(NL, B, Q, 3, device="cuda", generator=g)
+    boxes = torch.rand(NL, B, Q, 6, device="cuda", generator=g) * 0.4 + 0.1
+    sizes = [int(x) for x in torch.randint(0, 12, (B,)).tolist()]
+    T = sum(sizes)
+    flat = {"labels": torch.randint(0, 3, (T,), device="cuda", generator=g), "boxes_3d": torch.rand(T, 6, device="cuda", generator=g) * 0.4 + 0.1}
+    out = {}
+    for flag in (False, True):
+        M.BLOCK_COST = flag
+        try:
+            out[flag] = m.match_layers_end_flat(m.match_layers_begin(logits, boxes, flat, sizes, 11))
+        finally:
+            M.BLOCK_COST = True
+    assert np.array_equal(out[True], out[False])
