@@ -17,6 +17,13 @@ int mono_bias_act_f32(float *y, const float *bias, const float *residual, long l
 /* grad_in[i] = y[i] > 0 ? grad_out[i] : 0   (n % 4 == 0; grad_in may alias grad_out). */
 int mono_relu_grad_f32(const float *grad_out, const float *y, float *grad_in, long long n, void *stream);
 
+/* ReLU with a byte mask: y = relu(y + bias (+ residual)) in place and mask[i] = sign bits of elements 4i..4i+3 (one byte
+ * per float4); the backward below reads the mask instead of y (1/16 of the bytes).  grad_b may be NULL. */
+int mono_bias_relu_mask_f32(float *y, const float *bias, const float *residual, unsigned char *mask, long long rows, int C,
+                            void *stream);
+int mono_relu_grad_mask_f32(const float *grad_a, const float *grad_b, const unsigned char *mask, float *grad_in, long long n,
+                            void *stream);
+
 /* grad_in = (grad_a + grad_b) * (y > 0): ReLU backward of a tensor with two consumers (ResNet block output -> next
  * convolution and identity branch, backbone.py:64-82 of the reference's torchvision ResNet) in one pass. */
 int mono_relu_grad2_f32(const float *grad_a, const float *grad_b, const float *y, float *grad_in, long long n, void *stream);

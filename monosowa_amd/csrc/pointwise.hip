@@ -29,6 +29,42 @@ __global__ __launch_bounds__(256) void bias_act_kernel(float *__restrict__ y, co
   }
 }
 
+// ReLU variants with a BYTE MASK per float4 (bit k = element k positive): the forward writes 1 B per 16 B of output, the
+// backward reads that instead of y (4 B per element from HBM: y was written long before its backward runs).
+template <bool RES>
+__global__ __launch_bounds__(256) void bias_relu_mask_kernel(float *__restrict__ y, const float *__restrict__ bias,
+                                                             const float *__restrict__ residual, unsigned char *__restrict__ mask,
+                                                             long long n_vec, int c_vec) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    float4 v = reinterpret_cast<float4 *>(y)[i];
+    const float4 b = reinterpret_cast<const float4 *>(bias)[i % c_vec];
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    if (RES) {
+      const float4 r = reinterpret_cast<const float4 *>(residual)[i];
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    mask[i] = (unsigned char)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    reinterpret_cast<float4 *>(y)[i] = v;
+  }
+}
+template <bool TWO>
+__global__ __launch_bounds__(256) void relu_grad_mask_kernel(const float *__restrict__ ga, const float *__restrict__ gb,
+                                                             const unsigned char *__restrict__ mask, float *__restrict__ grad_in,
+                                                             long long n_vec) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    float4 a = reinterpret_cast<const float4 *>(ga)[i];
+    if (TWO) {
+      const float4 b = reinterpret_cast<const float4 *>(gb)[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const unsigned m = mask[i];
+    reinterpret_cast<float4 *>(grad_in)[i] = make_float4((m & 1u) ? a.x : 0.f, (m & 2u) ? a.y : 0.f, (m & 4u) ? a.z : 0.f, (m & 8u) ? a.w : 0.f);
+  }
+}
+
 // grad_in = grad_out * (y > 0), optionally also written to a second buffer (the residual branch's gradient)
 __global__ __launch_bounds__(256) void relu_grad_kernel(const float *__restrict__ grad_out, const float *__restrict__ y,
                                                         float *__restrict__ grad_in, long long n_vec) {
@@ -302,6 +338,29 @@ int mono_bias_act_f32(float *y, const float *bias, const float *residual, long l
   else if (relu) mono::bias_act_kernel<true, false><<<g, 256, 0, stream>>>(y, bias, nullptr, n_vec, C / 4);
   else if (residual) mono::bias_act_kernel<false, true><<<g, 256, 0, stream>>>(y, bias, residual, n_vec, C / 4);
   else mono::bias_act_kernel<false, false><<<g, 256, 0, stream>>>(y, bias, nullptr, n_vec, C / 4);
+  return (int)hipGetLastError();
+}
+
+// y = relu(y + bias (+ residual)) in place, and mask[i] (one byte per 4 consecutive elements) = their sign bits.
+int mono_bias_relu_mask_f32(float *y, const float *bias, const float *residual, unsigned char *mask, long long rows, int C,
+                            void *stream_) {
+  if (!y || !bias || !mask) return -1;
+  if (rows <= 0 || C <= 0 || (C & 3) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)residual & 15)) return -2;
+  const long long n_vec = rows * C / 4;
+  const int g = mono::grid_for_vec(n_vec);
+  if (residual) mono::bias_relu_mask_kernel<true><<<g, 256, 0, (hipStream_t)stream_>>>(y, bias, residual, mask, n_vec, C / 4);
+  else mono::bias_relu_mask_kernel<false><<<g, 256, 0, (hipStream_t)stream_>>>(y, bias, nullptr, mask, n_vec, C / 4);
+  return (int)hipGetLastError();
+}
+
+// grad_in = (grad_a (+ grad_b)) where the mask bit is set, else 0; grad_b may be NULL.  n % 4 == 0.
+int mono_relu_grad_mask_f32(const float *grad_a, const float *grad_b, const unsigned char *mask, float *grad_in, long long n,
+                            void *stream_) {
+  if (!grad_a || !mask || !grad_in) return -1;
+  if (n <= 0 || (n & 3) || ((uintptr_t)grad_a & 15) || ((uintptr_t)grad_b & 15) || ((uintptr_t)grad_in & 15)) return -2;
+  const int g = mono::grid_for_vec(n / 4);
+  if (grad_b) mono::relu_grad_mask_kernel<true><<<g, 256, 0, (hipStream_t)stream_>>>(grad_a, grad_b, mask, grad_in, n / 4);
+  else mono::relu_grad_mask_kernel<false><<<g, 256, 0, (hipStream_t)stream_>>>(grad_a, nullptr, mask, grad_in, n / 4);
   return (int)hipGetLastError();
 }
 

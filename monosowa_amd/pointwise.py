@@ -6,7 +6,7 @@ import os
 import torch
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
-SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_dropout_add_layernorm_fwd_f32",
+SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32")
 _lib = None
@@ -23,6 +23,10 @@ def load():
         lib.mono_bias_act_f32.argtypes = [P, P, P, LL, I, I, P]
         lib.mono_relu_grad_f32.restype = I
         lib.mono_relu_grad_f32.argtypes = [P, P, P, LL, P]
+        lib.mono_bias_relu_mask_f32.restype = I
+        lib.mono_bias_relu_mask_f32.argtypes = [P, P, P, P, LL, I, P]
+        lib.mono_relu_grad_mask_f32.restype = I
+        lib.mono_relu_grad_mask_f32.argtypes = [P, P, P, P, LL, P]
         lib.mono_relu_grad2_f32.restype = I
         lib.mono_relu_grad2_f32.argtypes = [P, P, P, P, LL, P]
         U, F = ctypes.c_ulonglong, ctypes.c_float
@@ -59,32 +63,46 @@ def _nhwc_ok(t):
         and t.is_contiguous(memory_format=torch.channels_last) and t.data_ptr() % 16 == 0
 
 
+USE_RELU_MASK = True      # ReLU backward from a byte mask instead of re-reading the activation (tools/ab_step.py switch)
+
+
 class _BiasAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, bias, residual, relu):
         rows = y.numel() // y.size(1)
+        res_ptr = residual.data_ptr() if residual is not None else None
+        mask = None
         with torch.cuda.device(y.device):
-            code = load().mono_bias_act_f32(y.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
-                                            rows, y.size(1), int(relu), torch.cuda.current_stream().cuda_stream)
+            st = torch.cuda.current_stream().cuda_stream
+            if relu and USE_RELU_MASK and (y.requires_grad or (residual is not None and residual.requires_grad)):
+                mask = torch.empty(y.numel() // 4, dtype=torch.uint8, device=y.device)
+                code = load().mono_bias_relu_mask_f32(y.data_ptr(), bias.data_ptr(), res_ptr, mask.data_ptr(), rows, y.size(1), st)
+            else:
+                code = load().mono_bias_act_f32(y.data_ptr(), bias.data_ptr(), res_ptr, rows, y.size(1), int(relu), st)
         if code:
             raise RuntimeError("mono_bias_act_f32 failed with code %d" % code)
         ctx.mark_dirty(y)
         ctx.relu = relu
         ctx.has_res = residual is not None
         ctx.bias_grad = bias.requires_grad
+        ctx.masked = mask is not None
         if relu:
-            ctx.save_for_backward(y)
+            ctx.save_for_backward(mask if mask is not None else y)
         return y
 
     @staticmethod
     def backward(ctx, grad):
         if ctx.relu:
-            (y,) = ctx.saved_tensors
+            (y,) = ctx.saved_tensors                   # the byte mask when ctx.masked
             grad = grad.contiguous(memory_format=torch.channels_last)
             g = torch.empty_like(grad, memory_format=torch.channels_last)
             with torch.cuda.device(y.device):
-                code = load().mono_relu_grad_f32(grad.data_ptr(), y.data_ptr(), g.data_ptr(), grad.numel(),
-                                                 torch.cuda.current_stream().cuda_stream)
+                if ctx.masked:
+                    code = load().mono_relu_grad_mask_f32(grad.data_ptr(), None, y.data_ptr(), g.data_ptr(), grad.numel(),
+                                                          torch.cuda.current_stream().cuda_stream)
+                else:
+                    code = load().mono_relu_grad_f32(grad.data_ptr(), y.data_ptr(), g.data_ptr(), grad.numel(),
+                                                     torch.cuda.current_stream().cuda_stream)
             if code:
                 raise RuntimeError("mono_relu_grad_f32 failed with code %d" % code)
         else:
@@ -100,30 +118,43 @@ class _BiasActFork(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, bias, residual):
         rows = y.numel() // y.size(1)
+        mask = torch.empty(y.numel() // 4, dtype=torch.uint8, device=y.device) if USE_RELU_MASK else None
         with torch.cuda.device(y.device):
-            code = load().mono_bias_act_f32(y.data_ptr(), bias.data_ptr(), residual.data_ptr(), rows, y.size(1), 1,
-                                            torch.cuda.current_stream().cuda_stream)
+            st = torch.cuda.current_stream().cuda_stream
+            if mask is not None:
+                code = load().mono_bias_relu_mask_f32(y.data_ptr(), bias.data_ptr(), residual.data_ptr(), mask.data_ptr(), rows, y.size(1), st)
+            else:
+                code = load().mono_bias_act_f32(y.data_ptr(), bias.data_ptr(), residual.data_ptr(), rows, y.size(1), 1, st)
         if code:
             raise RuntimeError("mono_bias_act_f32 failed with code %d" % code)
         ctx.mark_dirty(y)
-        ctx.save_for_backward(y)
+        ctx.save_for_backward(mask if mask is not None else y)
+        ctx.masked = mask is not None
+        ctx.shape = y.shape
         ctx.bias_grad = bias.requires_grad
         return y, y.detach()
 
     @staticmethod
     def backward(ctx, ga, gb):
-        (y,) = ctx.saved_tensors
+        (y,) = ctx.saved_tensors                       # the byte mask when ctx.masked
         cl = lambda t: t.contiguous(memory_format=torch.channels_last)
         lib = load()
-        g = torch.empty_like(y, memory_format=torch.channels_last)
+        g = torch.empty(ctx.shape, dtype=torch.float32, device=y.device, memory_format=torch.channels_last)
+        n = g.numel()
         with torch.cuda.device(y.device):
             st = torch.cuda.current_stream().cuda_stream
             if ga is not None and gb is not None:
                 ga, gb = cl(ga), cl(gb)
-                code = lib.mono_relu_grad2_f32(ga.data_ptr(), gb.data_ptr(), y.data_ptr(), g.data_ptr(), y.numel(), st)
+                if ctx.masked:
+                    code = lib.mono_relu_grad_mask_f32(ga.data_ptr(), gb.data_ptr(), y.data_ptr(), g.data_ptr(), n, st)
+                else:
+                    code = lib.mono_relu_grad2_f32(ga.data_ptr(), gb.data_ptr(), y.data_ptr(), g.data_ptr(), n, st)
             else:
                 one = cl(ga if ga is not None else gb)
-                code = lib.mono_relu_grad_f32(one.data_ptr(), y.data_ptr(), g.data_ptr(), y.numel(), st)
+                if ctx.masked:
+                    code = lib.mono_relu_grad_mask_f32(one.data_ptr(), None, y.data_ptr(), g.data_ptr(), n, st)
+                else:
+                    code = lib.mono_relu_grad_f32(one.data_ptr(), y.data_ptr(), g.data_ptr(), n, st)
         if code:
             raise RuntimeError("mono_relu_grad(2)_f32 failed with code %d" % code)
         return g, (g.sum((0, 2, 3)) if ctx.bias_grad else None), g
