@@ -1,0 +1,107 @@
+"""The two halves of a visual-encoder layer as single autograd nodes (depthaware_transformer.py:339-354 of the reference:
+deformable self-attention + post-norm residual, FFN + post-norm residual).
+
+Same kernels and GEMMs as the module-by-module path; what changes is the backward's bookkeeping.  Inside one node the
+gradient of a tensor with several consumers (``src`` feeds the residual, ``value_proj`` and -- through ``src + pos`` --
+the offset / attention-weight projections; ``src1`` feeds the residual and ``linear1``) is built by GEMMs that accumulate
+into the LayerNorm backward's output (``addmm_``, beta = 1) instead of separate gradients that autograd then adds with
+[B*S, 256] elementwise passes: 3 of the 4 accumulation passes per layer (75 us each at 163k tokens) disappear, and so do
+eight autograd nodes per layer.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import MultiScaleDeformableAttention as MSDA
+from .pointwise import colsum, ln_backward, ln_forward, relu_dropout_backward, relu_dropout_forward
+from .token_linear import weight_grad
+
+
+class _AttnBlock(torch.autograd.Function):
+    """LayerNorm(src + dropout(output_proj(MSDA(value_proj(src), offsets(q), logits(q), ref))))"""
+
+    @staticmethod
+    def forward(ctx, src, q, ref, shapes, lsi, wv, bv, wo, bo, wa, ba, wp, bp, gamma, beta, p, eps, M, L, P):
+        N, S, C = src.shape
+        D = C // M
+        v = F.linear(src, wv, bv).view(N, S, M, D)
+        off = F.linear(q, wo, bo).view(N, S, M, L, P, 2)
+        logit = F.linear(q, wa, ba).view(N, S, M, L * P)
+        a = MSDA.ms_deform_attn_fused_forward(v, shapes, lsi, off, logit, ref)
+        z = F.linear(a, wp, bp)
+        y, s, mean, rstd, seed = ln_forward(src, z, gamma, beta, p, eps)
+        ctx.save_for_backward(src, q, ref, shapes, lsi, v, off, logit, a, s, mean, rstd, wv, wo, wa, wp, gamma)
+        ctx.p, ctx.seed = p, seed
+        ctx.host_geom = MSDA.host_geometry(shapes, lsi)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        src, q, ref, shapes, lsi, v, off, logit, a, s, mean, rstd, wv, wo, wa, wp, gamma = ctx.saved_tensors
+        C = src.shape[-1]
+        sh, ls = ctx.host_geom                                 # the saved pyramid tensors may come back as new objects
+        MSDA.attach_host_geometry(shapes, lsi, [(int(sh[2 * i]), int(sh[2 * i + 1])) for i in range(len(ls))], [int(x) for x in ls])
+        gx, gz, ggamma, gbeta = ln_backward(gy, s, mean, rstd, gamma, ctx.p, ctx.seed)
+        gz2 = gz.view(-1, C)
+        ga = (gz2 @ wp).view_as(a)
+        gwp, gbp = weight_grad(gz2, a.view(-1, C)), colsum(gz2)
+        gv, goff, glogit = MSDA.ms_deform_attn_fused_backward(v, shapes, lsi, off, logit, ref, ga.contiguous())
+        gv2, goff2, glogit2 = gv.view(-1, C), goff.view(-1, wo.shape[0]), glogit.view(-1, wa.shape[0])
+        gx.view(-1, C).addmm_(gv2, wv)                       # d src: residual + value path, no separate add pass
+        src2, q2 = src.reshape(-1, C), q.reshape(-1, C)
+        gq = goff2 @ wo
+        gq.addmm_(glogit2, wa)                               # d q: offsets + attention-weight paths
+        return (gx, gq.view_as(q), None, None, None, weight_grad(gv2, src2), colsum(gv2), weight_grad(goff2, q2), colsum(goff2),
+                weight_grad(glogit2, q2), colsum(glogit2), gwp, gbp, ggamma, gbeta, None, None, None, None, None)
+
+
+class _FFNBlock(torch.autograd.Function):
+    """LayerNorm(x + dropout(linear2(dropout(relu(linear1(x))))))"""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, p_hidden, p_res, eps):
+        h = F.linear(x, w1, b1)
+        hd = relu_dropout_forward(h, p_hidden) if p_hidden > 0 else torch.relu_(h)
+        f = F.linear(hd, w2, b2)
+        y, s, mean, rstd, seed = ln_forward(x, f, gamma, beta, p_res, eps)
+        ctx.save_for_backward(x, hd, s, mean, rstd, w1, w2, gamma)
+        ctx.p_hidden, ctx.p_res, ctx.seed = p_hidden, p_res, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, hd, s, mean, rstd, w1, w2, gamma = ctx.saved_tensors
+        C, Hd = x.shape[-1], hd.shape[-1]
+        gx, gf, ggamma, gbeta = ln_backward(gy, s, mean, rstd, gamma, ctx.p_res, ctx.seed)
+        gf2 = gf.view(-1, C)
+        ghd = (gf2 @ w2).view_as(hd)
+        gw2, gb2 = weight_grad(gf2, hd.view(-1, Hd)), colsum(gf2)
+        gh = relu_dropout_backward(ghd, hd, ctx.p_hidden) if ctx.p_hidden > 0 else ghd * (hd > 0)
+        gh2 = gh.view(-1, Hd)
+        gx.view(-1, C).addmm_(gh2, w1)                       # d x: residual + FFN path
+        return gx, weight_grad(gh2, x.reshape(-1, C)), colsum(gh2), gw2, gb2, ggamma, gbeta, None, None, None
+
+
+def supported(layer, src, pos, reference_points, spatial_shapes, padding_mask):
+    attn = layer.self_attn
+    return (src.is_cuda and src.dtype == torch.float32 and torch.is_grad_enabled() and layer.training and padding_mask is None
+            and src.shape[-1] == 256 and attn.d_model == 256 and getattr(attn, "fuse_prologue", False)
+            and src.shape[0] * src.shape[1] >= 32768 and layer.linear1.out_features % 4 == 0 and layer.linear1.out_features <= 256
+            and reference_points.dtype == torch.float32 and not reference_points.requires_grad
+            and all(m.elementwise_affine for m in (layer.norm1, layer.norm2)))
+
+
+def encoder_layer(layer, src, pos, reference_points, spatial_shapes, level_start_index):
+    """``VisualEncoderLayer.forward`` through the two block nodes (caller checked ``supported``)."""
+    attn = layer.self_attn
+    q = src if pos is None else src + pos
+    M, L, P = attn.n_heads, attn.n_levels, attn.n_points
+    v_probe = src.new_empty((src.shape[0], src.shape[1], M, 256 // M))
+    off_probe = src.new_empty((src.shape[0], src.shape[1], M, L, P, 2))
+    if not MSDA.fused_supported(v_probe, spatial_shapes, off_probe, reference_points):
+        return None
+    src1 = _AttnBlock.apply(src, q, reference_points.contiguous(), spatial_shapes, level_start_index,
+                            attn.value_proj.weight, attn.value_proj.bias, attn.sampling_offsets.weight, attn.sampling_offsets.bias,
+                            attn.attention_weights.weight, attn.attention_weights.bias, attn.output_proj.weight, attn.output_proj.bias,
+                            layer.norm1.weight, layer.norm1.bias, layer.dropout1.p, layer.norm1.eps, M, L, P)
+    return _FFNBlock.apply(src1, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
+                           layer.norm2.weight, layer.norm2.bias, layer.dropout2.p, layer.dropout3.p, layer.norm2.eps)

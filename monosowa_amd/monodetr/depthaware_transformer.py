@@ -19,11 +19,13 @@ from torch.nn.init import constant_, normal_, xavier_uniform_
 from .misc import inverse_sigmoid
 from .. import MultiScaleDeformableAttention as _MSDA
 from ..ms_deform_attn import MSDeformAttn
+from .. import encoder_block
 from ..flash_attn import mha_forward, mha_supported
 from ..pointwise import dropout_add_layernorm, relu_dropout
 from ..token_linear import token_linear
 
 
+ENCODER_BLOCKS = True     # encoder layers as two autograd nodes whose GEMMs accumulate shared gradients in place
 SELF_ATTN_HIP = True      # decoder self-attention (50 queries per group) through the HIP attention core (-0.27 ms/step, tools/ab_step.py)
 
 
@@ -69,6 +71,10 @@ class VisualEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+        if ENCODER_BLOCKS and encoder_block.supported(self, src, pos, reference_points, spatial_shapes, padding_mask):
+            out = encoder_block.encoder_layer(self, src, pos, reference_points, spatial_shapes, level_start_index)
+            if out is not None:
+                return out
         attn = self.self_attn(_add_pos(src, pos), reference_points, src, spatial_shapes, level_start_index, padding_mask)
         src = dropout_add_layernorm(src, attn, self.norm1, self.dropout1)
         ff = token_linear(relu_dropout(token_linear(src, self.linear1), self.dropout2), self.linear2)

@@ -196,21 +196,43 @@ def _next_seed():
 LN_MIN_ROWS = int(os.environ.get('MONOSOWA_LN_MIN_ROWS', '1'))
 
 
+def ln_forward(x, z, weight, bias, p, eps):
+    """y = LayerNorm_256(x + dropout_p(z)); returns (y, s, mean, rstd, seed) -- the last four feed ``ln_backward``."""
+    x, z = x.contiguous(), z.contiguous()
+    rows = x.numel() // 256
+    y, s = torch.empty_like(x), torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    seed = _next_seed() if p > 0 else 0
+    with torch.cuda.device(x.device):
+        code = load().mono_dropout_add_layernorm_fwd_f32(
+            x.data_ptr(), z.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), s.data_ptr(), mean.data_ptr(),
+            rstd.data_ptr(), rows, 256, float(p), seed, float(eps), torch.cuda.current_stream().cuda_stream)
+    if code:
+        raise RuntimeError("mono_dropout_add_layernorm_fwd_f32 failed with code %d" % code)
+    return y, s, mean, rstd, seed
+
+
+def ln_backward(gy, s, mean, rstd, weight, p, seed):
+    """-> (gx, gz, gweight, gbias) of ``ln_forward``."""
+    gy = gy.contiguous()
+    gx, gz = torch.empty_like(s), torch.empty_like(s)
+    rows = s.numel() // 256
+    gw = torch.empty(2, 256, dtype=torch.float32, device=s.device)
+    partials = torch.empty(load().mono_reduce_blocks(rows) * 512, dtype=torch.float32, device=s.device)
+    with torch.cuda.device(s.device):
+        code = load().mono_dropout_add_layernorm_bwd_f32(
+            gy.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), weight.data_ptr(), gx.data_ptr(), gz.data_ptr(),
+            gw.data_ptr(), partials.data_ptr(), rows, 256, float(p), seed, torch.cuda.current_stream().cuda_stream)
+    if code:
+        raise RuntimeError("mono_dropout_add_layernorm_bwd_f32 failed with code %d" % code)
+    return gx, gz, gw[0], gw[1]
+
+
 class _DropoutAddLayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, z, weight, bias, p, eps):
-        x, z = x.contiguous(), z.contiguous()
-        rows = x.numel() // 256
-        y, s = torch.empty_like(x), torch.empty_like(x)
-        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
-        rstd = torch.empty_like(mean)
-        seed = _next_seed() if p > 0 else 0
-        with torch.cuda.device(x.device):
-            code = load().mono_dropout_add_layernorm_fwd_f32(
-                x.data_ptr(), z.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), s.data_ptr(), mean.data_ptr(),
-                rstd.data_ptr(), rows, 256, float(p), seed, float(eps), torch.cuda.current_stream().cuda_stream)
-        if code:
-            raise RuntimeError("mono_dropout_add_layernorm_fwd_f32 failed with code %d" % code)
+        y, s, mean, rstd, seed = ln_forward(x, z, weight, bias, p, eps)
         ctx.save_for_backward(s, mean, rstd, weight)
         ctx.p, ctx.seed = p, seed
         return y
@@ -218,18 +240,7 @@ class _DropoutAddLayerNorm(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         s, mean, rstd, weight = ctx.saved_tensors
-        gy = gy.contiguous()
-        gx, gz = torch.empty_like(s), torch.empty_like(s)
-        rows = s.numel() // 256
-        gw = torch.empty(2, 256, dtype=torch.float32, device=s.device)
-        partials = torch.empty(load().mono_reduce_blocks(rows) * 512, dtype=torch.float32, device=s.device)
-        with torch.cuda.device(s.device):
-            code = load().mono_dropout_add_layernorm_bwd_f32(
-                gy.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), weight.data_ptr(), gx.data_ptr(), gz.data_ptr(),
-                gw.data_ptr(), partials.data_ptr(), rows, 256, float(ctx.p), ctx.seed, torch.cuda.current_stream().cuda_stream)
-        if code:
-            raise RuntimeError("mono_dropout_add_layernorm_bwd_f32 failed with code %d" % code)
-        return gx, gz, gw[0], gw[1], None, None
+        return ln_backward(gy, s, mean, rstd, weight, ctx.p, ctx.seed) + (None, None)
 
 
 def dropout_add_layernorm(x, z, norm, dropout):
@@ -384,16 +395,30 @@ class FusedAdamWPlan:
 
 
 # ---------------------------------------------------------------------------------------------------------
+def relu_dropout_forward(h, p):
+    h = h.contiguous()
+    y = torch.empty_like(h)
+    with torch.cuda.device(h.device):
+        code = load().mono_relu_dropout_fwd_f32(h.data_ptr(), y.data_ptr(), h.numel(), float(p), _next_seed(), torch.cuda.current_stream().cuda_stream)
+    if code:
+        raise RuntimeError("mono_relu_dropout_fwd_f32 failed with code %d" % code)
+    return y
+
+
+def relu_dropout_backward(gy, y, p):
+    gy = gy.contiguous()
+    gh = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        code = load().mono_relu_dropout_bwd_f32(gy.data_ptr(), y.data_ptr(), gh.data_ptr(), y.numel(), float(p), torch.cuda.current_stream().cuda_stream)
+    if code:
+        raise RuntimeError("mono_relu_dropout_bwd_f32 failed with code %d" % code)
+    return gh
+
+
 class _ReluDropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, p):
-        h = h.contiguous()
-        y = torch.empty_like(h)
-        seed = _next_seed()
-        with torch.cuda.device(h.device):
-            code = load().mono_relu_dropout_fwd_f32(h.data_ptr(), y.data_ptr(), h.numel(), float(p), seed, torch.cuda.current_stream().cuda_stream)
-        if code:
-            raise RuntimeError("mono_relu_dropout_fwd_f32 failed with code %d" % code)
+        y = relu_dropout_forward(h, p)
         ctx.save_for_backward(y)
         ctx.p = p
         return y
@@ -401,13 +426,7 @@ class _ReluDropout(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         (y,) = ctx.saved_tensors
-        gy = gy.contiguous()
-        gh = torch.empty_like(y)
-        with torch.cuda.device(y.device):
-            code = load().mono_relu_dropout_bwd_f32(gy.data_ptr(), y.data_ptr(), gh.data_ptr(), y.numel(), float(ctx.p), torch.cuda.current_stream().cuda_stream)
-        if code:
-            raise RuntimeError("mono_relu_dropout_bwd_f32 failed with code %d" % code)
-        return gh, None
+        return relu_dropout_backward(gy, y, ctx.p), None
 
 
 RELU_DROPOUT_MIN_NUMEL = 1 << 22

@@ -23,6 +23,14 @@ def _slices(tokens):
     return 0
 
 
+def weight_grad(g2, x2):
+    """g2^T @ x2 for [tokens, out] / [tokens, in] matrices: split-K batched GEMM when there are many tokens."""
+    s = _slices(x2.shape[0]) if x2.shape[0] >= MIN_TOKENS else 0
+    if s:
+        return torch.bmm(g2.view(s, -1, g2.shape[1]).transpose(1, 2), x2.view(s, -1, x2.shape[1])).sum(0)
+    return g2.t() @ x2
+
+
 class _TokenLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -38,12 +46,7 @@ class _TokenLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = (g2 @ weight).view_as(x)
         if ctx.needs_input_grad[1]:
-            x2 = x.reshape(-1, x.shape[-1])
-            s = _slices(x2.shape[0]) if x2.shape[0] >= MIN_TOKENS else 0
-            if s:
-                gw = torch.bmm(g2.view(s, -1, g2.shape[1]).transpose(1, 2), x2.view(s, -1, x2.shape[1])).sum(0)
-            else:
-                gw = g2.t() @ x2
+            gw = weight_grad(g2, x.reshape(-1, x.shape[-1]))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = colsum(g2.contiguous())
         return gx, gw, gb

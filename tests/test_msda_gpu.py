@@ -761,3 +761,44 @@ def test_block_cost_pass_is_bitwise_on_the_gpu_too():
         finally:
             M.BLOCK_COST = True
     assert np.array_equal(out[True], out[False])
+
+
+def test_encoder_block_nodes_equal_the_module_by_module_layer():
+    """encoder_block: one visual-encoder layer as two autograd nodes (in-place accumulated shared gradients) against the
+    same layer evaluated module by module -- eval-like (dropout 0) so both see identical arithmetic: output, input and
+    positional gradients, every parameter gradient."""
+    from monosowa_amd import MultiScaleDeformableAttention as MSDA
+    from monosowa_amd.monodetr import depthaware_transformer as T
+    torch.manual_seed(0)
+    layer = T.VisualEncoderLayer(256, 256, 0.0, "relu", 4, 8, 4).cuda().train()
+    levels = [(24, 80), (12, 40), (6, 20), (3, 10)]
+    S = sum(h * w for h, w in levels)
+    B = 16
+    shapes = torch.tensor(levels, dtype=torch.long, device="cuda")
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    starts = [0]
+    for h, w in levels[:-1]:
+        starts.append(starts[-1] + h * w)
+    MSDA.attach_host_geometry(shapes, lsi, levels, starts)
+    src = torch.randn(B, S, 256, device="cuda", requires_grad=True)
+    pos = torch.randn(B, S, 256, device="cuda", requires_grad=True)
+    ref = torch.rand(B, S, 4, 2, device="cuda")
+    go = torch.randn(B, S, 256, device="cuda")
+    params = list(layer.parameters())
+
+    def run(flag):
+        T.ENCODER_BLOCKS = flag
+        for t in [src, pos] + params:
+            t.grad = None
+        try:
+            y = layer(src, pos, ref, shapes, lsi, None)
+        finally:
+            T.ENCODER_BLOCKS = True
+        y.backward(go)
+        return [y.detach().clone(), src.grad.clone(), pos.grad.clone()] + [p_.grad.clone() for p_ in params], type(y.grad_fn).__name__
+    ours, name = run(True)
+    assert "FFNBlock" in name
+    ref_out, name0 = run(False)
+    assert "FFNBlock" not in name0
+    for a, b in zip(ours, ref_out):
+        assert (a - b).abs().max() <= 3e-5 * max(b.abs().max().item(), 1e-3)
