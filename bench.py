@@ -284,7 +284,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "MonoDETR %s img/s (KITTI 1280x384)" % ("training" if train else "inference"),
+            "metric": "MonoDETR %s img/s (KITTI %dx%d)" % ("training" if train else "inference", W, H),
             "value": value, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -802,3 +802,35 @@ def test_encoder_block_nodes_equal_the_module_by_module_layer():
     assert "FFNBlock" not in name0
     for a, b in zip(ours, ref_out):
         assert (a - b).abs().max() <= 3e-5 * max(b.abs().max().item(), 1e-3)
+
+
+@pytest.mark.parametrize("levels", [[(47, 176), (24, 88), (12, 44), (6, 22)],          # config 4: 1408x376, S = 11044
+                                    [(160, 240), (80, 120), (40, 60), (20, 30)]])       # config 5: 1920x1280, S = 51000
+def test_other_baseline_geometries_encoder_shape_vs_c_oracle(levels):
+    """BASELINE configs 4 and 5: the encoder-shaped call (Lq = S, queries on the pixel grid, +-4 px offsets)
+    of one sample against the C oracle -- forward and all three gradients, planned kernels (host geometry attached)."""
+    rng = np.random.default_rng(11)
+    shapes = np.array(levels, dtype=np.int64)
+    lsi = O.level_start_index(shapes)
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    B, M, D, L, P = 1, 8, 32, 4, 4
+    ref = np.concatenate([np.stack(np.meshgrid((np.arange(w) + 0.5) / w, (np.arange(h) + 0.5) / h), -1).reshape(-1, 2) for h, w in levels])
+    off = rng.uniform(-4, 4, (B, S, M, L, P, 2)) / shapes[None, None, None, :, None, ::-1]
+    loc = (ref[None, :, None, None, None, :] + off).astype(np.float32)
+    value = rng.standard_normal((B, S, M, D)).astype(np.float32)
+    w = rng.standard_normal((B, S, M, L * P))
+    w = (np.exp(w) / np.exp(w).sum(-1, keepdims=True)).reshape(B, S, M, L, P).astype(np.float32)
+    go = rng.standard_normal((B, S, M * D)).astype(np.float32)
+    want, want64 = _oracle_want(value, shapes, lsi, loc, w, go)
+    MSDA = _msda()
+    s_dev = _dev(shapes)
+    starts = [0]
+    for h, wd in levels[:-1]:
+        starts.append(starts[-1] + h * wd)
+    MSDA.attach_host_geometry(s_dev, _dev(lsi), levels, starts)
+    v, i, lc, ww, g = map(_dev, (value, lsi, loc, w, go))
+    out = MSDA.ms_deform_attn_forward(v, s_dev, i, lc, ww, 64)
+    gv, gl, gw = MSDA.ms_deform_attn_backward(v, s_dev, i, lc, ww, g, 64)
+    for got, r, name in ((out, want[0], "out"), (gv, want[1], "grad_value"), (gl, want[2], "grad_loc"), (gw, want[3], "grad_attw")):
+        _close(got, r, 1e-4, name)
+    _close(gv, want64[1], 1e-4, "grad_value vs f64")
