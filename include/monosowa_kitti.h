@@ -1,0 +1,25 @@
+/* monosowa_kitti.h -- C ABI of the rotated-box overlap kernels of the KITTI evaluation.
+ *
+ * Replaces lib/datasets/kitti/kitti_eval_python/rotate_iou.py:263-330 (`rotate_iou_gpu_eval`, a numba-CUDA kernel) and
+ * the CPU loop of eval.py:197-230 (`d3_box_overlap`).  Device pointers, asynchronous on `stream`.
+ * criterion: -1 IoU, 0 intersection / area of the first operand, 1 intersection / area of the second, 2 intersection.
+ * Return value: 0, -1 (NULL pointer), -2 (bad size / criterion) or a hipError_t.
+ */
+#ifndef MONOSOWA_KITTI_H
+#define MONOSOWA_KITTI_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* boxes [N, 5], query [K, 5] = (cx, cy, w, h, angle; clockwise positive) -> out [N, K].
+ * As in the reference, criterion 0 divides by the QUERY box's area and 1 by the box's (rotate_iou.py:249-260, :289). */
+int mono_rotate_iou_f32(const float *boxes, const float *query, float *out, long long N, long long K, int criterion, void *stream);
+
+/* Camera-frame 3D boxes [*, 7] = (x, y, z, d3, d4, d5, ry): BEV rectangle (x, z, d3, d5, ry), bottom at y, height d4;
+ * out [N, K] = 3D overlap (criterion 0: / volume of the box, 1: / volume of the query box, as eval.py:210-221). */
+int mono_box3d_overlap_f32(const float *boxes, const float *query, float *out, long long N, long long K, int criterion, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

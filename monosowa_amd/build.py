@@ -20,6 +20,7 @@ LIBS = {
     "libmonosowa_msda.so": ("msda_capi.hip", [os.path.join("..", "..", "include", "monosowa_msda.h")]),
     "libmonosowa_pointwise.so": ("pointwise.hip", [os.path.join("..", "..", "include", "monosowa_pointwise.h")]),
     "libmonosowa_attn.so": ("flash_attn.hip", [os.path.join("..", "..", "include", "monosowa_attn.h")]),
+    "libmonosowa_kitti.so": ("rotate_iou.hip", [os.path.join("..", "..", "include", "monosowa_kitti.h")]),
 }
 
 FLAGS = ["-O3", "--offload-arch=" + ARCH, "-munsafe-fp-atomics", "-fPIC", "-shared", "-std=c++17",
