@@ -103,9 +103,18 @@ class VisualEncoder(nn.Module):
         return reference_points[:, :, None] * valid_ratios[:, None]
 
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None,
-                spatial_shapes_list=None):
+                spatial_shapes_list=None, unit_ratios=False):
+        """``unit_ratios``: the caller built ``valid_ratios`` as all ones (no padding anywhere), so the reference grid
+        depends on the pyramid only and is kept across steps."""
         shapes_for_ref = spatial_shapes_list if spatial_shapes_list is not None else spatial_shapes
-        reference_points = self.get_reference_points(shapes_for_ref, valid_ratios, device=src.device)
+        if unit_ratios and spatial_shapes_list is not None:
+            key = (tuple(map(tuple, spatial_shapes_list)), valid_ratios.shape[0], src.device)
+            cache = self.__dict__.setdefault("_ref_cache", {})
+            if key not in cache:
+                cache[key] = self.get_reference_points(shapes_for_ref, valid_ratios, device=src.device).detach()
+            reference_points = cache[key]
+        else:
+            reference_points = self.get_reference_points(shapes_for_ref, valid_ratios, device=src.device)
         out = src
         for layer in self.layers:
             out = layer(out, pos, reference_points, spatial_shapes, level_start_index, padding_mask)
@@ -322,7 +331,7 @@ class DepthAwareTransformer(nn.Module):
             valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
 
         memory = self.encoder(src_flat, spatial_shapes, level_start_index, valid_ratios, pos_flat, mask_flat,
-                              spatial_shapes_list=shapes)
+                              spatial_shapes_list=shapes, unit_ratios=all_valid)
 
         bs, _, c = memory.shape
         query_pos, tgt = torch.split(query_embed, c, dim=1)

@@ -127,7 +127,7 @@ class MonoDETR(nn.Module):
         for l in range(len(srcs), self.num_feature_levels):   # extra stride-2 levels from C5
             src = self._project(l, features[-1].tensors if l == len(features) else srcs[-1])
             mask = torch.zeros(src.shape[0], src.shape[2], src.shape[3], dtype=torch.bool, device=src.device)
-            pos.append(self.backbone[1](NestedTensor(src, mask)).to(src.dtype))
+            pos.append(self.backbone[1](NestedTensor(src, mask, all_valid=True)).to(src.dtype))
             srcs.append(src)
             masks.append(mask)
         self._all_valid = all_valid          # the extra levels are built with all-False masks above
