@@ -26,6 +26,7 @@ from ..token_linear import token_linear
 
 
 ENCODER_BLOCKS = True     # encoder layers as two autograd nodes whose GEMMs accumulate shared gradients in place
+MERGE_SA_PROJ = True      # decoder self-attention: content + positional projections as one GEMM (same input)
 SELF_ATTN_HIP = True      # decoder self-attention (50 queries per group) through the HIP attention core (-0.27 ms/step, tools/ab_step.py)
 
 
@@ -161,8 +162,14 @@ class DepthAwareDecoderLayer(nn.Module):
         """q = k = content/pos projections of (tgt + query_pos); v = raw tgt.  In training the
         group_num query groups attend only within their group (folded into the batch)."""
         x = _add_pos(tgt, query_pos)
-        q = self.sa_qcontent_proj(x) + self.sa_qpos_proj(x)
-        k = self.sa_kcontent_proj(x) + self.sa_kpos_proj(x)
+        if MERGE_SA_PROJ:
+            # content and positional projections see the same input x = tgt + query_pos (depthaware_transformer.py:471-480):
+            # x Wc^T + x Wp^T = x (Wc + Wp)^T -- one GEMM per q / k (and one set of backward kernels) instead of two plus an add
+            q = F.linear(x, self.sa_qcontent_proj.weight + self.sa_qpos_proj.weight, self.sa_qcontent_proj.bias + self.sa_qpos_proj.bias)
+            k = F.linear(x, self.sa_kcontent_proj.weight + self.sa_kpos_proj.weight, self.sa_kcontent_proj.bias + self.sa_kpos_proj.bias)
+        else:
+            q = self.sa_qcontent_proj(x) + self.sa_qpos_proj(x)
+            k = self.sa_kcontent_proj(x) + self.sa_kpos_proj(x)
         v = tgt
         B, Lq, C = tgt.shape
         if self.training:
