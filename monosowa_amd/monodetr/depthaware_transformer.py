@@ -162,14 +162,6 @@ class DepthAwareDecoderLayer(nn.Module):
         """q = k = content/pos projections of (tgt + query_pos); v = raw tgt.  In training the
         group_num query groups attend only within their group (folded into the batch)."""
         x = _add_pos(tgt, query_pos)
-        if MERGE_SA_PROJ:
-            # content and positional projections see the same input x = tgt + query_pos (depthaware_transformer.py:471-480):
-            # x Wc^T + x Wp^T = x (Wc + Wp)^T -- one GEMM per q / k (and one set of backward kernels) instead of two plus an add
-            q = F.linear(x, self.sa_qcontent_proj.weight + self.sa_qpos_proj.weight, self.sa_qcontent_proj.bias + self.sa_qpos_proj.bias)
-            k = F.linear(x, self.sa_kcontent_proj.weight + self.sa_kpos_proj.weight, self.sa_kcontent_proj.bias + self.sa_kpos_proj.bias)
-        else:
-            q = self.sa_qcontent_proj(x) + self.sa_qpos_proj(x)
-            k = self.sa_kcontent_proj(x) + self.sa_kpos_proj(x)
         v = tgt
         B, Lq, C = tgt.shape
         if self.training:
@@ -177,9 +169,21 @@ class DepthAwareDecoderLayer(nn.Module):
             if Lq != G * n:
                 raise NotImplementedError("denoising (extra noise queries) is off in every shipped config; "
                                           "expected %d x %d queries, got %d" % (G, n, Lq))
-            fold = lambda t: t.reshape(B * G, n, C).transpose(0, 1)
-            return self._mha(self.self_attn, fold(q), fold(k), fold(v)).transpose(0, 1).reshape(B, Lq, C)
-        return self._mha(self.self_attn, q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1)).transpose(0, 1)
+            fold = lambda t: t.reshape(B * G, n, t.shape[-1]).transpose(0, 1)
+        else:
+            fold = lambda t: t.transpose(0, 1)
+        mha = self.self_attn
+        if MERGE_SA_PROJ:
+            # content and positional projections see the same input x = tgt + query_pos (depthaware_transformer.py:471-480):
+            # x Wc^T + x Wp^T = x (Wc + Wp)^T -- one GEMM per q / k (and one set of backward kernels) instead of two plus an add
+            # (-0.65 ms/step; composing further with the attention module's own input projections measured +1.0 ms: the
+            # extra 256^3 products and their backward cost more than the two [8800, 256] GEMMs they replace)
+            q = F.linear(x, self.sa_qcontent_proj.weight + self.sa_qpos_proj.weight, self.sa_qcontent_proj.bias + self.sa_qpos_proj.bias)
+            k = F.linear(x, self.sa_kcontent_proj.weight + self.sa_kpos_proj.weight, self.sa_kcontent_proj.bias + self.sa_kpos_proj.bias)
+        else:
+            q = self.sa_qcontent_proj(x) + self.sa_qpos_proj(x)
+            k = self.sa_kcontent_proj(x) + self.sa_kpos_proj(x)
+        return self._mha(mha, fold(q), fold(k), fold(v)).transpose(0, 1).reshape(B, Lq, C)
 
     @staticmethod
     def _mha(mha, q, k, v):
