@@ -60,12 +60,43 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
 
 
+# Optimizers may update parameters through raw pointers (the fused AdamW kernel does) without touching the tensors'
+# version counters: every optimizer step anywhere invalidates the folded-weight cache below.
+_PARAM_EPOCH = [0]
+
+
+def _bump_param_epoch(*_args, **_kwargs):
+    _PARAM_EPOCH[0] += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook
+    register_optimizer_step_post_hook(_bump_param_epoch)
+except ImportError:             # very old torch: no global hook -> never cache
+    _PARAM_EPOCH = None
+
+
+def folded_weight(conv, bn, scale):
+    """``conv.weight * scale`` (frozen BN folded into the convolution).  When no gradient will flow to the weight (frozen
+    stem / layer1, or inference) the product only changes when the weight or the BN buffers do: kept across calls."""
+    w = conv.weight
+    if (w.requires_grad and torch.is_grad_enabled()) or _PARAM_EPOCH is None:
+        return w * scale.view(-1, 1, 1, 1)
+    key = (w.data_ptr(), w._version, scale.data_ptr(), scale._version, _PARAM_EPOCH[0])
+    cached = conv.__dict__.get("_folded")
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            cached = conv.__dict__["_folded"] = (key, (w * scale.view(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
+                                                 if w.is_contiguous(memory_format=torch.channels_last) else w * scale.view(-1, 1, 1, 1))
+    return cached[1]
+
+
 def conv_bn_fork(x, conv, bn, residual):
     """``conv_bn(x, conv, bn, residual)`` returned as a pair for its two consumers (next block's first convolution and
     identity branch): their gradients are added inside the fused ReLU backward (``pointwise.bias_act_fork``)."""
     if isinstance(bn, FrozenBatchNorm2d):
         scale, shift = bn.scale_shift()
-        y = F.conv2d(x, conv.weight * scale.view(-1, 1, 1, 1), None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        y = F.conv2d(x, folded_weight(conv, bn, scale), None, conv.stride, conv.padding, conv.dilation, conv.groups)
         return bias_act_fork(y, shift, residual)
     out = conv_bn(x, conv, bn, residual)
     return out, out
@@ -77,7 +108,7 @@ def conv_bn(x, conv, bn, residual=None, relu=True):
     an add pass and a ReLU pass)."""
     if isinstance(bn, FrozenBatchNorm2d):
         scale, shift = bn.scale_shift()
-        y = F.conv2d(x, conv.weight * scale.view(-1, 1, 1, 1), None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        y = F.conv2d(x, folded_weight(conv, bn, scale), None, conv.stride, conv.padding, conv.dilation, conv.groups)
         return bias_act(y, shift, residual, relu)
     y = bn(conv(x))
     if residual is not None:

@@ -413,3 +413,25 @@ def test_block_cost_pass_is_bitwise_the_gathered_cross_matrix():
     for la, lr in zip(a, ref):
         for (s1, t1), (s2, t2) in zip(la, lr):
             assert np.array_equal(s1, s2) and np.array_equal(t1, t2)
+
+
+def test_folded_weight_cache_is_invalidated_by_optimizer_steps():
+    """The frozen-BN-folded convolution weights are cached when no gradient flows (inference, frozen layers); an
+    optimizer step that rewrites the parameters (even behind autograd's back) must invalidate the cache."""
+    from monosowa_amd.monodetr import backbone as BB
+    conv = torch.nn.Conv2d(4, 8, 1, bias=False)
+    bn = BB.FrozenBatchNorm2d(8)
+    bn.weight.uniform_(0.5, 1.5)
+    x = torch.randn(1, 4, 3, 3)
+    with torch.no_grad():
+        y0 = BB.conv_bn(x, conv, bn, relu=False).clone()
+        w_cached = BB.folded_weight(conv, bn, bn.scale_shift()[0])
+        assert BB.folded_weight(conv, bn, bn.scale_shift()[0]) is w_cached            # reused
+    opt = torch.optim.SGD(conv.parameters(), lr=0.5)
+    conv(x).sum().backward()
+    conv.weight.grad.fill_(1.0)
+    opt.step()
+    with torch.no_grad():
+        y1 = BB.conv_bn(x, conv, bn, relu=False)
+        ref = bn(conv(x))
+    assert not torch.allclose(y0, y1) and torch.allclose(y1, ref, atol=1e-6)
