@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float *__re
 // (Same-address global atomics serialise in L2: 1275 workgroups x 256 atomics cost 100 us, hence two stages.)
 template <int JJ>
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ g, float *__restrict__ partials, long long rows,
-                                                     int C, int rows_per_block) {
+                                                     int C, int rows_per_block, long long rows_per_batch, long long batch_stride) {
   __shared__ float4 red[3][JJ][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cv = C >> 2;
   const long long r0 = (long long)blockIdx.x * rows_per_block;
@@ -228,7 +228,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ g
     for (int j = 0; j < JJ; ++j) {
       const int c = lane + 64 * j;
       if (c < cv) {
-        const float4 v = *reinterpret_cast<const float4 *>(g + r * C + c * 4);
+        // row r of the virtual [batch * rows_per_batch, C] matrix (contiguous input: rows_per_batch = rows, one batch)
+        const long long bidx = r / rows_per_batch;
+        const float4 v = *reinterpret_cast<const float4 *>(g + bidx * batch_stride + (r - bidx * rows_per_batch) * C + c * 4);
         acc[j].x += v.x; acc[j].y += v.y; acc[j].z += v.z; acc[j].w += v.w;
       }
     }
@@ -488,9 +490,24 @@ int mono_colsum_f32(const float *g, float *out, float *partials, long long rows,
   hipStream_t st = (hipStream_t)stream_;
   const int grid = mono_reduce_blocks(rows);
   const int rpb = (int)((rows + grid - 1) / grid + 63) / 64 * 64;
-  if (C <= 256) mono::colsum_kernel<1><<<grid, 256, 0, st>>>(g, partials, rows, C, rpb);
-  else if (C <= 512) mono::colsum_kernel<2><<<grid, 256, 0, st>>>(g, partials, rows, C, rpb);
-  else mono::colsum_kernel<4><<<grid, 256, 0, st>>>(g, partials, rows, C, rpb);
+  if (C <= 256) mono::colsum_kernel<1><<<grid, 256, 0, st>>>(g, partials, rows, C, rpb, rows, 0);
+  else if (C <= 512) mono::colsum_kernel<2><<<grid, 256, 0, st>>>(g, partials, rows, C, rpb, rows, 0);
+  else mono::colsum_kernel<4><<<grid, 256, 0, st>>>(g, partials, rows, C, rpb, rows, 0);
+  mono::partial_sum_kernel<<<(C / 4 + 63) / 64, 1024, 0, st>>>(partials, out, grid, C);
+  return (int)hipGetLastError();
+}
+
+// Column sums of a [batch, rows, C] view whose batches are batch_stride floats apart (rows of a batch contiguous):
+// out[c] = sum_{b, r} g[b * batch_stride + r * C + c].  partials: mono_reduce_blocks(batch * rows) * C floats.
+int mono_colsum_strided_f32(const float *g, float *out, float *partials, int batch, long long rows, long long batch_stride,
+                            int C, void *stream_) {
+  if (!g || !out || !partials) return -1;
+  if (batch <= 0 || rows <= 0 || C <= 0 || C % 4 || C > 256 || batch_stride % 4) return -2;
+  hipStream_t st = (hipStream_t)stream_;
+  const long long total = (long long)batch * rows;
+  const int grid = mono_reduce_blocks(total);
+  const int rpb = (int)((total + grid - 1) / grid + 63) / 64 * 64;
+  mono::colsum_kernel<1><<<grid, 256, 0, st>>>(g, partials, total, C, rpb, rows, batch_stride);
   mono::partial_sum_kernel<<<(C / 4 + 63) / 64, 1024, 0, st>>>(partials, out, grid, C);
   return (int)hipGetLastError();
 }

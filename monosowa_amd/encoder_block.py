@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import MultiScaleDeformableAttention as MSDA
-from .pointwise import colsum, ln_backward, ln_forward, relu_dropout_backward, relu_dropout_forward
+from .pointwise import colsum, colsum_levels, ln_backward, ln_forward, relu_dropout_backward, relu_dropout_forward
 from .token_linear import weight_grad
 
 
@@ -20,9 +20,17 @@ class _AttnBlock(torch.autograd.Function):
     """LayerNorm(src + dropout(output_proj(MSDA(value_proj(src), offsets(q), logits(q), ref))))"""
 
     @staticmethod
-    def forward(ctx, src, q, ref, shapes, lsi, wv, bv, wo, bo, wa, ba, wp, bp, gamma, beta, p, eps, M, L, P):
+    def forward(ctx, src, q, ref, shapes, lsi, wv, bv, wo, bo, wa, ba, wp, bp, gamma, beta, p, eps, M, L, P,
+                level_embed=None, bounds=None):
+        """``level_embed`` / ``bounds``: when given, ``q`` is a constant pos tensor (sine encoding + level_embed values,
+        detached) and the node forms q = src + pos itself; the backward then returns the level_embed gradient -- the
+        per-level sums of d q -- from small segmented column sums instead of a [B, S, 256] pos gradient that autograd
+        would accumulate over the layers and reduce per level with 0.5 TB/s kernels."""
         N, S, C = src.shape
         D = C // M
+        ctx.levels = bounds if level_embed is not None else None
+        if level_embed is not None:
+            q = src + q
         v = F.linear(src, wv, bv).view(N, S, M, D)
         off = F.linear(q, wo, bo).view(N, S, M, L, P, 2)
         logit = F.linear(q, wa, ba).view(N, S, M, L * P)
@@ -48,10 +56,20 @@ class _AttnBlock(torch.autograd.Function):
         gv2, goff2, glogit2 = gv.view(-1, C), goff.view(-1, wo.shape[0]), glogit.view(-1, wa.shape[0])
         gx.view(-1, C).addmm_(gv2, wv)                       # d src: residual + value path, no separate add pass
         src2, q2 = src.reshape(-1, C), q.reshape(-1, C)
-        gq = goff2 @ wo
-        gq.addmm_(glogit2, wa)                               # d q: offsets + attention-weight paths
-        return (gx, gq.view_as(q), None, None, None, weight_grad(gv2, src2), colsum(gv2), weight_grad(goff2, q2), colsum(goff2),
-                weight_grad(glogit2, q2), colsum(glogit2), gwp, gbp, ggamma, gbeta, None, None, None, None, None)
+        g_level = gq = None
+        if ctx.levels is not None:
+            # q = src + pos with constant pos: d q lands in d src directly; d level_embed[l] = (sum of d offsets over the
+            # level's tokens) @ Wo + (sum of d logits) @ Wa
+            gx.view(-1, C).addmm_(goff2, wo)
+            gx.view(-1, C).addmm_(glogit2, wa)
+            g_level = colsum_levels(goff.view(goff.shape[0], goff.shape[1], -1), ctx.levels) @ wo \
+                + colsum_levels(glogit.view(glogit.shape[0], glogit.shape[1], -1), ctx.levels) @ wa
+        else:
+            gq = (goff2 @ wo)
+            gq.addmm_(glogit2, wa)                           # d q: offsets + attention-weight paths
+            gq = gq.view_as(q)
+        return (gx, gq, None, None, None, weight_grad(gv2, src2), colsum(gv2), weight_grad(goff2, q2), colsum(goff2),
+                weight_grad(glogit2, q2), colsum(glogit2), gwp, gbp, ggamma, gbeta, None, None, None, None, None, g_level, None)
 
 
 class _FFNBlock(torch.autograd.Function):
@@ -90,10 +108,15 @@ def supported(layer, src, pos, reference_points, spatial_shapes, padding_mask):
             and all(m.elementwise_affine for m in (layer.norm1, layer.norm2)))
 
 
-def encoder_layer(layer, src, pos, reference_points, spatial_shapes, level_start_index):
-    """``VisualEncoderLayer.forward`` through the two block nodes (caller checked ``supported``)."""
+def encoder_layer(layer, src, pos, reference_points, spatial_shapes, level_start_index, level_embed=None, bounds=None):
+    """``VisualEncoderLayer.forward`` through the two block nodes (caller checked ``supported``).  With ``level_embed``
+    (the parameter) and ``bounds`` (token range of each level), ``pos`` must be the DETACHED sum of the sine encoding and
+    the level embedding: its gradient is then produced inside the node (see ``_AttnBlock.forward``)."""
     attn = layer.self_attn
-    q = src if pos is None else src + pos
+    if level_embed is not None:
+        q = pos
+    else:
+        q = src if pos is None else src + pos
     M, L, P = attn.n_heads, attn.n_levels, attn.n_points
     v_probe = src.new_empty((src.shape[0], src.shape[1], M, 256 // M))
     off_probe = src.new_empty((src.shape[0], src.shape[1], M, L, P, 2))
@@ -102,6 +125,6 @@ def encoder_layer(layer, src, pos, reference_points, spatial_shapes, level_start
     src1 = _AttnBlock.apply(src, q, reference_points.contiguous(), spatial_shapes, level_start_index,
                             attn.value_proj.weight, attn.value_proj.bias, attn.sampling_offsets.weight, attn.sampling_offsets.bias,
                             attn.attention_weights.weight, attn.attention_weights.bias, attn.output_proj.weight, attn.output_proj.bias,
-                            layer.norm1.weight, layer.norm1.bias, layer.dropout1.p, layer.norm1.eps, M, L, P)
+                            layer.norm1.weight, layer.norm1.bias, layer.dropout1.p, layer.norm1.eps, M, L, P, level_embed, bounds)
     return _FFNBlock.apply(src1, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
                            layer.norm2.weight, layer.norm2.bias, layer.dropout2.p, layer.dropout3.p, layer.norm2.eps)

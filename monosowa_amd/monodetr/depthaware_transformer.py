@@ -25,6 +25,7 @@ from ..pointwise import dropout_add_layernorm, relu_dropout
 from ..token_linear import token_linear
 
 
+LEVEL_EMBED_IN_BLOCK = True   # level_embed gradient from per-level sums inside the encoder blocks (constant pos tensor)
 ENCODER_BLOCKS = True     # encoder layers as two autograd nodes whose GEMMs accumulate shared gradients in place
 MERGE_SA_PROJ = True      # decoder self-attention: content + positional projections as one GEMM (same input)
 SELF_ATTN_HIP = True      # decoder self-attention (50 queries per group) through the HIP attention core (-0.27 ms/step, tools/ab_step.py)
@@ -104,7 +105,7 @@ class VisualEncoder(nn.Module):
         return reference_points[:, :, None] * valid_ratios[:, None]
 
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None,
-                spatial_shapes_list=None, unit_ratios=False):
+                spatial_shapes_list=None, unit_ratios=False, level_embed=None):
         """``unit_ratios``: the caller built ``valid_ratios`` as all ones (no padding anywhere), so the reference grid
         depends on the pyramid only and is kept across steps."""
         shapes_for_ref = spatial_shapes_list if spatial_shapes_list is not None else spatial_shapes
@@ -117,6 +118,24 @@ class VisualEncoder(nn.Module):
         else:
             reference_points = self.get_reference_points(shapes_for_ref, valid_ratios, device=src.device)
         out = src
+        if level_embed is not None and LEVEL_EMBED_IN_BLOCK and ENCODER_BLOCKS and spatial_shapes_list is not None and pos is not None \
+                and all(encoder_block.supported(layer, src, pos, reference_points, spatial_shapes, padding_mask) for layer in self.layers):
+            # pos = sine encoding + level_embed: hand the layers a constant pos and the parameter itself, so that the
+            # level_embed gradient comes from small per-level sums inside the blocks (encoder_block._AttnBlock)
+            bounds, start = [], 0
+            for h, w in spatial_shapes_list:
+                bounds.append((start, start + h * w))
+                start += h * w
+            pos_const = pos.detach()
+            for layer in self.layers:
+                nxt = encoder_block.encoder_layer(layer, out, pos_const, reference_points, spatial_shapes, level_start_index,
+                                                  level_embed, bounds)
+                if nxt is None:
+                    break
+                out = nxt
+            else:
+                return out
+            out = src                                    # (not reached with the shipped geometry) start over, module by module
         for layer in self.layers:
             out = layer(out, pos, reference_points, spatial_shapes, level_start_index, padding_mask)
         return out
@@ -342,7 +361,7 @@ class DepthAwareTransformer(nn.Module):
             valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
 
         memory = self.encoder(src_flat, spatial_shapes, level_start_index, valid_ratios, pos_flat, mask_flat,
-                              spatial_shapes_list=shapes, unit_ratios=all_valid)
+                              spatial_shapes_list=shapes, unit_ratios=all_valid, level_embed=self.level_embed)
 
         bs, _, c = memory.shape
         query_pos, tgt = torch.split(query_embed, c, dim=1)

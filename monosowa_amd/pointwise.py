@@ -7,7 +7,7 @@ import torch
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_dropout_add_layernorm_fwd_f32",
-           "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
+           "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32")
 _lib = None
 
@@ -52,6 +52,8 @@ def load():
         lib.mono_matched_losses_bwd_f32.argtypes = [P] * 16 + [I] * 4 + [P]
         lib.mono_adamw_step_f32.restype = I
         lib.mono_adamw_step_f32.argtypes = [P, I] + [ctypes.c_double] * 4 + [P]
+        lib.mono_colsum_strided_f32.restype = I
+        lib.mono_colsum_strided_f32.argtypes = [P, P, P, I, LL, LL, I, P]
         lib.mono_colsum_f32.restype = I
         lib.mono_colsum_f32.argtypes = [P, P, P, LL, I, P]
         _lib = lib
@@ -322,6 +324,22 @@ def conv_group_norm(x, conv, gn, relu=False):
             return group_norm(y, gn, relu, pre_bias=conv.bias)
         return group_norm(y + conv.bias.view(1, -1, 1, 1), gn, relu)
     return group_norm(conv(x), gn, relu)
+
+
+def colsum_levels(g3, bounds):
+    """Per-level column sums of a [B, S, C] tensor (contiguous, C <= 256): rows [a, b) of every batch for each (a, b)
+    in ``bounds`` -> [len(bounds), C]."""
+    B, S, C = g3.shape
+    out = torch.empty((len(bounds), C), dtype=torch.float32, device=g3.device)
+    lib = load()
+    with torch.cuda.device(g3.device):
+        st = torch.cuda.current_stream().cuda_stream
+        for i, (a, b) in enumerate(bounds):
+            partials = torch.empty(lib.mono_reduce_blocks(B * (b - a)) * C, dtype=torch.float32, device=g3.device)
+            code = lib.mono_colsum_strided_f32(g3.data_ptr() + a * C * 4, out[i].data_ptr(), partials.data_ptr(), B, b - a, S * C, C, st)
+            if code:
+                raise RuntimeError("mono_colsum_strided_f32 failed with code %d" % code)
+    return out
 
 
 def colsum(g2):

@@ -834,3 +834,43 @@ def test_other_baseline_geometries_encoder_shape_vs_c_oracle(levels):
     for got, r, name in ((out, want[0], "out"), (gv, want[1], "grad_value"), (gl, want[2], "grad_loc"), (gw, want[3], "grad_attw")):
         _close(got, r, 1e-4, name)
     _close(gv, want64[1], 1e-4, "grad_value vs f64")
+
+
+def test_level_embed_gradient_from_the_encoder_blocks():
+    """The whole transformer (train mode, dropout 0 so both paths see the same arithmetic) with the level_embed gradient
+    produced inside the encoder blocks from per-level column sums, against the path where pos carries the gradient:
+    level_embed.grad, the feature gradients and a few parameter gradients."""
+    import yaml
+    from monosowa_amd.monodetr import depthaware_transformer as T
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "configs", "monodetr.yaml")))["model"]
+    torch.manual_seed(0)
+    tr = T.build_depthaware_transformer(dict(cfg, dropout=0.0)).cuda().train()
+    for m in tr.modules():
+        if isinstance(m, (torch.nn.Dropout, torch.nn.MultiheadAttention)):
+            m.p = 0.0 if isinstance(m, torch.nn.Dropout) else None
+            if isinstance(m, torch.nn.MultiheadAttention):
+                m.dropout = 0.0
+    tr.decoder.bbox_embed = torch.nn.ModuleList([T.MLP(256, 256, 6, 3) for _ in range(3)]).cuda()
+    tr.decoder.dim_embed = torch.nn.ModuleList([T.MLP(256, 256, 3, 2) for _ in range(3)]).cuda()
+    B = 16
+    levels = [(24, 80), (12, 40), (6, 20), (3, 10)]
+    srcs = [torch.randn(B, 256, h, w, device="cuda", requires_grad=True) for h, w in levels]
+    masks = [torch.zeros(B, h, w, dtype=torch.bool, device="cuda") for h, w in levels]
+    pos = [torch.randn(B, 256, h, w, device="cuda") for h, w in levels]
+    query = torch.randn(550, 512, device="cuda")
+    dpe = torch.randn(B, 256, *levels[0], device="cuda")
+    params = [tr.level_embed, tr.encoder.layers[0].self_attn.sampling_offsets.weight, tr.encoder.layers[2].linear1.bias]
+
+    def run(flag):
+        T.LEVEL_EMBED_IN_BLOCK = flag
+        for t in srcs + params:
+            t.grad = None
+        try:
+            hs = tr(srcs, masks, pos, query, dpe, dpe, all_valid=True)[0]
+        finally:
+            T.LEVEL_EMBED_IN_BLOCK = True
+        hs.square().mean().backward()
+        return [hs.detach().clone()] + [t.grad.clone() for t in params + srcs]
+    a, b = run(True), run(False)
+    for x, y, n in zip(a, b, ["hs", "level_embed", "offsets.weight", "linear1.bias"] + ["src%d" % i for i in range(4)]):
+        assert (x - y).abs().max() <= 1e-4 * max(y.abs().max().item(), 1e-6), n
