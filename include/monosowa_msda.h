@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 4
+#define MSDA_ABI_VERSION 5
 
 #define MSDA_E_NULLPTR (-1)   /* a required pointer is NULL                        */
 #define MSDA_E_SHAPE (-2)     /* a dimension is <= 0 or exceeds the indexing range */
@@ -120,6 +120,22 @@ int msda_fused_backward_f32(const float *value, const int64_t *shapes, const int
                             int B, int S, int M, int D, int L, int Lq, int P,
                             const int64_t *shapes_host, const int64_t *level_start_host,
                             void *workspace, size_t workspace_bytes, void *stream);
+
+/* ABI v5: the same two operators with row strides -- offsets_row_stride / logits_row_stride = floats between consecutive
+ * queries in `offsets` / `logits` (and, in the backward, in grad_offsets / grad_logits); M*32 / M*16 when contiguous,
+ * e.g. 384 / 384 when both are column blocks of one [B, Lq, 384] projection output (offsets | logits), which lets the
+ * module run sampling_offsets and attention_weights (ms_deform_attn.py:142-145) as ONE GEMM. */
+int msda_fused_forward_strided_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                                   const float *offsets, const float *logits, const float *ref, int ref_dim, float *out,
+                                   int B, int S, int M, int D, int L, int Lq, int P, int offsets_row_stride,
+                                   int logits_row_stride, const int64_t *shapes_host, const int64_t *level_start_host,
+                                   void *stream);
+int msda_fused_backward_strided_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                                    const float *offsets, const float *logits, const float *ref, int ref_dim,
+                                    const float *grad_out, float *grad_value, float *grad_offsets, float *grad_logits,
+                                    int B, int S, int M, int D, int L, int Lq, int P, int offsets_row_stride,
+                                    int logits_row_stride, const int64_t *shapes_host, const int64_t *level_start_host,
+                                    void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -76,7 +76,7 @@ int mono_dropout_add_layernorm_bwd_f32(const float *gy, const float *s, const fl
  * layer over tokens (autograd's `grad.sum(0)` for nn.Linear in the reference).  out is overwritten.
  * partials: scratch of mono_reduce_blocks(rows) * C floats. */
 int mono_colsum_f32(const float *g, float *out, float *partials, long long rows, int C, void *stream);
-/* The same over a [batch, rows, C] view with batch_stride floats between batches (C <= 256): sums of one pyramid level's
+/* The same over a [batch, rows, C] view with batch_stride floats between batches (C <= 512): sums of one pyramid level's
  * tokens over the batch (the level_embed gradient of the visual encoder, depthaware_transformer.py:232-240). */
 int mono_colsum_strided_f32(const float *g, float *out, float *partials, int batch, long long rows, long long batch_stride,
                             int C, void *stream);

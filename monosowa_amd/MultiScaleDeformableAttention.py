@@ -251,3 +251,57 @@ def install():
     """Register this module under the reference's import name."""
     sys.modules["MultiScaleDeformableAttention"] = sys.modules[__name__]
     return sys.modules[__name__]
+
+
+def ms_deform_attn_fused_forward_merged(value, spatial_shapes, level_start_index, proj, reference_points):
+    """Fused operator on ONE projection output ``proj`` [B, Lq, M*48] = (offsets M*32 | logits M*16) of a merged
+    sampling_offsets / attention_weights GEMM, read in place through row strides (msda_fused_forward_strided_f32)."""
+    B, S, M, D = value.shape
+    Lq = proj.shape[1]
+    L = P = 4
+    _assert(proj.is_contiguous() and proj.shape[2] == M * 48 and proj.dtype == torch.float32, "proj must be [B, Lq, M*48] float32")
+    geom = host_geometry(spatial_shapes, level_start_index)
+    out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    timer = LaunchTimer.active
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream()
+        if timer is not None:
+            e0, e1 = timer.bracket("fwd", (B, S, M, D, L, Lq, P))
+            e0.record(stream)
+        code = _lib.load().msda_fused_forward_strided_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
+            proj.data_ptr() + M * 32 * 4, reference_points.data_ptr(), reference_points.size(3), out.data_ptr(),
+            B, S, M, D, L, Lq, P, M * 48, M * 48, geom[0], geom[1], stream.cuda_stream)
+        if timer is not None:
+            e1.record(stream)
+    _lib.check(code, "ms_deform_attn_fused_forward_merged")
+    return out
+
+
+def ms_deform_attn_fused_backward_merged(value, spatial_shapes, level_start_index, proj, reference_points, grad_output):
+    """-> grad_value, grad_proj [B, Lq, M*48] (grad offsets | grad logits in the layout of ``proj``)."""
+    B, S, M, D = value.shape
+    Lq = proj.shape[1]
+    L = P = 4
+    _assert(grad_output.is_contiguous() and grad_output.numel() == B * Lq * M * D, "grad_output shape mismatch")
+    lib = _lib.load()
+    geom = host_geometry(spatial_shapes, level_start_index)
+    grad_value = torch.empty_like(value)
+    grad_proj = torch.empty_like(proj)
+    ws_bytes = lib.msda_backward_workspace_bytes(B, S, M, D, L, Lq, P, 4)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
+    timer = LaunchTimer.active
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream()
+        if timer is not None:
+            e0, e1 = timer.bracket("bwd", (B, S, M, D, L, Lq, P))
+            e0.record(stream)
+        code = lib.msda_fused_backward_strided_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(), proj.data_ptr() + M * 32 * 4,
+            reference_points.data_ptr(), reference_points.size(3), grad_output.data_ptr(), grad_value.data_ptr(),
+            grad_proj.data_ptr(), grad_proj.data_ptr() + M * 32 * 4, B, S, M, D, L, Lq, P, M * 48, M * 48, geom[0], geom[1],
+            ws.data_ptr(), ws_bytes, stream.cuda_stream)
+        if timer is not None:
+            e1.record(stream)
+    _lib.check(code, "ms_deform_attn_fused_backward_merged")
+    return grad_value, grad_proj

@@ -9,10 +9,11 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmonosowa_msda.so")
 # every symbol include/monosowa_msda.h declares
 SYMBOLS = ("msda_abi_version", "msda_strerror", "msda_set_option", "msda_backward_workspace_bytes",
            "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64",
-           "msda_fused_forward_f32", "msda_fused_backward_f32")
+           "msda_fused_forward_f32", "msda_fused_backward_f32", "msda_fused_forward_strided_f32",
+           "msda_fused_backward_strided_f32")
 
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class MSDALibraryError(RuntimeError):
@@ -47,6 +48,10 @@ def load():
     lib.msda_fused_forward_f32.argtypes = [P] * 6 + [I, P] + [I] * 7 + [P, P, P]
     lib.msda_fused_backward_f32.restype = I
     lib.msda_fused_backward_f32.argtypes = [P] * 6 + [I] + [P] * 4 + [I] * 7 + [P, P, P, Z, P]
+    lib.msda_fused_forward_strided_f32.restype = I
+    lib.msda_fused_forward_strided_f32.argtypes = [P] * 6 + [I, P] + [I] * 9 + [P, P, P]
+    lib.msda_fused_backward_strided_f32.restype = I
+    lib.msda_fused_backward_strided_f32.argtypes = [P] * 6 + [I] + [P] * 4 + [I] * 9 + [P, P, P, Z, P]
     if lib.msda_abi_version() != ABI_VERSION:
         raise MSDALibraryError("ABI version mismatch in %s" % LIB_PATH)
     _lib = lib

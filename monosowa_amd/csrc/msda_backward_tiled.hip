@@ -85,7 +85,7 @@ __global__ __launch_bounds__(1024) void bwd_prep_kernel(
     const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out,
     const int64_t *__restrict__ shapes, float2 *__restrict__ rec_hw, float *__restrict__ rec_aw,
     ChunkBox *__restrict__ boxes, const float *__restrict__ ref, int ref_dim, int M, int L, int Lq,
-    int n_chunks_per_list) {
+    int n_chunks_per_list, int loc_rs, int aw_rs) {
   static_assert(P == 4, "one float4 of attention weights / two float4 of locations per (query, head, level)");
   const int chunk = blockIdx.x % n_chunks_per_list;
   const long long b = blockIdx.x / n_chunks_per_list;
@@ -102,11 +102,12 @@ __global__ __launch_bounds__(1024) void bwd_prep_kernel(
     const int q = chunk * 16 + 2 * j + k;
     if (q >= Lq) continue;
     const long long pair = (b * Lq + q) * M + m;
-    const float *lp = loc + (pair * L + l) * P * 2;
+    const long long q_lin = b * Lq + q;                              // loc_rs / aw_rs: floats per query row (see gather_rec_kernel)
+    const float *lp = loc + q_lin * loc_rs + (m * L + l) * P * 2;
     float4 xy01 = ld4(lp), xy23 = ld4(lp + 4);
-    float4 aw = ld4(attw + (pair * L + l) * P);
+    float4 aw = ld4(attw + q_lin * aw_rs + (m * L + l) * P);
     if (FUSED) {
-      const float *lg = attw + pair * L * P;                       // the pair's 16 logits
+      const float *lg = attw + q_lin * aw_rs + m * L * P;          // the pair's 16 logits
       float mx = -INFINITY;
 #pragma unroll
       for (int i = 0; i < 16; ++i) mx = fmaxf(mx, lg[i]);

@@ -100,7 +100,9 @@ inline int gather_mode() { return options().gather; }
 template <bool BWD, bool FUSED>
 void launch_gather(const float *value, const float *loc, const float *attw, const float *grad_out, float *out,
                    float *grad_loc, float *grad_attw, const float *ref, int ref_dim, const int64_t *shapes_host,
-                   const int64_t *lsi_host, int B, int S, int M, int Lq, hipStream_t stream) {
+                   const int64_t *lsi_host, int B, int S, int M, int Lq, hipStream_t stream, int loc_rs = 0, int aw_rs = 0) {
+  if (!loc_rs) loc_rs = M * 32;
+  if (!aw_rs) aw_rs = M * 16;
   msda::GatherGeom geom;
   const long long n_pairs = (long long)B * Lq * M;
   const bool staged = make_gather_geom(shapes_host, lsi_host, B, M, Lq, S, geom) && gather_mode() > 1;
@@ -108,11 +110,11 @@ void launch_gather(const float *value, const float *loc, const float *attw, cons
     const int bm_groups = (B * M + 7) / 8;
     msda::gather_rec_kernel<BWD, true, FUSED>
         <<<8 * geom.n_chunks * bm_groups, BWD ? msda::kStagedThreadsBwd : msda::kStagedThreadsFwd, 0, stream>>>(
-            value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, geom, B, S, M, Lq, n_pairs);
+            value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, geom, B, S, M, Lq, n_pairs, loc_rs, aw_rs);
   } else {
     geom.first_lds_level = 4;
     msda::gather_rec_kernel<BWD, false, FUSED><<<grid_pairs(n_pairs), msda::kPlainThreads, 0, stream>>>(
-        value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, geom, B, S, M, Lq, n_pairs);
+        value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, geom, B, S, M, Lq, n_pairs, loc_rs, aw_rs);
   }
 }
 
@@ -208,7 +210,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
                   const T *attw, const T *grad_out, T *grad_value, T *grad_loc, T *grad_attw,
                   int B, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
                   const int64_t *lsi_host, void *workspace, size_t workspace_bytes, void *stream_,
-                  const float *fused_ref = nullptr, int fused_ref_dim = 0) {
+                  const float *fused_ref = nullptr, int fused_ref_dim = 0, int loc_rs = 0, int aw_rs = 0) {
   if (!value || !shapes || !lsi || !loc || !attw || !grad_out || !grad_value || !grad_loc || !grad_attw)
     return MSDA_E_NULLPTR;
   if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
@@ -247,10 +249,11 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       float *bounds = reinterpret_cast<float *>(wsp + ws.off_bounds);
       if (fused_ref)
         msda::bwd_prep_kernel<4, true><<<(unsigned)(B * ws.n_chunks_per_list), M * L * 8, 0, stream>>>(
-            loc, attw, grad_out, shapes, rec_hw, rec_aw, boxes, fused_ref, fused_ref_dim, M, L, Lq, (int)ws.n_chunks_per_list);
+            loc, attw, grad_out, shapes, rec_hw, rec_aw, boxes, fused_ref, fused_ref_dim, M, L, Lq, (int)ws.n_chunks_per_list,
+            loc_rs ? loc_rs : M * 32, aw_rs ? aw_rs : M * 16);
       else
         msda::bwd_prep_kernel<4, false><<<(unsigned)(B * ws.n_chunks_per_list), M * L * 8, 0, stream>>>(
-            loc, attw, grad_out, shapes, rec_hw, rec_aw, boxes, nullptr, 0, M, L, Lq, (int)ws.n_chunks_per_list);
+            loc, attw, grad_out, shapes, rec_hw, rec_aw, boxes, nullptr, 0, M, L, Lq, (int)ws.n_chunks_per_list, M * 32, M * 16);
       msda::bwd_bounds_kernel<<<B * M, 256, 0, stream>>>(boxes, bounds, (int)(L * ws.n_chunks_per_list));
       // levels shared by several workgroups are accumulated with atomics: zero exactly those rows
       for (int l = 0; l < L; ++l) {
@@ -274,7 +277,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       if (gather_mode() > 0 || fused_ref) {
         if (fused_ref)
           launch_gather<true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
-                                    shapes_host, lsi_host, B, S, M, Lq, stream);
+                                    shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs);
         else
           launch_gather<true, false>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, nullptr, 0, shapes_host,
                                      lsi_host, B, S, M, Lq, stream);
@@ -360,8 +363,23 @@ int msda_fused_forward_f32(const float *value, const int64_t *shapes, const int6
     return MSDA_E_NULLPTR;
   if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
   if (!(D == 32 && L == 4 && P == 4) || (ref_dim != 2 && ref_dim != 6)) return MSDA_E_UNSUPPORTED;
+  return msda_fused_forward_strided_f32(value, shapes, level_start, offsets, logits, ref, ref_dim, out, B, S, M, D, L, Lq, P,
+                                        M * 32, M * 16, shapes_host, level_start_host, stream);
+}
+
+int msda_fused_forward_strided_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                                   const float *offsets, const float *logits, const float *ref, int ref_dim, float *out,
+                                   int B, int S, int M, int D, int L, int Lq, int P, int offsets_row_stride,
+                                   int logits_row_stride, const int64_t *shapes_host, const int64_t *level_start_host,
+                                   void *stream) {
+  if (!value || !shapes || !level_start || !offsets || !logits || !ref || !out || !shapes_host || !level_start_host)
+    return MSDA_E_NULLPTR;
+  if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
+  if (!(D == 32 && L == 4 && P == 4) || (ref_dim != 2 && ref_dim != 6)) return MSDA_E_UNSUPPORTED;
+  if (offsets_row_stride < M * 32 || logits_row_stride < M * 16 || (offsets_row_stride & 3) || (logits_row_stride & 3))
+    return MSDA_E_SHAPE;
   launch_gather<false, true>(value, offsets, logits, nullptr, out, nullptr, nullptr, ref, ref_dim, shapes_host,
-                             level_start_host, B, S, M, Lq, (hipStream_t)stream);
+                             level_start_host, B, S, M, Lq, (hipStream_t)stream, offsets_row_stride, logits_row_stride);
   return (int)hipGetLastError();
 }
 
@@ -370,11 +388,24 @@ int msda_fused_backward_f32(const float *value, const int64_t *shapes, const int
                             const float *grad_out, float *grad_value, float *grad_offsets, float *grad_logits,
                             int B, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
                             const int64_t *level_start_host, void *workspace, size_t workspace_bytes, void *stream) {
+  return msda_fused_backward_strided_f32(value, shapes, level_start, offsets, logits, ref, ref_dim, grad_out, grad_value,
+                                         grad_offsets, grad_logits, B, S, M, D, L, Lq, P, M * 32, M * 16, shapes_host,
+                                         level_start_host, workspace, workspace_bytes, stream);
+}
+
+int msda_fused_backward_strided_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                                    const float *offsets, const float *logits, const float *ref, int ref_dim,
+                                    const float *grad_out, float *grad_value, float *grad_offsets, float *grad_logits,
+                                    int B, int S, int M, int D, int L, int Lq, int P, int offsets_row_stride,
+                                    int logits_row_stride, const int64_t *shapes_host, const int64_t *level_start_host,
+                                    void *workspace, size_t workspace_bytes, void *stream) {
   if (!ref || !shapes_host || !level_start_host) return MSDA_E_NULLPTR;
   if (!(D == 32 && L == 4 && P == 4) || (ref_dim != 2 && ref_dim != 6) || M * L * 8 > 1024) return MSDA_E_UNSUPPORTED;
+  if (offsets_row_stride < M * 32 || logits_row_stride < M * 16 || (offsets_row_stride & 3) || (logits_row_stride & 3))
+    return MSDA_E_SHAPE;
   return backward_impl<float>(value, shapes, level_start, offsets, logits, grad_out, grad_value, grad_offsets,
                               grad_logits, B, S, M, D, L, Lq, P, shapes_host, level_start_host, workspace,
-                              workspace_bytes, stream, ref, ref_dim);
+                              workspace_bytes, stream, ref, ref_dim, offsets_row_stride, logits_row_stride);
 }
 
 int msda_backward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,

@@ -56,7 +56,9 @@ void gather_rec_kernel(
     const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attw,
     const float *__restrict__ grad_out, float *__restrict__ out, float *__restrict__ grad_loc,
     float *__restrict__ grad_attw, const float *__restrict__ ref, int ref_dim, const GatherGeom g, int B, int S,
-    int M, int Lq, long long n_pairs) {
+    int M, int Lq, long long n_pairs, int loc_rs, int aw_rs) {
+  // loc_rs / aw_rs: floats between consecutive queries in loc / attw (and their gradients): M*32 / M*16 when contiguous;
+  // larger when both live in one [B, Lq, 384] buffer (offsets | logits of a merged projection)
   constexpr int kThreads = STAGED ? (BWD ? kStagedThreadsBwd : kStagedThreadsFwd) : kPlainThreads;
   constexpr int kWaves = kThreads / 64;
   constexpr int kRecF4 = BWD ? 4 : 2;                          // float4 slots per record
@@ -99,8 +101,10 @@ void gather_rec_kernel(
     const int b = (int)(pair / ((long long)M * Lq));
     const float *vb = value + ((long long)b * S * M + m) * 32 + sub * 4;      // + corner offset
     const float *sb = staged + sub * 4;
-    float4 lc = ld4(loc + pair * 32 + sub * 4);                               // points 2*sub, 2*sub+1: x,y,x,y
-    float2 aw = *reinterpret_cast<const float2 *>(attw + pair * 16 + sub * 2);
+    const long long q_lin = pair / M;
+    const long long loc_at = q_lin * loc_rs + m * 32 + sub * 4, aw_at = q_lin * aw_rs + m * 16 + sub * 2;
+    float4 lc = ld4(loc + loc_at);                                            // points 2*sub, 2*sub+1: x,y,x,y
+    float2 aw = *reinterpret_cast<const float2 *>(attw + aw_at);
     float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
     if (BWD) go = ld4(grad_out + pair * 32 + sub * 4);
 
@@ -226,8 +230,8 @@ void gather_rec_kernel(
         out_loc = make_float4(offset_grad<4>(out_loc.x, rs.sx, ref_dim), offset_grad<4>(out_loc.y, rs.sy, ref_dim),
                               offset_grad<4>(out_loc.z, rs.sx, ref_dim), offset_grad<4>(out_loc.w, rs.sy, ref_dim));
       }
-      st4(grad_loc + pair * 32 + sub * 4, out_loc);
-      *reinterpret_cast<float2 *>(grad_attw + pair * 16 + sub * 2) = out_aw;
+      st4(grad_loc + loc_at, out_loc);
+      *reinterpret_cast<float2 *>(grad_attw + aw_at) = out_aw;
     }
     wave_lds_order();          // records are rewritten by the next iteration
   }

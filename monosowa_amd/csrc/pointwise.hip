@@ -502,12 +502,13 @@ int mono_colsum_f32(const float *g, float *out, float *partials, long long rows,
 int mono_colsum_strided_f32(const float *g, float *out, float *partials, int batch, long long rows, long long batch_stride,
                             int C, void *stream_) {
   if (!g || !out || !partials) return -1;
-  if (batch <= 0 || rows <= 0 || C <= 0 || C % 4 || C > 256 || batch_stride % 4) return -2;
+  if (batch <= 0 || rows <= 0 || C <= 0 || C % 4 || C > 512 || batch_stride % 4) return -2;
   hipStream_t st = (hipStream_t)stream_;
   const long long total = (long long)batch * rows;
   const int grid = mono_reduce_blocks(total);
   const int rpb = (int)((total + grid - 1) / grid + 63) / 64 * 64;
-  mono::colsum_kernel<1><<<grid, 256, 0, st>>>(g, partials, total, C, rpb, rows, batch_stride);
+  if (C <= 256) mono::colsum_kernel<1><<<grid, 256, 0, st>>>(g, partials, total, C, rpb, rows, batch_stride);
+  else mono::colsum_kernel<2><<<grid, 256, 0, st>>>(g, partials, total, C, rpb, rows, batch_stride);
   mono::partial_sum_kernel<<<(C / 4 + 63) / 64, 1024, 0, st>>>(partials, out, grid, C);
   return (int)hipGetLastError();
 }

@@ -16,6 +16,9 @@ from .pointwise import colsum, colsum_levels, ln_backward, ln_forward, relu_drop
 from .token_linear import weight_grad
 
 
+MERGED_PROJ = True      # sampling_offsets and attention_weights as one 384-wide GEMM read in place by the strided operator
+
+
 class _AttnBlock(torch.autograd.Function):
     """LayerNorm(src + dropout(output_proj(MSDA(value_proj(src), offsets(q), logits(q), ref))))"""
 
@@ -32,19 +35,28 @@ class _AttnBlock(torch.autograd.Function):
         if level_embed is not None:
             q = src + q
         v = F.linear(src, wv, bv).view(N, S, M, D)
-        off = F.linear(q, wo, bo).view(N, S, M, L, P, 2)
-        logit = F.linear(q, wa, ba).view(N, S, M, L * P)
-        a = MSDA.ms_deform_attn_fused_forward(v, shapes, lsi, off, logit, ref)
+        ctx.merged = MERGED_PROJ and L == 4 and P == 4 and D == 32
+        if ctx.merged:
+            # one GEMM for both projections of q; the operator reads (offsets | logits) in place through row strides
+            w_ol, b_ol = torch.cat([wo, wa]), torch.cat([bo, ba])
+            proj = F.linear(q, w_ol, b_ol)                                        # [N, S, M*48]
+            a = MSDA.ms_deform_attn_fused_forward_merged(v, shapes, lsi, proj, ref)
+            off = logit = None
+        else:
+            off = F.linear(q, wo, bo).view(N, S, M, L, P, 2)
+            logit = F.linear(q, wa, ba).view(N, S, M, L * P)
+            a = MSDA.ms_deform_attn_fused_forward(v, shapes, lsi, off, logit, ref)
+            proj = w_ol = None
         z = F.linear(a, wp, bp)
         y, s, mean, rstd, seed = ln_forward(src, z, gamma, beta, p, eps)
-        ctx.save_for_backward(src, q, ref, shapes, lsi, v, off, logit, a, s, mean, rstd, wv, wo, wa, wp, gamma)
+        ctx.save_for_backward(src, q, ref, shapes, lsi, v, off, logit, proj, w_ol, a, s, mean, rstd, wv, wo, wa, wp, gamma)
         ctx.p, ctx.seed = p, seed
         ctx.host_geom = MSDA.host_geometry(shapes, lsi)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        src, q, ref, shapes, lsi, v, off, logit, a, s, mean, rstd, wv, wo, wa, wp, gamma = ctx.saved_tensors
+        src, q, ref, shapes, lsi, v, off, logit, proj, w_ol, a, s, mean, rstd, wv, wo, wa, wp, gamma = ctx.saved_tensors
         C = src.shape[-1]
         sh, ls = ctx.host_geom                                 # the saved pyramid tensors may come back as new objects
         MSDA.attach_host_geometry(shapes, lsi, [(int(sh[2 * i]), int(sh[2 * i + 1])) for i in range(len(ls))], [int(x) for x in ls])
@@ -52,24 +64,41 @@ class _AttnBlock(torch.autograd.Function):
         gz2 = gz.view(-1, C)
         ga = (gz2 @ wp).view_as(a)
         gwp, gbp = weight_grad(gz2, a.view(-1, C)), colsum(gz2)
-        gv, goff, glogit = MSDA.ms_deform_attn_fused_backward(v, shapes, lsi, off, logit, ref, ga.contiguous())
-        gv2, goff2, glogit2 = gv.view(-1, C), goff.view(-1, wo.shape[0]), glogit.view(-1, wa.shape[0])
-        gx.view(-1, C).addmm_(gv2, wv)                       # d src: residual + value path, no separate add pass
         src2, q2 = src.reshape(-1, C), q.reshape(-1, C)
+        n_off = wo.shape[0]
+        if ctx.merged:
+            gv, gproj = MSDA.ms_deform_attn_fused_backward_merged(v, shapes, lsi, proj, ref, ga.contiguous())
+            gp2 = gproj.view(-1, gproj.shape[-1])
+            gw_ol, gb_ol = weight_grad(gp2, q2), colsum(gp2)
+            gwo, gwa, gbo, gba = gw_ol[:n_off], gw_ol[n_off:], gb_ol[:n_off], gb_ol[n_off:]
+        else:
+            gv, goff, glogit = MSDA.ms_deform_attn_fused_backward(v, shapes, lsi, off, logit, ref, ga.contiguous())
+            goff2, glogit2 = goff.view(-1, n_off), glogit.view(-1, wa.shape[0])
+            gwo, gbo, gwa, gba = weight_grad(goff2, q2), colsum(goff2), weight_grad(glogit2, q2), colsum(glogit2)
+        gv2 = gv.view(-1, C)
+        gx2 = gx.view(-1, C)
+        gx2.addmm_(gv2, wv)                                  # d src: residual + value path, no separate add pass
         g_level = gq = None
         if ctx.levels is not None:
             # q = src + pos with constant pos: d q lands in d src directly; d level_embed[l] = (sum of d offsets over the
             # level's tokens) @ Wo + (sum of d logits) @ Wa
-            gx.view(-1, C).addmm_(goff2, wo)
-            gx.view(-1, C).addmm_(glogit2, wa)
-            g_level = colsum_levels(goff.view(goff.shape[0], goff.shape[1], -1), ctx.levels) @ wo \
-                + colsum_levels(glogit.view(glogit.shape[0], glogit.shape[1], -1), ctx.levels) @ wa
+            if ctx.merged:
+                gx2.addmm_(gp2, w_ol)
+                g_level = colsum_levels(gproj, ctx.levels) @ w_ol
+            else:
+                gx2.addmm_(goff2, wo)
+                gx2.addmm_(glogit2, wa)
+                g_level = colsum_levels(goff.view(goff.shape[0], goff.shape[1], -1), ctx.levels) @ wo \
+                    + colsum_levels(glogit.view(glogit.shape[0], glogit.shape[1], -1), ctx.levels) @ wa
         else:
-            gq = (goff2 @ wo)
-            gq.addmm_(glogit2, wa)                           # d q: offsets + attention-weight paths
-            gq = gq.view_as(q)
-        return (gx, gq, None, None, None, weight_grad(gv2, src2), colsum(gv2), weight_grad(goff2, q2), colsum(goff2),
-                weight_grad(glogit2, q2), colsum(glogit2), gwp, gbp, ggamma, gbeta, None, None, None, None, None, g_level, None)
+            if ctx.merged:
+                gq = (gp2 @ w_ol).view_as(q)
+            else:
+                gq = (goff2 @ wo)
+                gq.addmm_(glogit2, wa)                       # d q: offsets + attention-weight paths
+                gq = gq.view_as(q)
+        return (gx, gq, None, None, None, weight_grad(gv2, src2), colsum(gv2), gwo, gbo, gwa, gba, gwp, gbp, ggamma, gbeta,
+                None, None, None, None, None, g_level, None)
 
 
 class _FFNBlock(torch.autograd.Function):

@@ -342,11 +342,14 @@ def colsum_levels(g3, bounds):
     return out
 
 
+COLSUM_MAX_C = 512     # wider matrices: the PyTorch reduction is as fast
+
+
 def colsum(g2):
     """``g2.sum(0)`` of a [rows, C] matrix (bias gradients); HIP kernel for contiguous float32 GPU input with
-    C % 4 == 0 and C <= 256 (wider matrices: the PyTorch reduction is as fast), torch otherwise."""
+    C % 4 == 0 and C <= 512 (wider matrices: the PyTorch reduction is as fast), torch otherwise."""
     if g2.is_cuda and g2.dtype == torch.float32 and g2.dim() == 2 and g2.is_contiguous() and g2.size(1) % 4 == 0 \
-            and g2.size(1) <= 256 and g2.size(0) > 0 and g2.data_ptr() % 16 == 0:
+            and g2.size(1) <= COLSUM_MAX_C and g2.size(0) > 0 and g2.data_ptr() % 16 == 0:
         out = torch.empty(g2.size(1), dtype=torch.float32, device=g2.device)
         partials = torch.empty(load().mono_reduce_blocks(g2.size(0)) * g2.size(1), dtype=torch.float32, device=g2.device)
         with torch.cuda.device(g2.device):

@@ -874,3 +874,32 @@ def test_level_embed_gradient_from_the_encoder_blocks():
     a, b = run(True), run(False)
     for x, y, n in zip(a, b, ["hs", "level_embed", "offsets.weight", "linear1.bias"] + ["src%d" % i for i in range(4)]):
         assert (x - y).abs().max() <= 1e-4 * max(y.abs().max().item(), 1e-6), n
+
+
+def test_strided_fused_operator_reads_a_merged_projection_in_place():
+    """msda_fused_*_strided_f32 (ABI v5): offsets | logits as column blocks of one [B, Lq, 384] buffer give the same
+    output and gradients as the contiguous fused operator on the split tensors (bitwise: same kernels, other addresses)."""
+    MSDA = _msda()
+    torch.manual_seed(9)
+    levels = [(12, 40), (6, 20), (3, 10), (2, 5)]
+    B, M, D, L, P, Lq = 2, 8, 32, 4, 4, 333
+    shapes = torch.tensor(levels, dtype=torch.long, device="cuda")
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    starts = [0]
+    for h, w in levels[:-1]:
+        starts.append(starts[-1] + h * w)
+    MSDA.attach_host_geometry(shapes, lsi, levels, starts)
+    S = int(shapes.prod(1).sum())
+    value = torch.randn(B, S, M, D, device="cuda")
+    proj = torch.randn(B, Lq, M * 48, device="cuda")
+    ref = torch.rand(B, Lq, L, 2, device="cuda")
+    go = torch.randn(B, Lq, M * D, device="cuda")
+    off = proj[..., :M * 32].contiguous().view(B, Lq, M, L, P, 2)
+    logit = proj[..., M * 32:].contiguous().view(B, Lq, M, L * P)
+    out_m = MSDA.ms_deform_attn_fused_forward_merged(value, shapes, lsi, proj, ref)
+    out_s = MSDA.ms_deform_attn_fused_forward(value, shapes, lsi, off, logit, ref)
+    assert torch.equal(out_m, out_s)
+    gv_m, gp = MSDA.ms_deform_attn_fused_backward_merged(value, shapes, lsi, proj, ref, go)
+    gv_s, goff, glog = MSDA.ms_deform_attn_fused_backward(value, shapes, lsi, off, logit, ref, go)
+    assert torch.equal(gv_m, gv_s)
+    assert torch.equal(gp[..., :M * 32], goff.view(B, Lq, -1)) and torch.equal(gp[..., M * 32:], glog.view(B, Lq, -1))
