@@ -22,6 +22,9 @@ def _is_power_of_2(n):
     return (n & (n - 1) == 0) and n != 0
 
 
+MERGED_PROJ = True     # offsets + logits projections as one GEMM in front of the strided fused operator
+
+
 class MSDeformAttn(nn.Module):
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
         super().__init__()
@@ -79,6 +82,17 @@ class MSDeformAttn(nn.Module):
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        if self.fuse_prologue and MERGED_PROJ and self.n_levels == 4 and self.n_points == 4 and self.d_model == 32 * self.n_heads \
+                and query.is_cuda and query.dtype == torch.float32 and not reference_points.requires_grad \
+                and reference_points.shape[-1] in (2, 6) and geom is not None \
+                and _func.MSDeformAttnFunction.__module__ == _func.__name__:
+            # sampling_offsets and attention_weights as ONE GEMM; the operator reads (offsets | logits) in place
+            w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight])
+            b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias])
+            proj = F.linear(query, w, b)
+            output = _func.MSDeformAttnFusedMergedFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
+                                                                 proj, reference_points.contiguous())
+            return token_linear(output, self.output_proj)
         sampling_offsets = token_linear(query, self.sampling_offsets).view(
             N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
         attention_weights = token_linear(query, self.attention_weights).view(

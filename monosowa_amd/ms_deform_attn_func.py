@@ -58,6 +58,26 @@ class MSDeformAttnFusedFunction(Function):
         return gv, None, None, goff, glog, None
 
 
+class MSDeformAttnFusedMergedFunction(Function):
+    """The fused operator on one merged projection output ``proj`` [B, Lq, M*48] = (sampling offsets | attention logits),
+    read and differentiated in place through row strides (msda_fused_*_strided_f32)."""
+
+    @staticmethod
+    def forward(ctx, value, spatial_shapes, level_start_index, proj, reference_points):
+        output = MSDA.ms_deform_attn_fused_forward_merged(value, spatial_shapes, level_start_index, proj, reference_points)
+        ctx.save_for_backward(value, spatial_shapes, level_start_index, proj, reference_points)
+        ctx.host_geom = MSDA.host_geometry(spatial_shapes, level_start_index)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, proj, ref = ctx.saved_tensors
+        MSDA.attach_host_geometry(shapes, lsi, *_unpack_geom(ctx.host_geom))
+        gv, gproj = MSDA.ms_deform_attn_fused_backward_merged(value, shapes, lsi, proj, ref, grad_output.contiguous())
+        return gv, None, None, gproj, None
+
+
 def _unpack_geom(geom):
     sh, ls = geom
     L = len(ls)
