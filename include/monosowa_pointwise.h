@@ -24,6 +24,13 @@ int mono_bias_relu_mask_f32(float *y, const float *bias, const float *residual, 
 int mono_relu_grad_mask_f32(const float *grad_a, const float *grad_b, const unsigned char *mask, float *grad_in, long long n,
                             void *stream);
 
+/* Frozen batch-norm + ReLU after a convolution without residual, applied here instead of folded into the weights
+ * (backbone.py:28-65): y = relu(y * scale[c] + shift[c]) in place + byte mask; grad_in = grad * mask * scale[c]. */
+int mono_affine_relu_mask_f32(float *y, const float *scale, const float *shift, unsigned char *mask, long long rows, int C,
+                              void *stream);
+int mono_affine_relu_grad_f32(const float *grad, const unsigned char *mask, const float *scale, float *grad_in, long long rows,
+                              int C, void *stream);
+
 /* grad_in = (grad_a + grad_b) * (y > 0): ReLU backward of a tensor with two consumers (ResNet block output -> next
  * convolution and identity branch, backbone.py:64-82 of the reference's torchvision ResNet) in one pass. */
 int mono_relu_grad2_f32(const float *grad_a, const float *grad_b, const float *y, float *grad_in, long long n, void *stream);

@@ -65,6 +65,34 @@ __global__ __launch_bounds__(256) void relu_grad_mask_kernel(const float *__rest
   }
 }
 
+// The affine form for convolutions WITHOUT a residual: y = relu(y * scale[c] + shift[c]) (frozen batch-norm applied here
+// instead of folded into the weights: no per-step weight multiply and no multiply in the weight's backward), byte mask as
+// above; backward grad_in = grad * mask * scale[c].
+__global__ __launch_bounds__(256) void affine_relu_mask_kernel(float *__restrict__ y, const float *__restrict__ scale,
+                                                               const float *__restrict__ shift, unsigned char *__restrict__ mask,
+                                                               long long n_vec, int c_vec) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    float4 v = reinterpret_cast<float4 *>(y)[i];
+    const float4 a = reinterpret_cast<const float4 *>(scale)[i % c_vec], b = reinterpret_cast<const float4 *>(shift)[i % c_vec];
+    v.x = v.x * a.x + b.x; v.y = v.y * a.y + b.y; v.z = v.z * a.z + b.z; v.w = v.w * a.w + b.w;
+    mask[i] = (unsigned char)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    reinterpret_cast<float4 *>(y)[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void affine_relu_grad_kernel(const float *__restrict__ g, const unsigned char *__restrict__ mask,
+                                                               const float *__restrict__ scale, float *__restrict__ grad_in,
+                                                               long long n_vec, int c_vec) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    const float4 a = reinterpret_cast<const float4 *>(g)[i], sc = reinterpret_cast<const float4 *>(scale)[i % c_vec];
+    const unsigned m = mask[i];
+    reinterpret_cast<float4 *>(grad_in)[i] = make_float4((m & 1u) ? a.x * sc.x : 0.f, (m & 2u) ? a.y * sc.y : 0.f,
+                                                         (m & 4u) ? a.z * sc.z : 0.f, (m & 8u) ? a.w * sc.w : 0.f);
+  }
+}
+
 // grad_in = grad_out * (y > 0), optionally also written to a second buffer (the residual branch's gradient)
 __global__ __launch_bounds__(256) void relu_grad_kernel(const float *__restrict__ grad_out, const float *__restrict__ y,
                                                         float *__restrict__ grad_in, long long n_vec) {
@@ -352,6 +380,24 @@ int mono_bias_relu_mask_f32(float *y, const float *bias, const float *residual, 
   const int g = mono::grid_for_vec(n_vec);
   if (residual) mono::bias_relu_mask_kernel<true><<<g, 256, 0, (hipStream_t)stream_>>>(y, bias, residual, mask, n_vec, C / 4);
   else mono::bias_relu_mask_kernel<false><<<g, 256, 0, (hipStream_t)stream_>>>(y, bias, nullptr, mask, n_vec, C / 4);
+  return (int)hipGetLastError();
+}
+
+// y = relu(y * scale[c] + shift[c]) in place + byte mask; backward: grad_in = grad * mask * scale[c]   ([rows, C], C % 4 == 0)
+int mono_affine_relu_mask_f32(float *y, const float *scale, const float *shift, unsigned char *mask, long long rows, int C,
+                              void *stream_) {
+  if (!y || !scale || !shift || !mask) return -1;
+  if (rows <= 0 || C <= 0 || (C & 3) || ((uintptr_t)y & 15) || ((uintptr_t)scale & 15) || ((uintptr_t)shift & 15)) return -2;
+  const long long n_vec = rows * C / 4;
+  mono::affine_relu_mask_kernel<<<mono::grid_for_vec(n_vec), 256, 0, (hipStream_t)stream_>>>(y, scale, shift, mask, n_vec, C / 4);
+  return (int)hipGetLastError();
+}
+int mono_affine_relu_grad_f32(const float *grad, const unsigned char *mask, const float *scale, float *grad_in, long long rows,
+                              int C, void *stream_) {
+  if (!grad || !mask || !scale || !grad_in) return -1;
+  if (rows <= 0 || C <= 0 || (C & 3) || ((uintptr_t)grad & 15) || ((uintptr_t)scale & 15) || ((uintptr_t)grad_in & 15)) return -2;
+  const long long n_vec = rows * C / 4;
+  mono::affine_relu_grad_kernel<<<mono::grid_for_vec(n_vec), 256, 0, (hipStream_t)stream_>>>(grad, mask, scale, grad_in, n_vec, C / 4);
   return (int)hipGetLastError();
 }
 

@@ -16,11 +16,12 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..pointwise import bias_act, bias_act_fork
+from ..pointwise import affine_relu, affine_relu_supported, bias_act, bias_act_fork
 from .misc import NestedTensor
 from .position_encoding import build_position_encoding
 
 
+AFFINE_IN_KERNEL = True      # frozen-BN affine map inside the ReLU kernels for residual-free trainable convolutions
 CACHE_SCALE_SHIFT = True
 
 
@@ -108,6 +109,13 @@ def conv_bn(x, conv, bn, residual=None, relu=True):
     an add pass and a ReLU pass)."""
     if isinstance(bn, FrozenBatchNorm2d):
         scale, shift = bn.scale_shift()
+        if AFFINE_IN_KERNEL and relu and residual is None and conv.weight.requires_grad and torch.is_grad_enabled() and x.is_cuda:
+            # trainable convolution without residual: raw weights, the BN affine map runs inside the ReLU kernels
+            # (forward y*scale+shift, backward grad*mask*scale) -- no weight multiply per step, none in the backward
+            y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if affine_relu_supported(y, scale):
+                return affine_relu(y, scale, shift)
+            return torch.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
         y = F.conv2d(x, folded_weight(conv, bn, scale), None, conv.stride, conv.padding, conv.dilation, conv.groups)
         return bias_act(y, shift, residual, relu)
     y = bn(conv(x))

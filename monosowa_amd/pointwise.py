@@ -6,7 +6,7 @@ import os
 import torch
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
-SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_dropout_add_layernorm_fwd_f32",
+SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32")
 _lib = None
@@ -27,6 +27,10 @@ def load():
         lib.mono_bias_relu_mask_f32.argtypes = [P, P, P, P, LL, I, P]
         lib.mono_relu_grad_mask_f32.restype = I
         lib.mono_relu_grad_mask_f32.argtypes = [P, P, P, P, LL, P]
+        lib.mono_affine_relu_mask_f32.restype = I
+        lib.mono_affine_relu_mask_f32.argtypes = [P, P, P, P, LL, I, P]
+        lib.mono_affine_relu_grad_f32.restype = I
+        lib.mono_affine_relu_grad_f32.argtypes = [P, P, P, P, LL, I, P]
         lib.mono_relu_grad2_f32.restype = I
         lib.mono_relu_grad2_f32.argtypes = [P, P, P, P, LL, P]
         U, F = ctypes.c_ulonglong, ctypes.c_float
@@ -111,6 +115,44 @@ class _BiasAct(torch.autograd.Function):
             g = grad
         gb = g.sum((0, 2, 3)) if ctx.bias_grad else None
         return g, gb, (g if ctx.has_res else None), None
+
+
+class _AffineRelu(torch.autograd.Function):
+    """relu(y * scale[c] + shift[c]) in place (frozen BN + ReLU after a convolution without residual)."""
+
+    @staticmethod
+    def forward(ctx, y, scale, shift):
+        rows, C = y.numel() // y.size(1), y.size(1)
+        mask = torch.empty(y.numel() // 4, dtype=torch.uint8, device=y.device)
+        with torch.cuda.device(y.device):
+            code = load().mono_affine_relu_mask_f32(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), mask.data_ptr(), rows, C,
+                                                    torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_affine_relu_mask_f32 failed with code %d" % code)
+        ctx.mark_dirty(y)
+        ctx.save_for_backward(mask, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        mask, scale = ctx.saved_tensors
+        grad = grad.contiguous(memory_format=torch.channels_last)
+        g = torch.empty_like(grad, memory_format=torch.channels_last)
+        with torch.cuda.device(grad.device):
+            code = load().mono_affine_relu_grad_f32(grad.data_ptr(), mask.data_ptr(), scale.data_ptr(), g.data_ptr(),
+                                                    grad.numel() // grad.size(1), grad.size(1), torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_affine_relu_grad_f32 failed with code %d" % code)
+        return g, None, None
+
+
+def affine_relu_supported(y, scale):
+    return _nhwc_ok(y) and y.requires_grad and torch.is_grad_enabled() and scale.is_cuda and scale.dtype == torch.float32 \
+        and scale.data_ptr() % 16 == 0 and not scale.requires_grad
+
+
+def affine_relu(y, scale, shift):
+    return _AffineRelu.apply(y, scale.contiguous(), shift.contiguous())
 
 
 class _BiasActFork(torch.autograd.Function):
