@@ -27,6 +27,7 @@ from ..token_linear import token_linear
 
 LEVEL_EMBED_IN_BLOCK = True   # level_embed gradient from per-level sums inside the encoder blocks (constant pos tensor)
 ENCODER_BLOCKS = True     # encoder layers as two autograd nodes whose GEMMs accumulate shared gradients in place
+MERGE_HEADS = False       # bbox + dim heads inside the decoder loop as one GEMM: measured neutral (tools/ab_step.py), off
 MERGE_SA_PROJ = True      # decoder self-attention: content + positional projections as one GEMM (same input)
 SELF_ATTN_HIP = True      # decoder self-attention (50 queries per group) through the HIP attention core (-0.27 ms/step, tools/ab_step.py)
 
@@ -46,6 +47,23 @@ class MLP(nn.Module):
             if i < self.num_layers - 1:
                 x = F.relu(x)
         return x
+
+    def forward_from_first(self, h):
+        """The rest of the stack given ``h = layers[0](x)`` (see ``merged_first_layers``)."""
+        for i, layer in enumerate(self.layers[1:], start=1):
+            h = token_linear(F.relu(h), layer)
+        return h
+
+
+def merged_first_layers(x, heads):
+    """``[head(x) for head in heads]`` for heads (``MLP`` or ``nn.Linear``) that all read the same ``x``: their first
+    linear layers run as ONE GEMM over the concatenated weights (one forward launch, one set of backward kernels and one
+    gradient for ``x`` instead of one per head), the rest of every MLP continues from its column block."""
+    firsts = [h.layers[0] if isinstance(h, MLP) else h for h in heads]
+    w = torch.cat([f.weight for f in firsts])
+    b = torch.cat([f.bias for f in firsts])
+    parts = F.linear(x, w, b).split([f.out_features for f in firsts], dim=-1)
+    return [h.forward_from_first(p) if isinstance(h, MLP) else p for h, p in zip(heads, parts)]
 
 
 def _clones(module, n):
@@ -259,14 +277,20 @@ class DepthAwareDecoder(nn.Module):
             output = layer(output, query_pos, reference_points_input, src, src_spatial_shapes,
                            src_level_start_index, src_padding_mask, depth_pos_embed, mask_depth)
             if self.bbox_embed is not None:   # iterative refinement, detached between layers (:602-613)
-                tmp = self.bbox_embed[lid](output)
+                if MERGE_HEADS and self.dim_embed is not None:
+                    tmp, reference_dims = merged_first_layers(output, [self.bbox_embed[lid], self.dim_embed[lid]])
+                else:
+                    tmp, reference_dims = self.bbox_embed[lid](output), None
                 self.bbox_raw.append(tmp)
                 if reference_points.shape[-1] == 6:
                     new_ref = tmp + inverse_sigmoid(reference_points)
                 else:
                     new_ref = torch.cat([tmp[..., :2] + inverse_sigmoid(reference_points), tmp[..., 2:]], -1)
                 reference_points = new_ref.sigmoid().detach()
-            reference_dims = self.dim_embed[lid](output) if self.dim_embed is not None else None
+            else:
+                reference_dims = None
+            if reference_dims is None:
+                reference_dims = self.dim_embed[lid](output) if self.dim_embed is not None else None
             if self.return_intermediate:
                 inter.append(output)
                 inter_refs.append(reference_points)

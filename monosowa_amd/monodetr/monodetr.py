@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..pointwise import conv_group_norm
-from .depthaware_transformer import MLP
+from .depthaware_transformer import MLP, merged_first_layers
 from .misc import NestedTensor, inverse_sigmoid
 
 
@@ -24,6 +24,7 @@ def _clones(module, n):
     return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
 
 
+MERGE_HEADS = True
 REUSE_BBOX_RAW = True
 
 
@@ -164,14 +165,20 @@ class MonoDETR(nn.Module):
                 tmp = torch.cat([tmp[..., :2] + reference, tmp[..., 2:]], -1)
             outputs_coord = tmp.sigmoid()                                   # 3D-centre projection + l,r,t,b
             coords.append(outputs_coord)
-            classes.append(self.class_embed[lvl](hs[lvl]))
+            if MERGE_HEADS:
+                # class / depth / angle heads read the same hs[lvl]: first layers as one GEMM
+                cls, depth_reg, angle = merged_first_layers(hs[lvl], [self.class_embed[lvl], self.depth_embed[lvl], self.angle_embed[lvl]])
+            else:
+                cls, depth_reg, angle = self.class_embed[lvl](hs[lvl]), None, None
+            classes.append(cls)
             size3d = inter_references_dim[lvl]
             dims3d.append(size3d)
 
             # geometric depth from the 3D height and the predicted 2D box height (monodetr.py:246-248)
             box2d_height = torch.clamp((outputs_coord[:, :, 4] + outputs_coord[:, :, 5]) * img_h, min=1.0)
             depth_geo = size3d[:, :, 0] / box2d_height * fu
-            depth_reg = self.depth_embed[lvl](hs[lvl])
+            if depth_reg is None:
+                depth_reg = self.depth_embed[lvl](hs[lvl])
             # depth read from the predicted depth map at the projected 3D centre (:254-259)
             centre = ((outputs_coord[..., :2] - 0.5) * 2).unsqueeze(2).detach()
             depth_map = F.grid_sample(weighted_depth.unsqueeze(1), centre, mode="bilinear",
@@ -180,7 +187,7 @@ class MonoDETR(nn.Module):
                                     + depth_geo.unsqueeze(-1) + depth_map) / 3,
                                    depth_reg[:, :, 1:2]], -1)
             depths.append(depth_ave)
-            angles.append(self.angle_embed[lvl](hs[lvl]))
+            angles.append(angle if angle is not None else self.angle_embed[lvl](hs[lvl]))
 
         out = {"pred_logits": classes[-1], "pred_boxes": coords[-1], "pred_3d_dim": dims3d[-1],
                "pred_depth": depths[-1], "pred_angle": angles[-1],
