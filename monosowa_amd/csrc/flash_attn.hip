@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void delta_kernel(const Args a, int B) {
 // dQ: same decomposition as the forward (a lane owns one query); per 32-key half: S^T (recomputed), dP^T = V dO^T,
 // dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T -- 48 MFMAs.
 template <bool DROP>
-__global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const Args a) {
+__global__ __launch_bounds__(256, 3) void bwd_dq_kernel(const Args a) {
   __shared__ float Ks[2][kTileK * kKStride];
   __shared__ float Vs[2][kTileK * kKStride];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const Args a) {
 // dK, dV: a lane owns one KEY (S = Q K^T untransposed: col = key, rows = 16 queries); per 32-query half:
 // S, dP = dO V^T, dV^T += dO^T P_drop, dK^T += Q^T dS -- 64 MFMAs.  Row statistics (lse, delta) come from LDS.
 template <bool DROP>
-__global__ __launch_bounds__(256, 2) void bwd_dkdv_kernel(const Args a) {
+__global__ __launch_bounds__(256, 3) void bwd_dkdv_kernel(const Args a) {
   __shared__ float Qs[2][kTileK * kKStride];
   __shared__ float Ds[2][kTileK * kKStride];
   __shared__ float Ls[2][kTileK], Es[2][kTileK];          // lse, delta of the tile's queries
