@@ -37,7 +37,7 @@ inline int check_dims(int B, int S, int M, int D, int L, int Lq, int P) {
 // Geometry of the LDS-resident gather kernels: stage the longest tail of levels that fits kLdsRows.
 // Returns false when nothing would be staged (the plain gather kernels are used instead).
 bool make_gather_geom(const int64_t *shapes_host, const int64_t *lsi_host, int B, int M, int Lq, int S,
-                      msda::GatherGeom &g) {
+                      msda::GatherGeom &g, bool bwd = false) {
   int first = 4;
   long long rows = 0;
   for (int l = 3; l >= 0; --l) {
@@ -58,10 +58,12 @@ bool make_gather_geom(const int64_t *shapes_host, const int64_t *lsi_host, int B
   g.n_lds_rows = (int)rows;
   // Query slices per (batch, head).  Workgroups of one (batch, head) run back to back on one XCD (32 CUs):
   // with c slices an XCD has 32 / c value planes (1.2 MB of fine levels each at 1280x384) live in its 4 MB
-  // L2 -- measured L2 hit rate 31 % at c = 2.  8 slices keep ~4 planes live; each slice still gets >= 256
-  // queries so the 76 KB of staging stays amortised.
+  // L2 -- measured L2 hit rate 31 % at c = 2.  The forward (one 16-wave workgroup per CU) runs 16 slices = 2 planes live
+  // (0.420 -> 0.382 ms against 8 slices, tools/msda_kernel_bench.py; -0.10 ms/step in situ); the backward's gather (two
+  // 8-wave workgroups per CU) is best at 8.  Each slice still gets >= 256 queries so the 76 KB of staging stays amortised.
   (void)B;
-  long long chunks = 8;
+  long long chunks = bwd ? 8 : 16;
+  if (const char *e = std::getenv(bwd ? "MSDA_GATHER_CHUNKS_BWD" : "MSDA_GATHER_CHUNKS")) chunks = std::max(1, std::atoi(e));
   const long long max_chunks = std::max<long long>(1, Lq / 256);
   g.n_chunks = (int)std::max<long long>(1, std::min(chunks, max_chunks));
   return true;
@@ -105,7 +107,7 @@ void launch_gather(const float *value, const float *loc, const float *attw, cons
   if (!aw_rs) aw_rs = M * 16;
   msda::GatherGeom geom;
   const long long n_pairs = (long long)B * Lq * M;
-  const bool staged = make_gather_geom(shapes_host, lsi_host, B, M, Lq, S, geom) && gather_mode() > 1;
+  const bool staged = make_gather_geom(shapes_host, lsi_host, B, M, Lq, S, geom, BWD) && gather_mode() > 1;
   if (staged) {
     const int bm_groups = (B * M + 7) / 8;
     msda::gather_rec_kernel<BWD, true, FUSED>

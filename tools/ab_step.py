@@ -27,7 +27,12 @@ from monosowa_amd.synthetic import make_batch, prepare_targets    # noqa: E402
 def main():
     path, a, b = sys.argv[1], sys.argv[2], sys.argv[3]
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 60
-    if path.startswith("option:"):            # a kernel-generation switch of the MSDA library: option:scatter_sorted 0 2
+    if path.startswith("env:"):               # an environment variable read per call by the native code: env:MSDA_GATHER_CHUNKS 8 16
+        class _Env:
+            pass
+        mod, attr, values = _Env(), path.split(":", 1)[1], [a, b]
+        _Env.__setattr__ = lambda self, k, v: os.environ.__setitem__(k, str(v))
+    elif path.startswith("option:"):            # a kernel-generation switch of the MSDA library: option:scatter_sorted 0 2
         from monosowa_amd import _lib
 
         class _Opt:
