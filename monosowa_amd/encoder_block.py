@@ -69,7 +69,10 @@ class _AttnBlock(torch.autograd.Function):
         if ctx.merged:
             gv, gproj = MSDA.ms_deform_attn_fused_backward_merged(v, shapes, lsi, proj, ref, ga.contiguous())
             gp2 = gproj.view(-1, gproj.shape[-1])
-            gw_ol, gb_ol = weight_grad(gp2, q2), colsum(gp2)
+            # per-level column sums of d proj serve twice: their total is the bias gradient, times W they are d level_embed
+            level_sums = colsum_levels(gproj, ctx.levels) if ctx.levels is not None else None
+            gw_ol = weight_grad(gp2, q2)
+            gb_ol = level_sums.sum(0) if level_sums is not None else colsum(gp2)
             gwo, gwa, gbo, gba = gw_ol[:n_off], gw_ol[n_off:], gb_ol[:n_off], gb_ol[n_off:]
         else:
             gv, goff, glogit = MSDA.ms_deform_attn_fused_backward(v, shapes, lsi, off, logit, ref, ga.contiguous())
@@ -84,7 +87,7 @@ class _AttnBlock(torch.autograd.Function):
             # level's tokens) @ Wo + (sum of d logits) @ Wa
             if ctx.merged:
                 gx2.addmm_(gp2, w_ol)
-                g_level = colsum_levels(gproj, ctx.levels) @ w_ol
+                g_level = level_sums @ w_ol
             else:
                 gx2.addmm_(goff2, wo)
                 gx2.addmm_(glogit2, wa)
