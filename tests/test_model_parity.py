@@ -248,3 +248,74 @@ def test_optimised_train_step_reduces_the_loss_on_a_repeated_batch():
         hist.append(total.item())
     assert all(h == h and abs(h) < 1e6 for h in hist), hist
     assert min(hist[-5:]) < 0.75 * hist[0], hist
+
+
+@pytest.mark.gpu
+def test_fused_training_path_tracks_the_module_by_module_path():
+    """Three optimizer steps (dropout 0, same initial weights and batch) with every structural optimisation switched ON
+    against the same steps with all of them OFF (module-by-module autograd, PyTorch matched losses, foreach AdamW,
+    unmerged projections ...): the loss sequences and the updated weights must agree to fp32 training noise."""
+    import copy
+    import yaml
+    from monosowa_amd import encoder_block, ms_deform_attn, pointwise
+    from monosowa_amd.helpers.model_helper import build_model, to_mi355x_layout
+    from monosowa_amd.helpers.optimizer_helper import build_optimizer
+    from monosowa_amd.monodetr import backbone, criterion, depthaware_transformer, matcher, monodetr, position_encoding
+    from monosowa_amd.synthetic import make_batch, prepare_targets
+    switches = [(criterion, "FUSED_MATCHED"), (depthaware_transformer, "ENCODER_BLOCKS"), (depthaware_transformer, "LEVEL_EMBED_IN_BLOCK"),
+                (depthaware_transformer, "MERGE_SA_PROJ"), (depthaware_transformer, "SELF_ATTN_HIP"), (monodetr, "MERGE_HEADS"),
+                (monodetr, "REUSE_BBOX_RAW"), (ms_deform_attn, "MERGED_PROJ"), (encoder_block, "MERGED_PROJ"),
+                (backbone, "AFFINE_IN_KERNEL"), (backbone, "CACHE_SCALE_SHIFT"), (pointwise, "USE_RELU_MASK"),
+                (matcher, "BLOCK_COST"), (position_encoding, "CACHE_ALL_VALID")]
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "configs", "monodetr.yaml")))
+    mcfg = dict(cfg["model"], device="cuda", dropout=0.0)
+    torch.manual_seed(7)
+    model0, crit = build_model(mcfg)
+    for m in model0.modules():                       # the depth predictor hard-codes dropout 0.1 (depth_predictor.py:48)
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    crit = crit.cuda().train()
+    inputs, calibs, targets, _ = make_batch(16, "cuda", seed=3, resolution=(640, 192))
+    inputs = inputs.contiguous(memory_format=torch.channels_last)
+
+    def run(on):
+        saved = [(mod, name, getattr(mod, name)) for mod, name in switches]
+        for mod, name in switches:
+            setattr(mod, name, on)
+        try:
+            model = to_mi355x_layout(copy.deepcopy(model0).cuda()).train()
+            opt = build_optimizer(cfg["optimizer"], model)
+            if not on:
+                opt._fused_step = lambda *a, **k: False
+            losses = []
+            for _ in range(3):
+                tl = prepare_targets(targets, 16)
+                opt.zero_grad(set_to_none=True)
+                total = criterion.weighted_total(crit(model(inputs, calibs, tl, targets["img_size"]), tl), crit.weight_dict)
+                total.backward()
+                opt.step()
+                losses.append(total.item())
+            probe = [model.depthaware_transformer.level_embed.detach().clone(),
+                     model.depthaware_transformer.encoder.layers[1].self_attn.sampling_offsets.weight.detach().clone(),
+                     model.backbone[0].body.layer3[2].conv2.weight.detach().clone(), model.class_embed[0].weight.detach().clone()]
+            return losses, probe
+        finally:
+            for mod, name, val in saved:
+                setattr(mod, name, val)
+    l_on, w_on = run(True)
+    l_off, w_off = run(False)
+    for a, b in zip(l_on, l_off):
+        assert abs(a - b) <= 2e-3 * abs(b), (l_on, l_off)
+    w0 = [model0.depthaware_transformer.level_embed.detach().cuda(),
+          model0.depthaware_transformer.encoder.layers[1].self_attn.sampling_offsets.weight.detach().cuda(),
+          model0.backbone[0].body.layer3[2].conv2.weight.detach().cuda(), model0.class_embed[0].weight.detach().cuda()]
+    for a, b, c in zip(w_on, w_off, w0):
+        c = c.to(b.dtype).reshape(b.shape)
+        upd_on, upd_off = (a - c).flatten().double(), (b - c).flatten().double()
+        assert upd_off.norm() > 0
+        # Adam's update is sign-like where the gradient is at noise level, so individual elements may differ by 2 lr;
+        # the update VECTORS must point the same way
+        cos = torch.dot(upd_on, upd_off) / (upd_on.norm() * upd_off.norm())
+        assert cos.item() > 0.98, cos.item()
