@@ -69,6 +69,12 @@ def msda_alg_bytes(kind, dims):
     return 4 * B * (Lq * M * D + S * M * D + Lq * M * L * P * 3 + S * M * D + Lq * M * L * P * 3)
 
 
+def dims_S(timer):
+    for _, dims, _, _ in timer.records:
+        return dims[1]
+    return 0
+
+
 def build_everything(args, device):
     import torch
     import yaml
@@ -138,16 +144,18 @@ def cpu_baseline(args):
         step = train_step_fn(model, criterion, optimizer)
         B = args.cpu_baseline_batch
         batch = make_batch(B, cpu, seed=444, resolution=(W, H))
+        tw = time.time()
+        step(batch)                          # 1 warm-up step, not timed
+        tw = time.time() - tw
         t0 = time.time()
         n = 0
-        while True:
+        while n < 3 or (time.time() - t0 < 10.0 and n < 8):      # >= 3 timed steps
             step(batch)
             n += 1
-            if time.time() - t0 > 12.0 or n >= 3:
-                break
         dt = time.time() - t0
         return {"value": B * n / dt, "unit": "img/s", "cores": cores, "kind": "port",
-                "sample": "%d train step(s) (fwd+criterion+bwd+AdamW) at batch %d, %dx%d, fp32, %.1f s" % (n, B, W, H, dt)}
+                "sample": "%d timed train steps (fwd+criterion+bwd+AdamW) after 1 warm-up step (%.1f s) at batch %d, %dx%d, "
+                          "fp32, %.1f s timed" % (n, tw, B, W, H, dt)}
     finally:
         F.MSDeformAttnFunction = saved
 
@@ -172,8 +180,28 @@ def default_conv_workload(args):
     return args.batch == 16 and args.backbone == "resnet50" and args.resolution == "1280x384"
 
 
+def launch_ranks(args):
+    """``python bench.py --gpus N`` started plainly: start the N ranks as a FRESH child (torch.distributed.run) before this
+    process has touched the GPU, relay its stdout (rank 0's JSON line) and exit with its code.  Never an exec of a
+    process that has initialised HIP."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("starting %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if (args.gpus > 1 or os.environ.get("MONOSOWA_BENCH_FORCE_LAUNCH") == "1") and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     guard = _StdoutGuard()
     # measured MIOpen kernel choices for the default workload (monosowa_amd/miopen_tuning.py); before torch loads MIOpen
     from monosowa_amd import miopen_tuning
@@ -270,17 +298,30 @@ def main():
     roofline = None
     if kernels:
         k = kernels[0]
-        traffic = None
+        # HBM traffic per launch from the PMC counters: collected by tools/collect_pmc.sh in separate rocprofv3 --pmc passes on
+        # the kernels this step runs; the file names its source profile and the kernel templates it was read from
+        traffic = traffic_src = None
         tf = os.path.join(ROOT, "profiles", "msda_traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("%s_Lq%d_B%d" % (k["kernel"], k["Lq"], k["B"]))
+                tj = json.load(open(tf))
+                traffic = tj.get("%s_Lq%d_B%d" % (k["kernel"], k["Lq"], k["B"]))
+                traffic_src = tj.get("_source")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "%s(B=%d,Lq=%d,S=10200,M=8,D=32,L=4,P=4)" % (k["kernel"], k["B"], k["Lq"]),
+        tot_bytes = sum(x["alg_bytes"] * x["launches_per_step"] for x in kernels)
+        tot_ms = sum(x["avg_ms"] * x["launches_per_step"] for x in kernels)
+        fwd = next((x for x in kernels if x["kernel"] == "msda_fwd" and x["Lq"] == k["Lq"]), None)
+        roofline = {"bound": "hbm", "kernel": "%s(B=%d,Lq=%d,S=%d,M=8,D=32,L=4,P=4)" % (k["kernel"], k["B"], k["Lq"], dims_S(timer)),
                     "achieved": k["achieved_GBps"], "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
-                    "frac": k["frac"], "traffic": traffic, "avg_launch_ms": k["avg_ms"],
-                    "alg_bytes_per_launch": k["alg_bytes"], "all_msda_kernels": kernels}
+                    "frac": k["frac"], "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": k["avg_ms"],
+                    "alg_bytes_per_launch": k["alg_bytes"],
+                    "forward_same_shape": None if fwd is None else {"avg_launch_ms": fwd["avg_ms"], "achieved": fwd["achieved_GBps"],
+                                                                    "frac": fwd["frac"]},
+                    "all_msda_aggregate": {"alg_bytes_per_step": tot_bytes, "ms_per_step": tot_ms,
+                                           "achieved": tot_bytes / (tot_ms * 1e-3) / 1e9,
+                                           "frac": tot_bytes / (tot_ms * 1e-3) / HBM_PEAK_BYTES_PER_S, "target_frac": 0.60},
+                    "all_msda_kernels": kernels}
 
     if rank == 0:
         line = {

@@ -34,6 +34,52 @@ inline int check_dims(int B, int S, int M, int D, int L, int Lq, int P) {
   return 0;
 }
 
+// MSDA_GATHER = 0: first-generation gather kernels; 1: tap records; 2 (default): records + coarse levels in LDS.
+// A tuning / A-B switch only; every mode computes the same function.
+// Kernel-generation switches (A/B measurement and test coverage; every setting computes the same function).
+//   gather        0: first-generation gather kernels, 1: tap records, 2 (default): records + coarse levels in LDS
+//   scatter_sorted 0 (default): never, 1: counting sort by bilinear cell + register sums (msda_backward_sorted.hip)
+//                  when a level's record list has >= 8192 points, 2: always.  Measured at B = 16, Lq = 10200:
+//                  0.90 vs 1.04 ms on random +-4 px offsets (tools/msda_kernel_bench.py) but 2.02 vs 1.88 ms per
+//                  backward inside the train step, whose freshly initialised offsets are whole pixels with ~5
+//                  points per cell -- hence opt-in.  Otherwise LDS-atomic tile accumulators, flavour by scatter_fixed:
+//   scatter_fixed 1 (default): 64-bit fixed-point tile accumulators (ds_add_u64), 0: double (ds_add_f64)
+// Initialised from MSDA_GATHER / MSDA_SCATTER_FIXED, changed at run time with msda_set_option().
+struct Options {
+  int gather = 2;
+  int scatter_fixed = 1;
+  int scatter_sorted = 0;
+  int gather_chunks_fwd = 16, gather_chunks_bwd = 8;      // query slices per (batch, head) of the staged gather kernels
+  Options() {                                               // the environment is read ONCE, at first use
+    if (const char *e = std::getenv("MSDA_GATHER")) gather = std::atoi(e);
+    if (const char *e = std::getenv("MSDA_SCATTER_FIXED")) scatter_fixed = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MSDA_SCATTER_SORTED")) scatter_sorted = std::atoi(e);
+    if (const char *e = std::getenv("MSDA_GATHER_CHUNKS")) gather_chunks_fwd = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("MSDA_GATHER_CHUNKS_BWD")) gather_chunks_bwd = std::max(1, std::atoi(e));
+  }
+};
+inline Options &options() {
+  static Options o;
+  return o;
+}
+inline bool scatter_fixed_point() { return options().scatter_fixed != 0; }
+inline int gather_mode() { return options().gather; }
+inline int gather_chunks_fwd() { return options().gather_chunks_fwd; }
+inline int gather_chunks_bwd() { return options().gather_chunks_bwd; }
+
+// A host copy of the pyramid is caller-provided (a Python attribute in the shim): before any kernel trusts it, the
+// levels must be positive and tile [0, S) in order -- otherwise a kernel would read past the value tensor.
+inline int check_host_geometry(const int64_t *shapes_host, const int64_t *lsi_host, int L, int S) {
+  long long next = 0;
+  for (int l = 0; l < L; ++l) {
+    const long long H = shapes_host[2 * l], W = shapes_host[2 * l + 1];
+    if (H <= 0 || W <= 0 || H > 32000 || W > 32000) return MSDA_E_SHAPE;     // 16-bit chunk boxes / window coordinates
+    if (lsi_host[l] != next) return MSDA_E_SHAPE;
+    next += H * W;
+  }
+  return next == S ? 0 : MSDA_E_SHAPE;
+}
+
 // Geometry of the LDS-resident gather kernels: stage the longest tail of levels that fits kLdsRows.
 // Returns false when nothing would be staged (the plain gather kernels are used instead).
 bool make_gather_geom(const int64_t *shapes_host, const int64_t *lsi_host, int B, int M, int Lq, int S,
@@ -62,40 +108,12 @@ bool make_gather_geom(const int64_t *shapes_host, const int64_t *lsi_host, int B
   // (0.420 -> 0.382 ms against 8 slices, tools/msda_kernel_bench.py; -0.10 ms/step in situ); the backward's gather (two
   // 8-wave workgroups per CU) is best at 8.  Each slice still gets >= 256 queries so the 76 KB of staging stays amortised.
   (void)B;
-  long long chunks = bwd ? 8 : 16;
-  if (const char *e = std::getenv(bwd ? "MSDA_GATHER_CHUNKS_BWD" : "MSDA_GATHER_CHUNKS")) chunks = std::max(1, std::atoi(e));
+  const long long chunks = bwd ? gather_chunks_bwd() : gather_chunks_fwd();
   const long long max_chunks = std::max<long long>(1, Lq / 256);
   g.n_chunks = (int)std::max<long long>(1, std::min(chunks, max_chunks));
   return true;
 }
 
-// MSDA_GATHER = 0: first-generation gather kernels; 1: tap records; 2 (default): records + coarse levels in LDS.
-// A tuning / A-B switch only; every mode computes the same function.
-// Kernel-generation switches (A/B measurement and test coverage; every setting computes the same function).
-//   gather        0: first-generation gather kernels, 1: tap records, 2 (default): records + coarse levels in LDS
-//   scatter_sorted 0 (default): never, 1: counting sort by bilinear cell + register sums (msda_backward_sorted.hip)
-//                  when a level's record list has >= 8192 points, 2: always.  Measured at B = 16, Lq = 10200:
-//                  0.90 vs 1.04 ms on random +-4 px offsets (tools/msda_kernel_bench.py) but 2.02 vs 1.88 ms per
-//                  backward inside the train step, whose freshly initialised offsets are whole pixels with ~5
-//                  points per cell -- hence opt-in.  Otherwise LDS-atomic tile accumulators, flavour by scatter_fixed:
-//   scatter_fixed 1 (default): 64-bit fixed-point tile accumulators (ds_add_u64), 0: double (ds_add_f64)
-// Initialised from MSDA_GATHER / MSDA_SCATTER_FIXED, changed at run time with msda_set_option().
-struct Options {
-  int gather = 2;
-  int scatter_fixed = 1;
-  int scatter_sorted = 0;
-  Options() {
-    if (const char *e = std::getenv("MSDA_GATHER")) gather = std::atoi(e);
-    if (const char *e = std::getenv("MSDA_SCATTER_FIXED")) scatter_fixed = std::atoi(e) != 0;
-    if (const char *e = std::getenv("MSDA_SCATTER_SORTED")) scatter_sorted = std::atoi(e);
-  }
-};
-inline Options &options() {
-  static Options o;
-  return o;
-}
-inline bool scatter_fixed_point() { return options().scatter_fixed != 0; }
-inline int gather_mode() { return options().gather; }
 
 // Launch of the record-based gather kernels (forward or the backward's grad_loc / grad_attn_w pass), staged when
 // the tail of the pyramid fits LDS and the option allows it.
@@ -131,6 +149,7 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
   if constexpr (sizeof(T) == 4) {
     if (D == 32 && L == 4 && P == 4) {
       if (shapes_host && lsi_host && gather_mode() > 0) {
+        if (int e = check_host_geometry(shapes_host, lsi_host, L, S)) return e;
         launch_gather<false, false>(value, loc, attw, nullptr, out, nullptr, nullptr, nullptr, 0, shapes_host, lsi_host,
                                     B, S, M, Lq, stream);
         return (int)hipGetLastError();
@@ -233,16 +252,9 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         shapes_host = host_geom;
         lsi_host = host_geom + 2 * L;
       }
-      long long tokens = 0;
-      for (int l = 0; l < L; ++l) {
-        if (shapes_host[2 * l] <= 0 || shapes_host[2 * l + 1] <= 0) return MSDA_E_SHAPE;
-        tokens += shapes_host[2 * l] * shapes_host[2 * l + 1];
-      }
-      if (tokens != S) return MSDA_E_SHAPE;
+      if (int e = check_host_geometry(shapes_host, lsi_host, L, S)) return e;
       const msda::BwdPlan plan = make_plan(shapes_host, lsi_host, L, Lq, P);
       if ((long long)Lq * P >= (1LL << (62 - msda::kFixBits))) return MSDA_E_SHAPE;   // fixed-point headroom
-      for (int l = 0; l < L; ++l)
-        if (shapes_host[2 * l] > 32000 || shapes_host[2 * l + 1] > 32000) return MSDA_E_SHAPE;   // 16-bit chunk boxes
       const TiledWorkspace ws = tiled_workspace(B, M, L, Lq, P);
       char *wsp = reinterpret_cast<char *>(workspace);
       float2 *rec_hw = reinterpret_cast<float2 *>(wsp);
@@ -380,6 +392,7 @@ int msda_fused_forward_strided_f32(const float *value, const int64_t *shapes, co
   if (!(D == 32 && L == 4 && P == 4) || (ref_dim != 2 && ref_dim != 6)) return MSDA_E_UNSUPPORTED;
   if (offsets_row_stride < M * 32 || logits_row_stride < M * 16 || (offsets_row_stride & 3) || (logits_row_stride & 3))
     return MSDA_E_SHAPE;
+  if (int e = check_host_geometry(shapes_host, level_start_host, L, S)) return e;
   launch_gather<false, true>(value, offsets, logits, nullptr, out, nullptr, nullptr, ref, ref_dim, shapes_host,
                              level_start_host, B, S, M, Lq, (hipStream_t)stream, offsets_row_stride, logits_row_stride);
   return (int)hipGetLastError();

@@ -105,6 +105,10 @@ class Trainer(object):
                         save_checkpoint(get_checkpoint_state(self.model, self.optimizer, self.epoch, best_result, best_epoch),
                                         os.path.join(self.output_dir, "checkpoint_best"))
                     self.logger.info("Best Result:{}, epoch:{}".format(best_result, best_epoch))
+            if (self.epoch % self.cfg["save_frequency"]) == 0 and misc.is_dist_avail_and_initialized():
+                # rank 0 saved / evaluated alone: the other ranks wait here instead of inside the next epoch's first
+                # gradient all-reduce (where a long evaluation would run into the collective watchdog)
+                torch.distributed.barrier()
             bar.update()
         self.logger.info("Best Result:{}, epoch:{}".format(best_result, best_epoch))
         return None

@@ -3,6 +3,7 @@
 Run in the build container only (``/root/reference`` does not exist on the GPU box):
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [msda] [module] [transformer] [depth] [misc]
+                                                       [adamw] [decode] [criterion] [heads]
 
 The reference tree is imported read-only, unmodified.  Third-party symbols that are absent
 from this image are shimmed (never reference code): the unbuilt CUDA extension module
@@ -285,6 +286,257 @@ def gen_misc():
     bins = crit.bin_depths(dm, target=True)
     _save("losses", sfl_logits=logits, sfl_targets=tgt, sfl=sfl, depth_logits=depth_logits, boxes=boxes,
           depth=depth, num_gt=np.array(num_gt), ddn_loss=ddn_loss, depth_map=dm, depth_bins=bins)
+
+
+# ----------------------------------------------------------------------------- round 2: AdamW, decode, criterion, heads
+def _more_shims():
+    """Absent third-party modules that reference files import at module level but never call on the paths
+    fixtured here: open3d / cv2 (visualisation, image IO) and torchvision.models (the ResNet body, replaced
+    by a feature stub below)."""
+    _shims()
+    for name in ("open3d", "cv2"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    tv = sys.modules["torchvision"]
+    if not hasattr(tv, "models"):
+        models = types.ModuleType("torchvision.models")
+        utils = types.ModuleType("torchvision.models._utils")
+
+        class IntermediateLayerGetter(torch.nn.Module):       # only named at import time (backbone.py:19)
+            pass
+        utils.IntermediateLayerGetter = IntermediateLayerGetter
+        models._utils = utils
+        tv.models = models
+        sys.modules.update({"torchvision.models": models, "torchvision.models._utils": utils})
+
+
+class _NoCuda:
+    """The reference hard-codes ``.cuda()`` / ``device='cuda'`` in its loss methods (monodetr.py:515,528,567-575,
+    ddn_loss.py:32).  Inside this context those land on the CPU: torch is patched, the reference is not."""
+
+    def __enter__(self):
+        self._saved = (torch.Tensor.cuda, torch.tensor, torch.cuda.current_device)
+        orig_tensor = torch.tensor
+
+        def tensor(*a, **k):
+            if str(k.get("device", "")).startswith("cuda"):
+                k.pop("device")
+            return orig_tensor(*a, **k)
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.tensor = tensor
+        torch.cuda.current_device = lambda: 0
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.cuda, torch.tensor, torch.cuda.current_device = self._saved
+
+
+def gen_adamw():
+    """The reference's own AdamW (lib/helpers/optimizer_helper.py:30-129): three steps on two parameter groups
+    (weight decay 0 / 1e-4) with tensors whose sizes exercise the fused kernel's aligned and unaligned paths."""
+    _shims()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import importlib
+    import warnings
+    oh = importlib.import_module("lib.helpers.optimizer_helper")
+    g = torch.Generator().manual_seed(71)
+    shapes = [(7,), (33,), (256,), (5, 3), (48, 64), (4097,), (3, 3, 3, 16), (1,)]
+    params = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    arrays = {"p%d_init" % i: p.detach().clone() for i, p in enumerate(params)}
+    groups = [{"params": params[0::2], "weight_decay": 0.0}, {"params": params[1::2], "weight_decay": 1e-4}]
+    opt = oh.AdamW(groups, lr=2e-4)
+    n_steps = 3
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for step in range(n_steps):
+            for i, p in enumerate(params):
+                grad = torch.randn(p.shape, generator=g) * (10.0 ** ((i % 3) - 1))
+                if step == 1 and i == 2:
+                    grad = torch.zeros_like(grad)          # a zero gradient: sqrt(v) + eps path
+                p.grad = grad
+                arrays["g%d_step%d" % (i, step)] = grad.clone()
+            opt.step()
+            for i, p in enumerate(params):
+                arrays["p%d_step%d" % (i, step)] = p.detach().clone()
+    for i, p in enumerate(params):
+        arrays["m%d" % i] = opt.state[p]["exp_avg"].clone()
+        arrays["v%d" % i] = opt.state[p]["exp_avg_sq"].clone()
+    _save("adamw", n_params=len(params), n_steps=n_steps, lr=2e-4, weight_decay=1e-4, **arrays)
+
+
+def _seeded_outputs(gen, B, Q, dtype=torch.float32):
+    o = {"pred_logits": torch.randn(B, Q, 3, generator=gen) * 2 - 1.5,
+         "pred_boxes": torch.cat([torch.rand(B, Q, 2, generator=gen) * 0.8 + 0.1,
+                                  torch.rand(B, Q, 4, generator=gen) * 0.15 + 0.01], -1),
+         "pred_3d_dim": torch.randn(B, Q, 3, generator=gen) * 0.2 + torch.tensor([1.5, 1.6, 3.9]),
+         "pred_depth": torch.cat([torch.rand(B, Q, 1, generator=gen) * 55 + 3, torch.randn(B, Q, 1, generator=gen) * 0.5], -1),
+         "pred_angle": torch.randn(B, Q, 24, generator=gen)}
+    return {k: v.to(dtype) for k, v in o.items()}
+
+
+def gen_decode():
+    """extract_dets_from_outputs + decode_detections (lib/helpers/decode_helper.py:8-111) with the reference's own
+    Calibration class (lib/datasets/kitti/kitti_utils.py:137-284) built from P2 matrices."""
+    _more_shims()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import importlib
+    dh = importlib.import_module("lib.helpers.decode_helper")
+    ku = importlib.import_module("lib.datasets.kitti.kitti_utils")
+    gen = torch.Generator().manual_seed(81)
+    B, Q = 3, 50
+    outputs = _seeded_outputs(gen, B, Q)
+    outputs["pred_logits"][0, 7] = outputs["pred_logits"][0, 3]          # exact ties in the top-k
+    outputs["pred_logits"][1, :, 1] = 4.0 - torch.arange(Q) * 0.01       # many confident detections
+    dets = dh.extract_dets_from_outputs(outputs, K=50, topk=50)
+    P2 = np.array([[[721.54, 0, 609.56, 44.857], [0, 721.54, 172.85, 0.2163], [0, 0, 1, 0.002746]],
+                   [[552.55, 0, 682.05, -328.3], [0, 552.55, 238.77, 0.0], [0, 0, 1, 0.0]],
+                   [[2055.6, 0, 939.66, 0.0], [0, 2055.6, 641.07, 0.0], [0, 0, 1, 0.0]]], dtype=np.float32)
+    calibs = [ku.Calibration({"P2": P2[i], "R0": np.eye(3, dtype=np.float32),
+                              "Tr_velo2cam": np.eye(3, 4, dtype=np.float32)}) for i in range(B)]
+    info = {"img_id": np.array([11, 22, 33]), "img_size": np.array([[1242, 375], [1408, 376], [1920, 1280]]),
+            "height_crop": np.array([1.0, 1.0, 2.5]), "canonical_scale": np.array([0.693, 0.905, 0.243])}
+    cls_mean_size = np.array([[1.76255119, 0.66068622, 0.84422524], [1.52563191, 1.62856739, 3.52588311],
+                              [1.73698127, 0.59706367, 1.76282397]])
+    res = dh.decode_detections(dets.detach().numpy().copy(), info, calibs, cls_mean_size, 0.2)
+    rows = np.zeros((B, 50, 14), dtype=np.float64)
+    counts = np.zeros(B, dtype=np.int64)
+    for i, img in enumerate(info["img_id"]):
+        counts[i] = len(res[img])
+        for j, r in enumerate(res[img]):
+            rows[i, j] = np.asarray(r, dtype=np.float64)
+    _save("decode", P2=P2, dets=dets, decoded=rows, counts=counts, cls_mean_size=cls_mean_size, threshold=0.2,
+          **{"info_" + k: v for k, v in info.items()}, **outputs)
+
+
+def _seeded_targets(gen, sizes):
+    targets = []
+    for n in sizes:
+        c = torch.rand(n, 2, generator=gen) * 0.8 + 0.1
+        lrtb = torch.rand(n, 4, generator=gen) * 0.09 + 0.01
+        b3 = torch.cat([c, lrtb], 1)
+        cx = c[:, 0] + (lrtb[:, 1] - lrtb[:, 0]) / 2
+        cy = c[:, 1] + (lrtb[:, 3] - lrtb[:, 2]) / 2
+        boxes = torch.stack([cx, cy, lrtb[:, 0] + lrtb[:, 1], lrtb[:, 2] + lrtb[:, 3]], 1)
+        targets.append({"labels": torch.randint(0, 3, (n,), generator=gen).to(torch.int8), "boxes": boxes, "boxes_3d": b3,
+                        "depth": torch.rand(n, 1, generator=gen) * 55 + 5,
+                        "size_3d": torch.randn(n, 3, generator=gen) * 0.1 + torch.tensor([1.53, 1.63, 3.88]),
+                        "heading_bin": torch.randint(0, 12, (n, 1), generator=gen),
+                        "heading_res": (torch.rand(n, 1, generator=gen) - 0.5) * (np.pi / 6)})
+    return targets
+
+
+CRIT_WEIGHTS = {"loss_ce": 2.0, "loss_bbox": 5.0, "loss_giou": 2.0, "loss_dim": 1.0, "loss_angle": 1.0, "loss_depth": 1.0,
+                "loss_center": 10.0, "loss_depth_map": 1.0, "loss_tfl": 0.0, "loss_mask": 0.0}
+
+
+def gen_criterion():
+    """SetCriterion.forward (monodetr.py:1188-1230) with its own loss methods (:396-536) and the reference matcher, train
+    mode (3 groups x 50 queries, two auxiliary layers): every entry of the loss dict plus the gradient of the weighted
+    total (trainer_helper.py:140-141) w.r.t. every prediction tensor."""
+    _more_shims()
+    imp = ref_pkg()
+    mono = imp.import_module("mdpkg.monodetr")
+    matcher = imp.import_module("mdpkg.matcher")
+    gen = torch.Generator().manual_seed(91)
+    B, G, NL = 3, 3, 3
+    Q = 50 * G
+    sizes = [4, 1, 7]
+    targets = _seeded_targets(gen, sizes)
+    layers = [_seeded_outputs(gen, B, Q) for _ in range(NL)]
+    depth_map_logits = torch.randn(B, 81, 24, 80, generator=gen)
+    leaves = []
+    for o in layers:
+        for k in o:
+            o[k].requires_grad_(True)
+            leaves.append(o[k])
+    depth_map_logits.requires_grad_(True)
+    outputs = dict(layers[-1])
+    outputs["pred_depth_map_logits"] = depth_map_logits
+    outputs["aux_outputs"] = layers[:-1]
+    weight_dict = dict(CRIT_WEIGHTS)
+    for i in range(NL - 1):
+        weight_dict.update({k + "_%d" % i: v for k, v in CRIT_WEIGHTS.items()})
+    losses = ["labels", "boxes", "cardinality", "depths", "dims", "angles", "center", "depth_map", "tfl"]
+    with _NoCuda():
+        m = matcher.HungarianMatcher(cost_class=2, cost_3dcenter=10, cost_bbox=5, cost_giou=2)
+        crit = mono.SetCriterion(3, matcher=m, weight_dict=weight_dict, focal_alpha=0.25, losses=losses, group_num=G)
+        crit.train()
+        loss_dict = crit(outputs, targets)
+        total = sum(loss_dict[k] * weight_dict[k] for k in loss_dict if k in weight_dict)
+        total.backward()
+    arrays = {"sizes": np.array(sizes), "group_num": G, "n_layers": NL, "total": total.detach(),
+              "depth_map_logits": depth_map_logits.detach(), "grad_depth_map_logits": depth_map_logits.grad}
+    for li, o in enumerate(layers):                      # layer NL-1 = final outputs, 0 .. NL-2 = aux_outputs
+        for k, v in o.items():
+            arrays["l%d_%s" % (li, k)] = v.detach()
+            arrays["l%d_grad_%s" % (li, k)] = v.grad if v.grad is not None else torch.zeros_like(v)
+    for i, t in enumerate(targets):
+        for k, v in t.items():
+            arrays["t%d_%s" % (i, k)] = v
+    for k, v in loss_dict.items():
+        arrays["loss__" + k] = v.detach() if torch.is_tensor(v) else torch.tensor(float(v))
+    arrays["weight_keys"] = np.array(sorted(weight_dict))
+    arrays["weight_vals"] = np.array([weight_dict[k] for k in sorted(weight_dict)], dtype=np.float64)
+    _save("criterion", **arrays)
+
+
+class _FeatureStub(torch.nn.Module):
+    """Stands in for torchvision's ResNet body (absent here): returns fixed C3/C4/C5 maps with all-False masks, as
+    BackboneBase.forward does (backbone.py:85-91).  Everything downstream is the reference's own code."""
+    strides = [8, 16, 32]
+    num_channels = [512, 1024, 2048]
+
+    def __init__(self, feats, NestedTensor):
+        super().__init__()
+        self.feats, self.NT = feats, NestedTensor
+
+    def forward(self, images):
+        return {str(i): self.NT(f, torch.zeros(f.shape[0], f.shape[2], f.shape[3], dtype=torch.bool))
+                for i, f in enumerate(self.feats)}
+
+
+def gen_heads():
+    """MonoDETR.forward behind the backbone body (monodetr.py:155-289): the reference's Joiner + sine encoding, input_proj,
+    extra level, DepthPredictor, transformer and all per-layer heads, eval (50 queries) and train (3 x 50, dropout off)."""
+    _more_shims()
+    imp = ref_pkg()
+    fill, manifest = _fill()
+    mono = imp.import_module("mdpkg.monodetr")
+    bb = imp.import_module("mdpkg.backbone")
+    pe = imp.import_module("mdpkg.position_encoding")
+    dp = imp.import_module("mdpkg.depth_predictor")
+    misc = importlib_misc()
+    torch.manual_seed(61)
+    G, B = 3, 2
+    feats = [torch.randn(B, c, h, w).double() * 0.5 for c, (h, w) in zip((512, 1024, 2048), KITTI_SMALL[:3])]
+    backbone = bb.Joiner(_FeatureStub(feats, misc.NestedTensor), pe.PositionEmbeddingSine(128, normalize=True))
+    cfg = {"num_depth_bins": 80, "depth_min": 1e-3, "depth_max": 60.0, "hidden_dim": 256}
+    model = mono.MonoDETR(backbone, _transformer(imp, G, dropout=0.0), dp.DepthPredictor(cfg), num_classes=3, num_queries=50,
+                          num_feature_levels=4, aux_loss=True, with_box_refine=True, two_stage=False, init_box=False,
+                          use_dab=False, group_num=G, two_stage_dino=False)
+    for mod in model.modules():                          # the depth encoder ships dropout 0.1: switch the randomness off
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    model = fill(model, 404).double()
+    images = torch.zeros(B, 3, 96, 128).double()
+    calibs = torch.tensor([[[707.05, 0, 640.0, 0], [0, 707.05, 192.0, 0], [0, 0, 1, 0]],
+                           [[552.6, 0, 682.0, 0], [0, 552.6, 238.8, 0], [0, 0, 1, 0]]]).double()
+    img_sizes = torch.tensor([[1242.0, 375.0], [1408.0, 376.0]]).double()
+    arrays = {"f%d" % i: f.float() for i, f in enumerate(feats)}
+    for mode in ("eval", "train"):
+        model.train(mode == "train")
+        out = model(images, calibs, None, img_sizes)
+        for k in ("pred_logits", "pred_boxes", "pred_3d_dim", "pred_depth", "pred_angle", "pred_depth_map_logits"):
+            arrays["%s_%s" % (mode, k)] = out[k].float()
+        for i, aux in enumerate(out["aux_outputs"]):
+            for k, v in aux.items():
+                arrays["%s_aux%d_%s" % (mode, i, k)] = v.float()
+    _save("monodetr_heads", calibs=calibs.float(), img_sizes=img_sizes.float(), group_num=G, manifest=manifest(model), **arrays)
+
 
 
 def importlib_misc():

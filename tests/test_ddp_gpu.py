@@ -1,0 +1,90 @@
+"""The data-parallel path on a GPU: one rank under DistributedDataParallel over RCCL (MONOSOWA_FORCE_DDP=1, world size 1)
+so that the reducer meets the fused autograd nodes (encoder blocks, HIP attention, merged projections), bucket-view
+gradients and the fused AdamW kernel -- against the same step on the unwrapped model.  Runs in a child process: the
+process group and RCCL stay out of the test runner.  Multi-rank semantics (mean of local gradients, num_boxes
+normalisation, monodetr.py:1202-1206) are covered on CPU by test_distributed_gloo.py."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["MONOSOWA_ROOT"])
+import torch, yaml
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+from monosowa_amd.helpers.model_helper import build_model, to_mi355x_layout
+from monosowa_amd.helpers.optimizer_helper import build_optimizer
+from monosowa_amd.helpers.trainer_helper import wrap_ddp
+from monosowa_amd.monodetr.criterion import weighted_total
+from monosowa_amd.synthetic import make_batch, prepare_targets
+
+cfg = yaml.safe_load(open(os.path.join(os.environ["MONOSOWA_ROOT"], "configs", "monodetr.yaml")))
+mcfg = dict(cfg["model"], device="cuda", depth_map_size=(20, 6))
+
+def build():
+    torch.manual_seed(444)
+    model, crit = build_model(mcfg)
+    model = to_mi355x_layout(model.to(dev)).train()
+    return model, crit.to(dev).train(), build_optimizer(cfg["optimizer"], model)
+
+inputs, calibs, targets, _ = make_batch(2, dev, seed=3, resolution=(320, 96))
+inputs = inputs.contiguous(memory_format=torch.channels_last)
+tl = prepare_targets(targets, 2)
+
+def step(net, crit, opt):
+    torch.manual_seed(7)                       # same dropout masks in both runs
+    opt.zero_grad(set_to_none=True)
+    total = weighted_total(crit(net(inputs, calibs, tl, targets["img_size"]), tl), crit.weight_dict)
+    total.backward()
+    return total.detach()
+
+plain, crit_a, opt_a = build()
+wrapped_core, crit_b, opt_b = build()
+ddp = wrap_ddp(wrapped_core, dev)
+assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel), "MONOSOWA_FORCE_DDP=1 must wrap at world size 1"
+frozen = set(wrapped_core.unused_parameter_names())
+assert frozen and all(not p.requires_grad for n, p in wrapped_core.named_parameters() if n in frozen)
+
+for it in range(2):                            # second iteration: bucket views are live, AdamW state exists
+    la, lb = step(plain, crit_a, opt_a), step(ddp, crit_b, opt_b)
+    assert torch.isfinite(la) and abs(la - lb) <= 1e-5 * abs(la), (la, lb)
+    ga = {n: p.grad for n, p in plain.named_parameters() if p.grad is not None and n not in frozen}
+    gb = {n: p.grad for n, p in wrapped_core.named_parameters() if p.grad is not None}
+    assert set(ga) == set(gb), sorted(set(ga) ^ set(gb))[:5]
+    worst = 0.0
+    for n in ga:
+        scale = ga[n].abs().max().item()
+        if scale > 0:
+            worst = max(worst, (ga[n] - gb[n]).abs().max().item() / scale)
+    assert worst <= 2e-4, worst                # f32 atomics of the coarse-level scatter are order-dependent
+    opt_a.step(); opt_b.step()
+    wa = dict(plain.named_parameters()); wb = dict(wrapped_core.named_parameters())
+    dw = max((wa[n] - wb[n]).abs().max().item() for n in ga)
+    assert dw <= 1e-5, dw
+    print("iteration %d: loss %.5f, worst gradient deviation %.2e, worst weight deviation %.2e" % (it, la.item(), worst, dw))
+torch.cuda.synchronize()
+dist.barrier()
+dist.destroy_process_group()
+print("ddp-ws1 ok")
+'''
+
+
+@pytest.mark.gpu
+def test_train_step_under_ddp_world_size_1_equals_the_unwrapped_step(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "ddp_ws1.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MONOSOWA_ROOT=ROOT, MONOSOWA_FORCE_DDP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ddp-ws1 ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

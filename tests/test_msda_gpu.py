@@ -51,14 +51,30 @@ def _oracle_want(value, shapes, lsi, loc, w, go):
     return want, w64
 
 
+def _close_elementwise(got, want, rel, what):
+    """Element-wise check for `out` (a convex combination of value rows: no cancellation beyond the sampled rows'
+    own magnitude): |err| <= rel * (|ref| + rms(ref)) for every element."""
+    got = got.detach().cpu().numpy().reshape(want.shape).astype(np.float64)
+    want = want.astype(np.float64)
+    floor = float(np.sqrt((want ** 2).mean())) + 1e-30
+    err = float((np.abs(got - want) / (np.abs(want) + floor)).max())
+    assert err <= rel, "%s: max element-wise err = %.3e > %.1e" % (what, err, rel)
+
+
 def _run_case(value, shapes, lsi, loc, attw, grad_out, want, rel, want64=None):
+    """Forward through BOTH d32 variants: without a host pyramid (fwd_d32_kernel; the forward never synchronises to
+    fetch one) and with it attached (the record / LDS-staged / windowed production kernels bench.py and training run)."""
     MSDA = _msda()
     v, s, i, lc, w, go = map(_dev, (value, shapes, lsi, loc, attw, grad_out))
+    out_plain = MSDA.ms_deform_attn_forward(v, s, i, lc, w, 64)
+    assert tuple(out_plain.shape) == (value.shape[0], loc.shape[1], value.shape[2] * value.shape[3])
+    _close(out_plain, want[0], rel, "out (no host pyramid)")
+    MSDA.attach_host_geometry(s, i, shapes.tolist(), lsi.tolist())
     out = MSDA.ms_deform_attn_forward(v, s, i, lc, w, 64)
-    assert tuple(out.shape) == (value.shape[0], loc.shape[1], value.shape[2] * value.shape[3])
     gv, gl, gw = MSDA.ms_deform_attn_backward(v, s, i, lc, w, go, 64)
     torch.cuda.synchronize()
     _close(out, want[0], rel, "out")
+    _close_elementwise(out, want[0], 10 * rel, "out")
     _close(gv, want[1], rel, "grad_value")
     _close(gl, want[2], rel, "grad_loc")
     _close(gw, want[3], rel, "grad_attw")
@@ -131,6 +147,103 @@ def test_kitti_geometry_encoder_one_sample_vs_c_oracle():
     _run_case(value, shapes, lsi, loc, w, go, want, 1e-4, want64)
 
 
+def _kitti_encoder_inputs(B, seed, offset_px=4.0):
+    rng = np.random.default_rng(seed)
+    shapes = np.array(KITTI_LEVELS, dtype=np.int64)
+    lsi = O.level_start_index(shapes)
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    M, D, L, P = 8, 32, 4, 4
+    ref = np.concatenate([np.stack(np.meshgrid((np.arange(w) + 0.5) / w, (np.arange(h) + 0.5) / h), -1).reshape(-1, 2)
+                          for h, w in KITTI_LEVELS]).astype(np.float32)                # [S,2] (x,y), pixel centres
+    offsets = rng.uniform(-offset_px, offset_px, (B, S, M, L, P, 2)).astype(np.float32)
+    logits = rng.standard_normal((B, S, M, L * P)).astype(np.float32)
+    value = rng.standard_normal((B, S, M, D)).astype(np.float32)
+    go = rng.standard_normal((B, S, M * D)).astype(np.float32)
+    return shapes, lsi, ref, offsets, logits, value, go
+
+
+@pytest.mark.parametrize("B,check,offset_px", [(2, (0, 1), 4.0), (16, (3, 15), 4.0), (2, (0, 1), 11.0)])
+def test_fused_strided_operator_at_the_kitti_pyramid_vs_c_oracle(B, check, offset_px):
+    """The operator the train step runs (msda_fused_*_strided_f32 on a merged [B, S, 384] projection, host pyramid
+    attached, 48x160 / 24x80 / 12x40 / 6x20) against the C oracle fed with the PyTorch-evaluated prologue
+    (softmax, ref + offset / (W, H): ms_deform_attn.py:146-152).  B = 16 is BASELINE configs[1]; the oracle checks two
+    of its samples.  offset_px = 11: most taps leave any tile-local window (fallback paths)."""
+    MSDA = _msda()
+    shapes, lsi, ref, offsets, logits, value, go = _kitti_encoder_inputs(B, 23 + B, offset_px)
+    S, M = value.shape[1], value.shape[2]
+    s, i = _dev(shapes), _dev(lsi)
+    MSDA.attach_host_geometry(s, i, shapes.tolist(), lsi.tolist())
+    proj = torch.cat([_dev(offsets).reshape(B, S, M * 32), _dev(logits).reshape(B, S, M * 16)], -1).contiguous()
+    refp = _dev(np.broadcast_to(ref[None, :, None, :], (B, S, 4, 2)).copy())
+    v, g = _dev(value), _dev(go)
+    out = MSDA.ms_deform_attn_fused_forward_merged(v, s, i, proj, refp)
+    gv, gproj = MSDA.ms_deform_attn_fused_backward_merged(v, s, i, proj, refp, g)
+    torch.cuda.synchronize()
+    # prologue in PyTorch on the device (the same f32 expressions the module evaluates), core through the oracle
+    off_t = _dev(offsets).requires_grad_(True)
+    log_t = _dev(logits).requires_grad_(True)
+    norm = torch.stack([s[:, 1], s[:, 0]], -1).float()
+    loc_t = refp[:, :, None, :, None, :] + off_t / norm[None, None, None, :, None, :]
+    aw_t = torch.softmax(log_t, -1).view(B, S, M, 4, 4)
+    for b in check:
+        loc_b, aw_b = loc_t[b:b + 1].detach().cpu().numpy(), aw_t[b:b + 1].detach().cpu().numpy()
+        want = (O.forward(value[b:b + 1], shapes, lsi, loc_b, aw_b),) + O.backward(value[b:b + 1], shapes, lsi, loc_b, aw_b, go[b:b + 1])
+        _close(out[b:b + 1], want[0], 1e-4, "fused out[%d]" % b)
+        _close_elementwise(out[b:b + 1], want[0], 1e-3, "fused out[%d]" % b)
+        _close(gv[b:b + 1], want[1], 1e-4, "fused grad_value[%d]" % b)
+        # chain the oracle's grad_loc / grad_attw through the prologue with autograd
+        gl = torch.from_numpy(want[2]).cuda()
+        ga = torch.from_numpy(want[3]).cuda()
+        g_off, g_log = torch.autograd.grad([loc_t[b:b + 1], aw_t[b:b + 1]], [off_t, log_t], [gl, ga], retain_graph=True)
+        got_off = gproj[b, :, :M * 32].reshape(1, S, M, 4, 4, 2)
+        got_log = gproj[b, :, M * 32:].reshape(1, S, M, 16)
+        assert (got_off - g_off[b:b + 1]).abs().max() <= 1e-4 * g_off[b].abs().max(), "grad_offsets[%d]" % b
+        assert (got_log - g_log[b:b + 1]).abs().max() <= 1e-4 * g_log[b].abs().max(), "grad_logits[%d]" % b
+
+
+def test_unfused_production_forward_b16_two_samples_vs_c_oracle():
+    """ms_deform_attn_forward / _backward with the host pyramid attached at BASELINE configs[1] (B = 16)."""
+    MSDA = _msda()
+    B = 16
+    shapes, lsi, ref, offsets, logits, value, go = _kitti_encoder_inputs(B, 41)
+    loc = (ref[None, :, None, None, None, :] + offsets / shapes[None, None, None, :, None, ::-1]).astype(np.float32)
+    e = np.exp(logits - logits.max(-1, keepdims=True))
+    aw = (e / e.sum(-1, keepdims=True)).reshape(B, -1, 8, 4, 4).astype(np.float32)
+    s, i = _dev(shapes), _dev(lsi)
+    MSDA.attach_host_geometry(s, i, shapes.tolist(), lsi.tolist())
+    v, lc, w, g = _dev(value), _dev(loc), _dev(aw), _dev(go)
+    out = MSDA.ms_deform_attn_forward(v, s, i, lc, w, 64)
+    gv, gl, gw = MSDA.ms_deform_attn_backward(v, s, i, lc, w, g, 64)
+    torch.cuda.synchronize()
+    for b in (0, 9):
+        want = (O.forward(value[b:b + 1], shapes, lsi, loc[b:b + 1], aw[b:b + 1]),) + \
+            O.backward(value[b:b + 1], shapes, lsi, loc[b:b + 1], aw[b:b + 1], go[b:b + 1])
+        _close(out[b:b + 1], want[0], 1e-4, "out[%d]" % b)
+        _close_elementwise(out[b:b + 1], want[0], 1e-3, "out[%d]" % b)
+        _close(gv[b:b + 1], want[1], 1e-4, "grad_value[%d]" % b)
+        _close(gl[b:b + 1], want[2], 1e-4, "grad_loc[%d]" % b)
+        _close(gw[b:b + 1], want[3], 1e-4, "grad_attw[%d]" % b)
+
+
+def test_host_pyramid_that_contradicts_the_tensors_is_refused():
+    """A host pyramid whose levels do not tile [0, S) must come back as MSDA_E_SHAPE, not as an out-of-bounds kernel."""
+    MSDA = _msda()
+    from monosowa_amd import _lib
+    levels = [(12, 40), (6, 20), (3, 10), (2, 5)]
+    value, shapes, lsi, loc, w, go = _random_case(5, 1, 8, 32, 64, levels, 4, np.float32)
+    v, s, i, lc, ww, g = map(_dev, (value, shapes, lsi, loc, w, go))
+    bad_shapes = [(12, 40), (6, 20), (3, 10), (4, 5)]                     # 10 rows more than S
+    geom = MSDA.attach_host_geometry(s, i, bad_shapes, lsi.tolist())
+    with pytest.raises(RuntimeError, match="dimension"):
+        MSDA.ms_deform_attn_forward(v, s, i, lc, ww, 64, host_geom=geom)
+    with pytest.raises(RuntimeError, match="dimension"):
+        MSDA.ms_deform_attn_backward(v, s, i, lc, ww, g, 64, host_geom=geom)
+    geom = MSDA.attach_host_geometry(s, i, levels, [0, 480, 600, 999])     # a level start past the end
+    with pytest.raises(RuntimeError, match="dimension"):
+        MSDA.ms_deform_attn_forward(v, s, i, lc, ww, 64, host_geom=geom)
+    del _lib
+
+
 def test_full_batch_properties_b16():
     """BASELINE configs[1] size (B=16, S=Lq=10200): size-independent properties.
     (1) a constant value field sampled strictly inside gives out = c * sum(w) = c;
@@ -184,6 +297,24 @@ def test_gradcheck_double_like_reference():
         aw = torch.rand(N, Lq, M, L, P).cuda() + 1e-5
         aw = (aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)).double().requires_grad_(True)
         assert torch.autograd.gradcheck(MSDeformAttnFunction.apply, (value, shapes, lsi, loc, aw, 2))
+
+
+@pytest.mark.parametrize("D", [1025, 2048, 3096])
+def test_gradcheck_double_large_channel_counts(D):
+    """The rest of ops/test.py:85's channel list (the reference's multi-block / global-memory backward variants,
+    cuh:731-920).  The full Jacobian of the value path is 8 GB at D = 2048, so these use gradcheck's fast mode
+    (directional derivatives along random vectors) -- same tolerance, every input covered."""
+    from monosowa_amd.ms_deform_attn_func import MSDeformAttnFunction
+    torch.manual_seed(3)
+    N, M, Lq, L, P = 1, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long).cuda()
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    value = (torch.rand(N, S, M, D).cuda() * 0.01).double().requires_grad_(True)
+    loc = torch.rand(N, Lq, M, L, P, 2).cuda().double().requires_grad_(True)
+    aw = torch.rand(N, Lq, M, L, P).cuda() + 1e-5
+    aw = (aw / aw.sum(-1, keepdim=True).sum(-2, keepdim=True)).double().requires_grad_(True)
+    assert torch.autograd.gradcheck(MSDeformAttnFunction.apply, (value, shapes, lsi, loc, aw, 2), fast_mode=True)
 
 
 def test_preconditions_on_gpu():
