@@ -22,14 +22,36 @@ struct Tap {
   bool valid;           // the cuh:274 test
 };
 
+// Individually rounded operations.  hipcc compiles device code with -ffp-contract=fast and HIP's "_rn" intrinsics for
+// multiply / add are plain `x * y` / `x + y` (__clang_hip_math.h), so a product handed to a subtraction through them still
+// becomes one v_fma -- found on a point whose rounded product lands exactly on k + 0.5 (loc * W = 8.49999964 -> 8.5 -> w_im
+// = 8.0, but 7.9999995 when fused): floor() and with it grad_loc change side.  The pragma removes the `contract` flag from
+// these operations themselves, which survives inlining.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+__device__ __forceinline__ double mul_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ double sub_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
 // Product rounded once, then the subtraction: the reference evaluates `loc * size - 0.5` with a
 // double literal, so the float product is rounded before the subtraction (no fused multiply-add).
-__device__ __forceinline__ float scale_loc(float loc, int size) {
-  return __fsub_rn(__fmul_rn(loc, (float)size), 0.5f);
-}
-__device__ __forceinline__ double scale_loc(double loc, int size) {
-  return __dsub_rn(__dmul_rn(loc, (double)size), 0.5);
-}
+__device__ __forceinline__ float scale_loc(float loc, int size) { return sub_rn(mul_rn(loc, (float)size), 0.5f); }
+__device__ __forceinline__ double scale_loc(double loc, int size) { return sub_rn(mul_rn(loc, (double)size), 0.5); }
 
 template <typename T>
 __device__ __forceinline__ Tap<T> make_tap(T loc_x, T loc_y, int H, int W) {
@@ -129,18 +151,18 @@ __device__ __forceinline__ RefScale load_ref(const float *rp, int ref_dim, int H
   r.rx = rp[0];
   r.ry = rp[1];
   if (ref_dim == 2) { r.sx = (float)W; r.sy = (float)H; }
-  else { r.sx = __fadd_rn(rp[2], rp[3]); r.sy = __fadd_rn(rp[4], rp[5]); }
+  else { r.sx = add_rn(rp[2], rp[3]); r.sy = add_rn(rp[4], rp[5]); }
   return r;
 }
 template <int P>
 __device__ __forceinline__ float loc_from_offset(float ref, float off, float s, int ref_dim) {
-  if (ref_dim == 2) return __fadd_rn(ref, __fdiv_rn(off, s));
-  return __fadd_rn(ref, __fmul_rn(__fmul_rn(__fdiv_rn(off, (float)P), s), 0.5f));
+  if (ref_dim == 2) return add_rn(ref, __fdiv_rn(off, s));
+  return add_rn(ref, mul_rn(mul_rn(__fdiv_rn(off, (float)P), s), 0.5f));
 }
 template <int P>
 __device__ __forceinline__ float offset_grad(float g, float s, int ref_dim) {       // autograd of the line above
   if (ref_dim == 2) return __fdiv_rn(g, s);
-  return __fdiv_rn(__fmul_rn(__fmul_rn(g, 0.5f), s), (float)P);
+  return __fdiv_rn(mul_rn(mul_rn(g, 0.5f), s), (float)P);
 }
 // sum / max over the 8 lanes of a (query, head) group (all lanes get the result)
 __device__ __forceinline__ float group_sum(float v) {

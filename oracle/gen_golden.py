@@ -387,7 +387,8 @@ def gen_decode():
     gen = torch.Generator().manual_seed(81)
     B, Q = 3, 50
     outputs = _seeded_outputs(gen, B, Q)
-    outputs["pred_logits"][0, 7] = outputs["pred_logits"][0, 3]          # exact ties in the top-k
+    outputs["pred_logits"][0, 3] = torch.tensor([3.0, 2.5, 2.0])         # exact score ties well inside the top-k (their
+    outputs["pred_logits"][0, 7] = outputs["pred_logits"][0, 3]          # relative order is device-dependent, membership is not)
     outputs["pred_logits"][1, :, 1] = 4.0 - torch.arange(Q) * 0.01       # many confident detections
     dets = dh.extract_dets_from_outputs(outputs, K=50, topk=50)
     P2 = np.array([[[721.54, 0, 609.56, 44.857], [0, 721.54, 172.85, 0.2163], [0, 0, 1, 0.002746]],

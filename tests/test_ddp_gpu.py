@@ -40,36 +40,46 @@ inputs = inputs.contiguous(memory_format=torch.channels_last)
 tl = prepare_targets(targets, 2)
 
 def step(net, crit, opt):
-    torch.manual_seed(7)                       # same dropout masks in both runs
+    torch.manual_seed(7)                       # same dropout masks in both runs: torch's generator and the HIP kernels'
+    from monosowa_amd import flash_attn, pointwise      # per-call seed counters (seed = f(initial_seed, counter, rank))
+    pointwise._seed_counter[0] = flash_attn._seed_counter[0] = 0
     opt.zero_grad(set_to_none=True)
     total = weighted_total(crit(net(inputs, calibs, tl, targets["img_size"]), tl), crit.weight_dict)
     total.backward()
     return total.detach()
 
 plain, crit_a, opt_a = build()
-wrapped_core, crit_b, opt_b = build()
+twin, crit_c, opt_c = build()                  # a second UNWRAPPED instance: measures the step's own run-to-run noise
+wrapped_core, crit_b, opt_b = build()          # (MIOpen's weight-gradient kernels and the coarse-level scatter use f32 atomics)
 ddp = wrap_ddp(wrapped_core, dev)
 assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel), "MONOSOWA_FORCE_DDP=1 must wrap at world size 1"
 frozen = set(wrapped_core.unused_parameter_names())
 assert frozen and all(not p.requires_grad for n, p in wrapped_core.named_parameters() if n in frozen)
 
+def deviation(ga, gb):
+    # per tensor, relative to its own largest entry -- but not below 1e-5 of the largest gradient in the model: the key
+    # biases of the attention blocks have an exactly-zero gradient (softmax is shift-invariant) that comes out as 1e-8 noise
+    gmax = max(g.abs().max().item() for g in ga.values())
+    return max((ga[n] - gb[n]).abs().max().item() / max(ga[n].abs().max().item(), 1e-5 * gmax) for n in ga)
+
 for it in range(2):                            # second iteration: bucket views are live, AdamW state exists
-    la, lb = step(plain, crit_a, opt_a), step(ddp, crit_b, opt_b)
+    la, lc, lb = step(plain, crit_a, opt_a), step(twin, crit_c, opt_c), step(ddp, crit_b, opt_b)
     assert torch.isfinite(la) and abs(la - lb) <= 1e-5 * abs(la), (la, lb)
     ga = {n: p.grad for n, p in plain.named_parameters() if p.grad is not None and n not in frozen}
+    gc = {n: p.grad for n, p in twin.named_parameters() if p.grad is not None and n not in frozen}
     gb = {n: p.grad for n, p in wrapped_core.named_parameters() if p.grad is not None}
     assert set(ga) == set(gb), sorted(set(ga) ^ set(gb))[:5]
-    worst = 0.0
-    for n in ga:
-        scale = ga[n].abs().max().item()
-        if scale > 0:
-            worst = max(worst, (ga[n] - gb[n]).abs().max().item() / scale)
-    assert worst <= 2e-4, worst                # f32 atomics of the coarse-level scatter are order-dependent
-    opt_a.step(); opt_b.step()
-    wa = dict(plain.named_parameters()); wb = dict(wrapped_core.named_parameters())
+    noise, worst = deviation(ga, gc), deviation(ga, gb)
+    assert worst <= 2e-4 + 3 * noise, (worst, noise)      # DDP adds nothing beyond the step's own nondeterminism
+    opt_a.step(); opt_c.step(); opt_b.step()
+    wa = dict(plain.named_parameters()); wb = dict(wrapped_core.named_parameters()); wc = dict(twin.named_parameters())
     dw = max((wa[n] - wb[n]).abs().max().item() for n in ga)
-    assert dw <= 1e-5, dw
-    print("iteration %d: loss %.5f, worst gradient deviation %.2e, worst weight deviation %.2e" % (it, la.item(), worst, dw))
+    dw_noise = max((wa[n] - wc[n]).abs().max().item() for n in ga)
+    # Adam's first steps move every weight by ~lr (2e-4) whatever the gradient's size: sign flips of noise-level
+    # gradients are the bound, measured by the unwrapped twin
+    assert dw <= 1e-6 + 3 * dw_noise, (dw, dw_noise)
+    print("iteration %d: loss %.5f, gradient deviation ddp %.2e / twin %.2e, weight deviation ddp %.2e / twin %.2e"
+          % (it, la.item(), worst, noise, dw, dw_noise))
 torch.cuda.synchronize()
 dist.barrier()
 dist.destroy_process_group()
@@ -87,4 +97,6 @@ def test_train_step_under_ddp_world_size_1_equals_the_unwrapped_step(tmp_path):
     env = dict(os.environ, MONOSOWA_ROOT=ROOT, MONOSOWA_FORCE_DDP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "ddp-ws1 ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    if r.returncode != 0 or "ddp-ws1 ok" not in r.stdout:
+        pytest.fail("DDP worker failed (rc %d)\n--- stdout ---\n%s\n--- stderr ---\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-6000:]),
+                    pytrace=False)

@@ -45,10 +45,12 @@ def _adamw_case(g, device):
         opt.step()
         for i, p in enumerate(params):
             want = torch.from_numpy(g["p%d_step%d" % (i, s)])
-            # element-wise: the update is lr-sized, so compare the CHANGE of every element, not the parameter
+            # element-wise: the stored parameter may differ by its own rounding (1 ulp) plus a fraction of the lr-sized
+            # UPDATE of that element (returned: error in units of ulp(p) + 2e-6 |update|)
             prev = torch.from_numpy(g["p%d_init" % i] if s == 0 else g["p%d_step%d" % (i, s - 1)])
-            d_want, d_got = (want - prev).double(), (p.detach().cpu() - prev).double()
-            worst = max(worst, ((d_got - d_want).abs() / (d_want.abs() + 1e-9)).max().item())
+            ulp = torch.from_numpy(np.spacing(np.abs(want.numpy()))).double()
+            allowed = ulp + 2e-6 * (want.double() - prev.double()).abs()
+            worst = max(worst, ((p.detach().cpu().double() - want.double()).abs() / allowed).max().item())
     for i, p in enumerate(params):
         st = opt.state[p]
         assert _rel(st["exp_avg"], g["m%d" % i]) < 1e-6 and _rel(st["exp_avg_sq"], g["v%d" % i]) < 1e-6
@@ -77,11 +79,12 @@ def test_adamw_cpu_equals_reference_class(golden_dir):
 @pytest.mark.gpu
 def test_adamw_hip_kernel_equals_reference_class(golden_dir):
     """mono_adamw_step_f32 (one launch per group, aligned and unaligned chunks) against the reference optimizer's
-    trajectory.  Tolerance: 2e-6 of every element's own update (the kernel contracts a*b+c into FMAs)."""
+    trajectory.  Tolerance per element: 1 ulp of the parameter + 2e-6 of its own update (the kernel contracts a*b+c
+    into FMAs; the CPU path above is bit for bit)."""
     from monosowa_amd import pointwise
-    assert pointwise.available()
+    assert pointwise.load().mono_adamw_step_f32 is not None            # the HIP library is loaded, not a fallback
     worst = _adamw_case(_npz(golden_dir, "adamw"), "cuda")
-    assert worst < 2e-6, worst
+    assert worst <= 1.0, worst
 
 
 # ------------------------------------------------------------------------------------------------ decode
@@ -97,8 +100,15 @@ def _decode_case(g, device):
     if device == "cpu":
         assert torch.equal(dets, want)
     else:
-        assert torch.equal(dets[:, :, gathered], want[:, :, gathered])
-        assert torch.allclose(dets, want, rtol=2e-6, atol=1e-7)
+        # torch.topk orders exact score ties differently on another device (unspecified in the reference too, whose own
+        # CUDA run is the one that matters): scores must come out sorted, and the ROWS must be the same set.  Rows are
+        # identified by their (x3d, y3d) columns, exact gathers of pred_boxes and unique per query.
+        assert (dets[:, :, 1][:, 1:] <= dets[:, :, 1][:, :-1]).all()
+        canon = lambda d: torch.stack([img[np.lexsort((img[:, 0].numpy(), img[:, 35].numpy(), img[:, 34].numpy()))] for img in d])
+        dets_c, want_c = canon(dets), canon(want)
+        assert torch.equal(dets_c[:, :, gathered], want_c[:, :, gathered])
+        assert torch.allclose(dets_c, want_c, rtol=2e-6, atol=1e-7)
+        dets = want.clone()           # decode below on the reference's own ordering
     info = {"img_id": g["info_img_id"], "img_size": g["info_img_size"], "height_crop": g["info_height_crop"],
             "canonical_scale": g["info_canonical_scale"]}
     calibs = [PinholeCalib(P) for P in g["P2"]]
