@@ -8,6 +8,10 @@
 #include "msda_backward_tiled.hip"
 #include "msda_backward_sorted.hip"
 #include "msda_gather_rec.hip"
+#include "msda_gather_win.hip"
+#include "msda_scatter_rows.hip"
+#include <map>
+#include <mutex>
 #include <cstdlib>
 #include <string>
 #include <algorithm>
@@ -50,12 +54,22 @@ struct Options {
   int scatter_fixed = 1;
   int scatter_sorted = 0;
   int gather_chunks_fwd = 16, gather_chunks_bwd = 8;      // query slices per (batch, head) of the staged gather kernels
+  int window = 3;              // tile-window gather kernels when Lq == S (msda_gather_win.hip): bit 0 forward, bit 1 backward
+  int window_halo = 5;         // pixels of the sampled level a window extends beyond its tile's queries
+  int window_debug = 0;        // timing experiments only (1: skip the window fill, 2: skip the compute): WRONG RESULTS
+  int scatter_rows = 1;        // 1 (default): row-tile scatter (msda_scatter_rows.hip) with the window backward when Lq == S
+  int scatter_reach = 6;       // its near-point reach in pixels (farther points: global atomics in the gather kernel)
   Options() {                                               // the environment is read ONCE, at first use
     if (const char *e = std::getenv("MSDA_GATHER")) gather = std::atoi(e);
     if (const char *e = std::getenv("MSDA_SCATTER_FIXED")) scatter_fixed = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSDA_SCATTER_SORTED")) scatter_sorted = std::atoi(e);
     if (const char *e = std::getenv("MSDA_GATHER_CHUNKS")) gather_chunks_fwd = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("MSDA_GATHER_CHUNKS_BWD")) gather_chunks_bwd = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("MSDA_WINDOW")) window = std::atoi(e) & 3;
+    if (const char *e = std::getenv("MSDA_WINDOW_DEBUG")) window_debug = std::atoi(e);
+    if (const char *e = std::getenv("MSDA_SCATTER_ROWS")) scatter_rows = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MSDA_SCATTER_REACH")) scatter_reach = std::min(16, std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("MSDA_WINDOW_HALO")) window_halo = std::min(32, std::max(0, std::atoi(e)));
   }
 };
 inline Options &options() {
@@ -115,14 +129,52 @@ bool make_gather_geom(const int64_t *shapes_host, const int64_t *lsi_host, int B
 }
 
 
+// Tiling of the tile-window kernels for a pyramid (searched once per geometry and halo, then cached).
+bool window_tiling(const int64_t *shapes_host, const int64_t *lsi_host, int halo, msda::WinGeom &out) {
+  static std::mutex mu;
+  static std::map<std::vector<int64_t>, std::pair<bool, msda::WinGeom>> cache;
+  std::vector<int64_t> key(shapes_host, shapes_host + 8);
+  key.insert(key.end(), lsi_host, lsi_host + 4);
+  key.push_back(halo);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    msda::WinGeom g{};
+    const bool ok = msda::choose_window_tiling(shapes_host, lsi_host, halo, g);
+    it = cache.emplace(key, std::make_pair(ok, g)).first;
+  }
+  out = it->second.second;
+  return it->second.first;
+}
+
+inline bool window_applies(bool bwd, const int64_t *shapes_host, const int64_t *lsi_host, int Lq, int S) {
+  msda::WinGeom wg;
+  return Lq == S && (options().window & (bwd ? 2 : 1)) && gather_mode() > 1 &&
+         window_tiling(shapes_host, lsi_host, options().window_halo, wg);
+}
+
 // Launch of the record-based gather kernels (forward or the backward's grad_loc / grad_attn_w pass), staged when
 // the tail of the pyramid fits LDS and the option allows it.
 template <bool BWD, bool FUSED>
 void launch_gather(const float *value, const float *loc, const float *attw, const float *grad_out, float *out,
                    float *grad_loc, float *grad_attw, const float *ref, int ref_dim, const int64_t *shapes_host,
-                   const int64_t *lsi_host, int B, int S, int M, int Lq, hipStream_t stream, int loc_rs = 0, int aw_rs = 0) {
+                   const int64_t *lsi_host, int B, int S, int M, int Lq, hipStream_t stream, int loc_rs = 0, int aw_rs = 0,
+                   float *grad_value = nullptr, int far_reach = -1) {
   if (!loc_rs) loc_rs = M * 32;
   if (!aw_rs) aw_rs = M * 16;
+  if (Lq == S && (options().window & (BWD ? 2 : 1)) && gather_mode() > 1) {
+    // self-attention shape: query i sits at token i's pixel -> tile-local value windows (msda_gather_win.hip)
+    msda::WinGeom wg;
+    if (window_tiling(shapes_host, lsi_host, options().window_halo, wg)) {
+      const int bm_groups = (B * M + 7) / 8;
+      msda::WinTable wt;
+      msda::fill_window_table(wg, wt);
+      msda::gather_win_kernel<BWD, FUSED><<<8 * wg.n_ty * wg.n_tx * bm_groups, msda::kWinThreads, 0, stream>>>(
+          value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, wt, B, S, M, loc_rs, aw_rs, options().window_debug,
+          grad_value, far_reach);
+      return;
+    }
+  }
   msda::GatherGeom geom;
   const long long n_pairs = (long long)B * Lq * M;
   const bool staged = make_gather_geom(shapes_host, lsi_host, B, M, Lq, S, geom, BWD) && gather_mode() > 1;
@@ -253,6 +305,38 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         lsi_host = host_geom + 2 * L;
       }
       if (int e = check_host_geometry(shapes_host, lsi_host, L, S)) return e;
+      // self-attention shape: row-tile scatter + window gather (no transposed lists, no LDS atomics per channel)
+      if (options().scatter_rows && window_applies(true, shapes_host, lsi_host, Lq, S)) {
+        msda::RowPlan rp;
+        if (msda::make_row_plan(shapes_host, lsi_host, options().scatter_reach, rp) &&
+            msda::row_plan_table_bytes(rp) <= workspace_bytes) {
+          msda::RowCandidate *table = reinterpret_cast<msda::RowCandidate *>(workspace);
+          int n_tiles = 0;
+          for (int l = 0; l < 4; ++l) n_tiles += rp.n_ty[l] * rp.n_tx[l];
+          msda::row_candidates_kernel<<<n_tiles, 256, 0, stream>>>(rp, table);
+          for (int l = 0; l < L; ++l) {          // levels shared by several workgroups are accumulated with atomics
+            if (rp.n_chunks[l] == 1) continue;
+            hipError_t e = hipMemset2DAsync(grad_value + (size_t)rp.start[l] * M * 32, sizeof(float) * (size_t)S * M * 32, 0,
+                                            sizeof(float) * (size_t)rp.H[l] * rp.W[l] * M * 32, B, stream);
+            if (e != hipSuccess) return (int)e;
+          }
+          const int groups = (B * M + 7) / 8;
+          const int lrs = loc_rs ? loc_rs : M * 32, ars = aw_rs ? aw_rs : M * 16;
+          if (fused_ref)
+            msda::scatter_rows_kernel<true><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
+                loc, attw, grad_out, grad_value, fused_ref, fused_ref_dim, table, rp, B, S, M, lrs, ars);
+          else
+            msda::scatter_rows_kernel<false><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
+                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, lrs, ars);
+          if (fused_ref)
+            launch_gather<true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
+                                      shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, rp.reach);
+          else
+            launch_gather<true, false>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, nullptr, 0, shapes_host,
+                                       lsi_host, B, S, M, Lq, stream, 0, 0, grad_value, rp.reach);
+          return (int)hipGetLastError();
+        }
+      }
       const msda::BwdPlan plan = make_plan(shapes_host, lsi_host, L, Lq, P);
       if ((long long)Lq * P >= (1LL << (62 - msda::kFixBits))) return MSDA_E_SHAPE;   // fixed-point headroom
       const TiledWorkspace ws = tiled_workspace(B, M, L, Lq, P);
@@ -322,6 +406,10 @@ int msda_set_option(const char *name, int value) {
   if (n == "gather" && value >= 0 && value <= 2) { options().gather = value; return 0; }
   if (n == "scatter_fixed" && (value == 0 || value == 1)) { options().scatter_fixed = value; return 0; }
   if (n == "scatter_sorted" && value >= 0 && value <= 2) { options().scatter_sorted = value; return 0; }
+  if (n == "window" && value >= 0 && value <= 3) { options().window = value; return 0; }
+  if (n == "window_halo" && value >= 0 && value <= 32) { options().window_halo = value; return 0; }
+  if (n == "scatter_rows" && (value == 0 || value == 1)) { options().scatter_rows = value; return 0; }
+  if (n == "scatter_reach" && value >= 1 && value <= 16) { options().scatter_reach = value; return 0; }
   return MSDA_E_UNSUPPORTED;
 }
 

@@ -16,6 +16,7 @@ namespace msda {
 template <typename T>
 struct Tap {
   int y0, y1, x0, x1;   // clamped rows / columns of the 2x2 footprint
+  int h_low, w_low;     // unclamped top-left corner (0 for a point that fails the cuh:274 test)
   T w1, w2, w3, w4;     // (y0,x0) (y0,x1) (y1,x0) (y1,x1); 0 where the corner is outside
   T lh, lw, hh, hw;     // fractional offsets (for the location gradient)
   bool t, b, l, r;      // which rows / columns are inside
@@ -65,6 +66,8 @@ __device__ __forceinline__ Tap<T> make_tap(T loc_x, T loc_y, int H, int W) {
   const T ws = tp.valid ? w_im : (T)0;
   const T hf = floor(hs), wf = floor(ws);
   const int h_low = (int)hf, w_low = (int)wf;
+  tp.h_low = h_low;
+  tp.w_low = w_low;
   tp.lh = hs - hf;
   tp.lw = ws - wf;
   tp.hh = (T)1 - tp.lh;
@@ -82,6 +85,25 @@ __device__ __forceinline__ Tap<T> make_tap(T loc_x, T loc_y, int H, int W) {
   tp.x0 = max(w_low, 0);
   tp.x1 = min(w_low + 1, W - 1);
   return tp;
+}
+
+// ---- "near" points of the self-attention shape (Lq == S: query i sits at token i's pixel) --------------------------------
+// A query at pixel c of a level of extent Nq has its centre at (c + 0.5) / Nq * N - 0.5 in pixels of a level of extent N;
+// centre_floor is the floor of that (the same integer formula on the host: msda_window.h / msda_scatter_plan.h).  A sampling
+// point is NEAR when the top-left corner of its bilinear footprint lies within `reach` pixels of that, in both axes.  The
+// row-tile scatter (msda_scatter_rows.hip) finds the near points of a value tile by scanning the queries around it; every
+// other point ("far": long learned offsets) is added to grad_value by the gather kernel with global atomics.  Both kernels
+// evaluate THIS function, so the two sets partition the points exactly.
+__device__ __forceinline__ int centre_floor(int c, int Nq, int N) {
+  // floor(num / den), den > 0, |num| < 2^23 (host: level extents <= 2048): a float estimate, then an exact integer fix-up
+  const int num = (2 * c + 1) * N - Nq, den = 2 * Nq;
+  int q = (int)floorf((float)num / (float)den);
+  const int r = num - q * den;
+  q += (r >= den) - (r < 0);
+  return q;
+}
+__device__ __forceinline__ bool near_point(int h_low, int w_low, int cy, int cx, int reach) {
+  return abs(h_low - cy) <= reach && abs(w_low - cx) <= reach;
 }
 
 // XCD-aware work mapping (speed only, never correctness): workgroups are dealt round-robin over the 8
@@ -115,6 +137,8 @@ __device__ __forceinline__ Tap<float> make_tap_im(float h_im, float w_im, int H,
   tp.valid = true;
   const float hf = floorf(h_im), wf = floorf(w_im);
   const int h_low = (int)hf, w_low = (int)wf;
+  tp.h_low = h_low;
+  tp.w_low = w_low;
   tp.lh = h_im - hf;
   tp.lw = w_im - wf;
   tp.hh = 1.f - tp.lh;

@@ -1,0 +1,235 @@
+// grad_value of the self-attention shape (Lq == S), d32 path: exclusive ROW TILES accumulated in registers.
+// Plan and geometry: msda_scatter_plan.h.
+//
+// The tile-owner generation (msda_backward_tiled.hip) is bound by LDS atomics: one ds_add_u64 per (point, corner, channel)
+// = 2.7 G of them per launch at B = 16, behind a transposing pre-pass (K1: 0.8 GB of traffic) and with grad_out rows
+// fetched per hit from L2.  Here a workgroup owns <= 256 value rows of one level of one (batch, head); each row belongs to 2
+// lanes (16 channels = four float4 accumulators each).  The points that can reach the tile come from a per-tile scan list of
+// candidate queries (the queries whose pixel centre lies within reach + 1 pixels of the tile; built once per call by
+// row_candidates_kernel and shared by all batch x head planes).  Per batch of 128 candidates:
+//   1. thread = (candidate, one of the level's 4 points): loads the point straight from loc / attn_w (fused: offsets /
+//      logits / reference points -- no transposed copy), resolves its tap; the batch's grad_out rows go to LDS (16 KB);
+//   2. every corner that lands in the tile takes a slot in its ROW's bucket (one ds_add_rtn_u32 per corner -- 1/32 of the
+//      atomics of the per-channel scheme) and leaves {weight, candidate};
+//   3. the row's 2 lanes walk the bucket: 4 x ds_read_b128 of grad_out + 16 FMAs per hit, sums stay in registers.
+// The inputs of a batch are fetched one batch ahead (candidate entries two ahead).
+// Single-workgroup tiles are written with plain 128-byte rows (no zero fill, no global atomics); levels whose scan lists
+// are split over workgroups add full rows atomically into a zeroed region.
+// Only NEAR points are scanned (near_point(), msda_common.h); the rest is added by the gather kernel (msda_gather_win.hip).
+#include "msda_common.h"
+#include "msda_scatter_plan.h"
+
+namespace msda {
+
+// Workgroup barrier for LDS hand-offs that leaves global loads in flight: __syncthreads() carries a workgroup-scope fence
+// that lowers to s_waitcnt vmcnt(0) as well, i.e. every barrier would wait for the next batch's prefetch.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// scan lists: one workgroup per (level, tile)
+__global__ __launch_bounds__(256) void row_candidates_kernel(const RowPlan p, RowCandidate *__restrict__ table) {
+  int l = 0, t = blockIdx.x;
+  while (l < 3 && t >= p.n_ty[l] * p.n_tx[l]) { t -= p.n_ty[l] * p.n_tx[l]; ++l; }
+  const int ty = t / p.n_tx[l], tx = t - ty * p.n_tx[l];
+  const RowAxis ay = p.ax[p.axis0[l] + ty], ax = p.ax[p.axis0[l] + p.n_ty[l] + tx];
+  RowCandidate *out = table + p.cand_base[l] + (long long)t * p.cand_stride[l];
+  int first = 0;
+  for (int lq = 0; lq < 4; ++lq) {
+    const int n = (int)ay.qn[lq] * (int)ax.qn[lq], w = ax.qn[lq];
+    for (int k = threadIdx.x; k < n; k += 256) {
+      const int dy = k / w, dx = k - dy * w;
+      const int yq = ay.q0[lq] + dy, xq = ax.q0[lq] + dx;
+      RowCandidate c;
+      c.token = p.start[lq] + yq * p.W[lq] + xq;
+      c.cy = (short)centre_floor(yq, p.H[lq], p.H[l]);
+      c.cx = (short)centre_floor(xq, p.W[lq], p.W[l]);
+      out[first + k] = c;
+    }
+    first += n;
+  }
+}
+
+// FUSED: `loc` / `attw` carry raw sampling offsets / attention logits, `ref` the reference points [B, Lq, 4, ref_dim].
+template <bool FUSED>
+__global__ __launch_bounds__(kRowThreads, 6) void scatter_rows_kernel(
+    const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out,
+    float *__restrict__ grad_value, const float *__restrict__ ref, int ref_dim, const RowCandidate *__restrict__ table,
+    const RowPlan p, int B, int S, int M, int loc_rs, int aw_rs) {
+  __shared__ float4 go_lds[kRowBatchQueries * 8];          // grad_out rows of the batch's candidates (this head), 16 KB
+  __shared__ uint2 bucket[kRowBucketEntries];              // per row: {weight bits, candidate slot}, 32 KB
+  __shared__ unsigned count[kRowTileRows];
+  __shared__ int overflow;                                 // some bucket was full: the batch needs another round
+
+  // blockIdx -> (batch * head, item); all items of one (batch, head) share blockIdx % 8, i.e. one XCD (speed only)
+  const int bm = (int)(blockIdx.x % 8) + 8 * (int)(blockIdx.x / (8 * p.n_items));
+  if (bm >= B * M) return;
+  const int it = (int)((blockIdx.x / 8) % p.n_items);
+  const int b = bm / M, m = bm - b * M;
+  int oi = 0;
+  while (oi < 3 && it >= p.first_item[oi + 1]) ++oi;
+  const int l = p.order[oi];
+  const int local = it - p.first_item[oi];
+  const int n_chunks = p.n_chunks[l];
+  const int chunk = local % n_chunks, tile = local / n_chunks;
+  const int ty = tile / p.n_tx[l], tx = tile - ty * p.n_tx[l];
+  const RowAxis ay = p.ax[p.axis0[l] + ty], ax = p.ax[p.axis0[l] + p.n_ty[l] + tx];
+  const int H = p.H[l], W = p.W[l];
+  const int y0 = ay.r0, x0 = ax.r0, th = ay.rn, tw = ax.rn, n_rows = th * tw;
+  // bucket slots per row and round (>= 15); rows are cap + 1 entries apart: with a power-of-two stride every row's bucket
+  // would start on the same LDS bank (counters: 58 % of the LDS cycles were bank conflicts)
+  const int cap = kRowBucketEntries / n_rows - 1, bstride = cap + 1;
+  int n_cand = 0;
+#pragma unroll
+  for (int lq = 0; lq < 4; ++lq) n_cand += (int)ay.qn[lq] * (int)ax.qn[lq];
+  const int c_begin = (int)((long long)n_cand * chunk / n_chunks), c_end = (int)((long long)n_cand * (chunk + 1) / n_chunks);
+  const RowCandidate *cands = table + p.cand_base[l] + (long long)tile * p.cand_stride[l];
+
+  const int tid = threadIdx.x;
+  const int slot = tid >> 2, pt = tid & 3;                 // scan role: candidate slot of the batch, point of level l
+  const int r = tid >> 1, half = tid & 1;                  // gather role: row of the tile, half of its 32 channels
+  if (tid < kRowTileRows) count[tid] = 0;
+  if (tid == 0) overflow = 0;
+  float4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // one batch of inputs per thread, fetched one batch AHEAD of its use (the scan is otherwise a chain of two dependent
+  // memory round trips per batch: candidate -> point): candidate entries run two batches ahead
+  struct Inputs { float4 g0, g1, lg; float2 xy; float wt; RefScale rs; short cy, cx; };
+  auto candidate = [&](const int j) {
+    RowCandidate c{0, 0, 0};
+    if (j < c_end) c = cands[j];
+    return c;
+  };
+  auto fetch = [&](const int j, const RowCandidate c) {
+    Inputs in{};
+    in.cy = c.cy; in.cx = c.cx;
+    if (j < c_end) {
+      const long long q_lin = (long long)b * S + c.token;                          // Lq == S
+      const float *gp = grad_out + (q_lin * M + m) * 32 + pt * 8;
+      in.g0 = ld4(gp);
+      in.g1 = ld4(gp + 4);
+      in.xy = *reinterpret_cast<const float2 *>(loc + q_lin * loc_rs + ((m * 4 + l) * 4 + pt) * 2);
+      if (FUSED) {
+        const float *lg = attw + q_lin * aw_rs + m * 16;
+        in.lg = ld4(lg + pt * 4);                  // the candidate's 4 threads take one level's four logits each
+        in.wt = lg[l * 4 + pt];                    // own logit
+        in.rs = load_ref(ref + (q_lin * 4 + l) * ref_dim, ref_dim, H, W);
+      } else {
+        in.wt = attw[q_lin * aw_rs + (m * 4 + l) * 4 + pt];
+      }
+    }
+    return in;
+  };
+  // Batch k takes candidates k, k + n_batches, k + 2 n_batches, ... of the chunk: a batch then samples the whole scan
+  // region.  Neighbouring queries sample alike (the model's offsets are a per-head pattern), so a batch of NEIGHBOURS
+  // lands on a handful of rows of a coarse level -- hundreds of hits per row against a bucket of ~32 (many overflow
+  // rounds with most lanes idle: measured 1.95 ms per backward in the train step against 1.45 ms on random offsets).
+  const int n_batches = (c_end - c_begin + kRowBatchQueries - 1) / kRowBatchQueries;
+  auto cand_index = [&](const int k) { return k < n_batches ? c_begin + k + slot * n_batches : c_end; };
+  RowCandidate c_next = candidate(cand_index(0));
+  Inputs nxt = fetch(cand_index(0), c_next);
+  c_next = candidate(cand_index(1));
+  lds_barrier();
+
+  for (int k = 0; k < n_batches; ++k) {
+    const bool have = cand_index(k) < c_end;
+    const Inputs in = nxt;
+    nxt = fetch(cand_index(k + 1), c_next);
+    c_next = candidate(cand_index(k + 2));
+    // ---- 1. this thread's point ------------------------------------------------------------------------------------
+    unsigned pend = 0;
+    int rows[4] = {0, 0, 0, 0};
+    float coef[4] = {0.f, 0.f, 0.f, 0.f};
+    float lx = in.xy.x, ly = in.xy.y, wt = in.wt;
+    if (FUSED) {
+      // softmax over the pair's 16 logits (quad reductions over the candidate's 4 threads)
+      float mx = fmaxf(fmaxf(in.lg.x, in.lg.y), fmaxf(in.lg.z, in.lg.w));
+      mx = fmaxf(mx, dpp_x<0xB1>(mx)); mx = fmaxf(mx, dpp_x<0x4E>(mx));
+      float sum = expf(in.lg.x - mx) + expf(in.lg.y - mx) + expf(in.lg.z - mx) + expf(in.lg.w - mx);
+      sum += dpp_x<0xB1>(sum); sum += dpp_x<0x4E>(sum);
+      wt = expf(in.wt - mx) / sum;
+      lx = loc_from_offset<4>(in.rs.rx, lx, in.rs.sx, ref_dim);
+      ly = loc_from_offset<4>(in.rs.ry, ly, in.rs.sy, ref_dim);
+    }
+    if (have) {
+      go_lds[slot * 8 + ((pt * 2) ^ (slot & 7))] = in.g0;          // chunk c of slot s at c ^ (s & 7): the gather's lanes read
+      go_lds[slot * 8 + ((pt * 2 + 1) ^ (slot & 7))] = in.g1;      // the same chunk of different rows -> different banks
+      const Tap<float> tp = make_tap<float>(lx, ly, H, W);
+      if (tp.valid && near_point(tp.h_low, tp.w_low, in.cy, in.cx, p.reach)) {
+        const int ry0 = tp.y0 - y0, ry1 = tp.y1 - y0, rx0 = tp.x0 - x0, rx1 = tp.x1 - x0;
+        const bool iy0 = tp.t && (unsigned)ry0 < (unsigned)th, iy1 = tp.b && (unsigned)ry1 < (unsigned)th;
+        const bool ix0 = tp.l && (unsigned)rx0 < (unsigned)tw, ix1 = tp.r && (unsigned)rx1 < (unsigned)tw;
+        rows[0] = ry0 * tw + rx0; rows[1] = ry0 * tw + rx1; rows[2] = ry1 * tw + rx0; rows[3] = ry1 * tw + rx1;
+        coef[0] = tp.w1 * wt; coef[1] = tp.w2 * wt; coef[2] = tp.w3 * wt; coef[3] = tp.w4 * wt;
+        pend = (iy0 && ix0 ? 1u : 0u) | (iy0 && ix1 ? 2u : 0u) | (iy1 && ix0 ? 4u : 0u) | (iy1 && ix1 ? 8u : 0u);
+      }
+    }
+    // ---- 2./3. buckets and row sums; a row whose bucket overflows (many points on one pixel) takes more rounds -----------
+    bool again;
+    do {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (pend & (1u << c)) {
+          const unsigned rank = atomicAdd(&count[rows[c]], 1u);
+          if (rank < (unsigned)cap) {
+            bucket[rows[c] * bstride + rank] = make_uint2(__float_as_uint(coef[c]), (unsigned)slot);
+            pend &= ~(1u << c);
+          }
+        }
+      if (pend) overflow = 1;                // rare
+      lds_barrier();
+      if (r < n_rows) {
+        const int n = min((int)count[r], cap);
+        const uint2 *bk = bucket + r * bstride;
+        for (int i = 0; i < n; ++i) {
+          const uint2 e = bk[i];
+          const float w = __uint_as_float(e.x);
+          const float4 *g4 = go_lds + e.y * 8;
+          const int sw = (half * 4) ^ (e.y & 7);     // grad_out rows are stored with their 16-byte chunks XOR-swizzled by the slot
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float4 a = g4[k ^ sw];
+            acc[k].x += w * a.x; acc[k].y += w * a.y; acc[k].z += w * a.z; acc[k].w += w * a.w;
+          }
+        }
+        if (half == 0) count[r] = 0;         // the row's two lanes sit in one wave: both have read it
+      }
+      lds_barrier();                       // orders the gather before the next appends / grad_out rows
+      again = overflow != 0;                 // written before the first barrier of the round: the same value for everyone
+      if (again) {
+        lds_barrier();
+        if (tid == 0) overflow = 0;
+        lds_barrier();
+      }
+    } while (again);
+  }
+
+  // ---- write the tile -------------------------------------------------------------------------------------------------
+  const long long tok0 = (long long)b * S + p.start[l];
+  if (n_chunks == 1) {
+    if (r < n_rows) {
+      const int ry = r / tw, rx = r - ry * tw;
+      float *dst = grad_value + ((tok0 + (long long)(y0 + ry) * W + (x0 + rx)) * M + m) * 32 + half * 16;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) st4(dst + 4 * k, acc[k]);
+    }
+  } else {
+    // several workgroups share the tile: full 128-byte rows of atomics (lane = channel), through LDS
+    float *rows_lds = reinterpret_cast<float *>(bucket);
+    if (r < n_rows) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *reinterpret_cast<float4 *>(rows_lds + r * 32 + half * 16 + 4 * k) = acc[k];
+    }
+    __syncthreads();
+    const int ch = tid & 31;
+    for (int rr = tid >> 5; rr < n_rows; rr += kRowThreads / 32) {
+      const float v = rows_lds[rr * 32 + ch];
+      const int ry = rr / tw, rx = rr - ry * tw;
+      if (v != 0.f) atomicAdd(grad_value + ((tok0 + (long long)(y0 + ry) * W + (x0 + rx)) * M + m) * 32 + ch, v);
+    }
+  }
+}
+
+}  // namespace msda

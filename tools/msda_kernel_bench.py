@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from monosowa_amd import MultiScaleDeformableAttention as MSDA  # noqa: E402
 
 LEVELS = [(48, 160), (24, 80), (12, 40), (6, 20)]
+INIT_LIKE = os.environ.get("MSDA_BENCH_INIT_LIKE") == "1"     # encoder offsets as the freshly initialised module produces them
 HBM_PEAK = 8.0e12
 
 
@@ -31,7 +32,18 @@ def make(B, Lq_kind, dev, seed=0):
         ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, device=dev) + 0.5) / h,
                                                     (torch.arange(w, device=dev) + 0.5) / w, indexing="ij")[::-1], -1).reshape(-1, 2)
                          for h, w in LEVELS])
-        off = (torch.rand(B, Lq, M, L, P, 2, device=dev, generator=g) * 8 - 4) / shapes.flip(1)[None, None, None, :, None, :]
+        if INIT_LIKE:
+            # the module's initial sampling_offsets bias (ms_deform_attn.py:106-114): head m looks along angle 2 pi m / M,
+            # point p sits p + 1 pixels out (direction normalised to max-abs 1) + a little learned jitter
+            import math
+            th = torch.arange(M, dtype=torch.float32, device=dev) * (2.0 * math.pi / M)
+            d = torch.stack([th.cos(), th.sin()], -1)
+            d = d / d.abs().max(-1, keepdim=True)[0]
+            px = d[None, None, :, None, None, :] * torch.arange(1, P + 1, device=dev)[None, None, None, None, :, None]
+            px = px + 0.02 * torch.randn(B, Lq, M, L, P, 2, device=dev, generator=g)
+            off = px / shapes.flip(1)[None, None, None, :, None, :]
+        else:
+            off = (torch.rand(B, Lq, M, L, P, 2, device=dev, generator=g) * 8 - 4) / shapes.flip(1)[None, None, None, :, None, :]
         loc = (ref[None, :, None, None, None, :] + off).contiguous()
     else:
         Lq = int(Lq_kind)
