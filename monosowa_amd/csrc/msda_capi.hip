@@ -56,7 +56,6 @@ struct Options {
   int gather_chunks_fwd = 16, gather_chunks_bwd = 8;      // query slices per (batch, head) of the staged gather kernels
   int window = 3;              // tile-window gather kernels when Lq == S (msda_gather_win.hip): bit 0 forward, bit 1 backward
   int window_halo = 5;         // pixels of the sampled level a window extends beyond its tile's queries
-  int window_debug = 0;        // timing experiments only (1: skip the window fill, 2: skip the compute): WRONG RESULTS
   int scatter_rows = 1;        // 1 (default): row-tile scatter (msda_scatter_rows.hip) with the window backward when Lq == S
   int scatter_reach = 6;       // its near-point reach in pixels (farther points: global atomics in the gather kernel)
   Options() {                                               // the environment is read ONCE, at first use
@@ -66,7 +65,6 @@ struct Options {
     if (const char *e = std::getenv("MSDA_GATHER_CHUNKS")) gather_chunks_fwd = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("MSDA_GATHER_CHUNKS_BWD")) gather_chunks_bwd = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("MSDA_WINDOW")) window = std::atoi(e) & 3;
-    if (const char *e = std::getenv("MSDA_WINDOW_DEBUG")) window_debug = std::atoi(e);
     if (const char *e = std::getenv("MSDA_SCATTER_ROWS")) scatter_rows = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSDA_SCATTER_REACH")) scatter_reach = std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("MSDA_WINDOW_HALO")) window_halo = std::min(32, std::max(0, std::atoi(e)));
@@ -170,7 +168,7 @@ void launch_gather(const float *value, const float *loc, const float *attw, cons
       msda::WinTable wt;
       msda::fill_window_table(wg, wt);
       msda::gather_win_kernel<BWD, FUSED><<<8 * wg.n_ty * wg.n_tx * bm_groups, msda::kWinThreads, 0, stream>>>(
-          value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, wt, B, S, M, loc_rs, aw_rs, options().window_debug,
+          value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, wt, B, S, M, loc_rs, aw_rs,
           grad_value, far_reach);
       return;
     }

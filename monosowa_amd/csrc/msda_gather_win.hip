@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
     const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attw,
     const float *__restrict__ grad_out, float *__restrict__ out, float *__restrict__ grad_loc,
     float *__restrict__ grad_attw, const float *__restrict__ ref, int ref_dim, const WinTable g, int B, int S, int M,
-    int loc_rs, int aw_rs, int dbg, float *__restrict__ grad_value, int far_reach) {
+    int loc_rs, int aw_rs, float *__restrict__ grad_value, int far_reach) {
   // far_reach >= 0 (backward, with msda_scatter_rows.hip): points that are not near_point(.., far_reach) add their
   // grad_value contributions here with global atomics -- the row-tile scatter handles exactly the near ones
   __shared__ float4 win[(kWinMaxRows + 1) * 8];                 // value windows, 8 float4 = one 128-byte row; + the zero row
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
       const int k = i - (ql == 0 ? 0 : (ql == 1 ? first1 : (ql == 2 ? first2 : first3)));
       const int dy = (int)(((float)k + 0.5f) / (float)axq.qn), dx = k - dy * axq.qn;          // exact: k < 256
       q_lin[ps] = b * S + g.start[ql] + (ayq.q0 + dy) * g.W[ql] + axq.q0 + dx;                // Lq == S
-      if (BWD) {
+      if (BWD && far_reach >= 0) {
         cf_y[ps] = centre_floor(ayq.q0 + dy, g.H[ql], g.H[sub >> 1]);
         cf_x[ps] = centre_floor(axq.q0 + dx, g.W[ql], g.W[sub >> 1]);
       }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
       const int ww = ax.wn, n_rows = (int)ay.wn * ww, Wl = g.W[l];
       const int first_tok = g.start[l] + (int)ay.w0 * Wl + ax.w0;
       const float inv_ww = 1.0f / (float)ww;
-      for (int r0 = wave * 8; r0 < n_rows && !(dbg & 1); r0 += kWinThreads / 8) {
+      for (int r0 = wave * 8; r0 < n_rows; r0 += kWinThreads / 8) {
         const int r = r0 + (lane >> 3);
         float4 *dst = win + (size_t)(rows + r0) * 8;                           // wave-uniform; lane i lands at dst + i
         if (r < n_rows) {
@@ -161,15 +161,9 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
                          loc_from_offset<4>(rs.rx, l4.z, rs.sx, ref_dim), loc_from_offset<4>(rs.ry, l4.w, rs.sy, ref_dim));
       }
     }
-    // backward: grad_out of the pair, all 32 channels in every lane (8 x 16-byte broadcast loads from L1), rotated as row()
-    float4 gq[BWD ? 8 : 1];
-    if (BWD) {
-      const float *gp = grad_out + (ql64 * M + m) * 32;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) gq[s] = live[ps] ? ld4(gp + 4 * (s ^ rot)) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
     int off[2][4];
     float cw[2][4];          // forward: corner weights x attn_w.  backward: lh, lw, W attn_w, H attn_w
+    int far_points = 0;      // backward with the row-tile scatter: which of the two points it does not cover
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
       const float lx = k2 ? l4.z : l4.x, ly = k2 ? l4.w : l4.y, wt = k2 ? a2.y : a2.x;
@@ -191,31 +185,14 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
       off[k2][3] = pick(lds00 + ldy + ldx, mem00 + mdy + mdx, tp.b && tp.r);
       if (BWD) { cw[k2][0] = tp.lh; cw[k2][1] = tp.lw; cw[k2][2] = (float)Wm * wt; cw[k2][3] = (float)Hm * wt; }
       else { cw[k2][0] = tp.w1 * wt; cw[k2][1] = tp.w2 * wt; cw[k2][2] = tp.w3 * wt; cw[k2][3] = tp.w4 * wt; }
-      if (BWD && far_reach >= 0 && live[ps] && tp.valid && !near_point(tp.h_low, tp.w_low, cf_y[ps], cf_x[ps], far_reach)) {
-        // a far point (rare): its four corner contributions w_corner attn_w grad_out[q, m, :] (cuh:125-152)
-        float *gv = grad_value + ((long long)b * S * M + m) * 32;
-        auto corner_add = [&](const int y, const int x, const bool keep, const float w) {
-          if (!keep) return;
-          float *row_p = gv + (long long)(start_m + y * Wm + x) * tok;
-          const float cwt = w * wt;
-#pragma unroll
-          for (int s2 = 0; s2 < 8; ++s2) {
-            float *d4 = row_p + 4 * (s2 ^ rot);
-            atomicAdd(d4, cwt * gq[s2].x); atomicAdd(d4 + 1, cwt * gq[s2].y); atomicAdd(d4 + 2, cwt * gq[s2].z); atomicAdd(d4 + 3, cwt * gq[s2].w);
-          }
-        };
-        corner_add(tp.y0, tp.x0, tp.t && tp.l, tp.w1);
-        corner_add(tp.y0, tp.x1, tp.t && tp.r, tp.w2);
-        corner_add(tp.y1, tp.x0, tp.b && tp.l, tp.w3);
-        corner_add(tp.y1, tp.x1, tp.b && tp.r, tp.w4);
-      }
+      if (BWD && far_reach >= 0 && live[ps] && tp.valid && !near_point(tp.h_low, tp.w_low, cf_y[ps], cf_x[ps], far_reach))
+        far_points |= 1 << k2;
     }
     if (!waited) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's share of the windows has landed
       __syncthreads();                                                    // ... and everyone else's
       waited = true;
     }
-    if (dbg & 2) continue;
 
     // one corner: the whole 128-byte row; register s receives 16-byte slot s ^ rot with rot = sub ^ (pair of the wave): the
     // 8 lanes of a pair start on 8 different slots and so do the 8 lanes with equal `sub` (whose rows are neighbours when
@@ -287,6 +264,36 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
                                      acc[0].z + dpp_x<0xB1>(acc[1].z), acc[0].w + dpp_x<0xB1>(acc[1].w));
       if (live[ps]) st4(out + (ql64 * M + m) * 32 + rot * 4, res);
     } else {
+      // grad_out of the pair, all 32 channels in every lane (8 x 16-byte broadcast loads from L1), rotated as row()
+      float4 gq[8];
+      const float *gp = grad_out + (ql64 * M + m) * 32;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) gq[s] = live[ps] ? ld4(gp + 4 * (s ^ rot)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (far_points) {
+        // far points (rare): their corner contributions w_corner attn_w grad_out[q, m, :] (cuh:125-152), which the row-tile
+        // scatter leaves out, with global atomics
+        float *gv = grad_value + ((long long)b * S * M + m) * 32;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          if (!(far_points & (1 << k2))) continue;
+          const float lx = k2 ? l4.z : l4.x, ly = k2 ? l4.w : l4.y, wt = k2 ? a2.y : a2.x;
+          const Tap<float> tp = make_tap<float>(lx, ly, Hm, Wm);
+          auto corner_add = [&](const int y, const int x, const bool keep, const float w) {
+            if (!keep) return;
+            float *row_p = gv + (long long)(start_m + y * Wm + x) * tok;
+            const float cwt = w * wt;
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+              float *d4 = row_p + 4 * (s2 ^ rot);
+              atomicAdd(d4, cwt * gq[s2].x); atomicAdd(d4 + 1, cwt * gq[s2].y); atomicAdd(d4 + 2, cwt * gq[s2].z); atomicAdd(d4 + 3, cwt * gq[s2].w);
+            }
+          };
+          corner_add(tp.y0, tp.x0, tp.t && tp.l, tp.w1);
+          corner_add(tp.y0, tp.x1, tp.t && tp.r, tp.w2);
+          corner_add(tp.y1, tp.x0, tp.b && tp.l, tp.w3);
+          corner_add(tp.y1, tp.x1, tp.b && tp.r, tp.w4);
+        }
+      }
       float4 ol = make_float4(0.f, 0.f, 0.f, 0.f);
       float2 oa = make_float2(0.f, 0.f);
 #pragma unroll

@@ -15,10 +15,10 @@ namespace msda {
 
 constexpr int kRowTileRows = 256;          // value rows per tile: 512 threads = 256 rows x 2 lanes (16 channels each)
 constexpr int kRowThreads = 512;
-constexpr int kRowBatchQueries = kRowThreads / 4;   // 128 queries x the level's 4 points per batch
+constexpr int kRowBatchQueries = kRowThreads / 2;   // 256 queries x the level's 4 points per batch (two points per thread)
 constexpr int kRowMaxAxisTiles = 96;       // sum over levels of (n_ty + n_tx)
-constexpr int kRowBucketEntries = 4096;    // hit records per batch (32 KB), shared equally by the tile's rows
-constexpr int kRowChunkQueries = 3584;     // candidates per workgroup (28 batches); longer scan lists are split
+constexpr int kRowBucketEntries = 5632;    // hit records per batch (44 KB), shared equally by the tile's rows
+constexpr int kRowChunkQueries = 3584;     // candidates per workgroup (14 batches); longer scan lists are split
 
 struct RowAxis {
   short r0, rn;            // the tile's rows (or columns) of its level

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void row_candidates_kernel(const RowPlan p, Ro
 
 // FUSED: `loc` / `attw` carry raw sampling offsets / attention logits, `ref` the reference points [B, Lq, 4, ref_dim].
 template <bool FUSED>
-__global__ __launch_bounds__(kRowThreads, 6) void scatter_rows_kernel(
+__global__ __launch_bounds__(kRowThreads, 4) void scatter_rows_kernel(
     const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out,
     float *__restrict__ grad_value, const float *__restrict__ ref, int ref_dim, const RowCandidate *__restrict__ table,
     const RowPlan p, int B, int S, int M, int loc_rs, int aw_rs) {
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kRowThreads, 6) void scatter_rows_kernel(
   const RowCandidate *cands = table + p.cand_base[l] + (long long)tile * p.cand_stride[l];
 
   const int tid = threadIdx.x;
-  const int slot = tid >> 2, pt = tid & 3;                 // scan role: candidate slot of the batch, point of level l
+  const int slot0 = tid >> 2, pt = tid & 3;                // scan role: candidate slots slot0, slot0 + 128 of the batch; point
   const int r = tid >> 1, half = tid & 1;                  // gather role: row of the tile, half of its 32 channels
   if (tid < kRowTileRows) count[tid] = 0;
   if (tid == 0) overflow = 0;
@@ -94,9 +94,18 @@ __global__ __launch_bounds__(kRowThreads, 6) void scatter_rows_kernel(
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // one batch of inputs per thread, fetched one batch AHEAD of its use (the scan is otherwise a chain of two dependent
-  // memory round trips per batch: candidate -> point): candidate entries run two batches ahead
-  struct Inputs { float4 g0, g1, lg; float2 xy; float wt; RefScale rs; short cy, cx; };
+  // The scan is a chain of two dependent memory round trips per batch (candidate -> point).  Candidate entries are read two
+  // batches ahead; a batch's points are requested as soon as the previous batch's inputs have been turned into taps, so the
+  // loads are in flight during that batch's bucket / gather phases (lds_barrier keeps them in flight).
+  // Batch k takes candidates k, k + n_batches, k + 2 n_batches, ... of the chunk: a batch then samples the whole scan
+  // region.  Neighbouring queries sample alike (the model's offsets are a per-head pattern), so a batch of NEIGHBOURS
+  // lands on a handful of rows of a coarse level -- hundreds of hits per row against a bucket of a few dozen (many overflow
+  // rounds with most lanes idle: measured 1.95 ms per backward in the train step against 1.45 ms on random offsets).
+  struct Inputs { float4 g0, g1, lg; float2 xy; float wt; RefScale rs; };
+  const int n_batches = (c_end - c_begin + kRowBatchQueries - 1) / kRowBatchQueries;
+  auto cand_index = [&](const int k, const int u) {
+    return k < n_batches ? c_begin + k + (slot0 + u * (kRowBatchQueries / 2)) * n_batches : c_end;
+  };
   auto candidate = [&](const int j) {
     RowCandidate c{0, 0, 0};
     if (j < c_end) c = cands[j];
@@ -104,7 +113,6 @@ __global__ __launch_bounds__(kRowThreads, 6) void scatter_rows_kernel(
   };
   auto fetch = [&](const int j, const RowCandidate c) {
     Inputs in{};
-    in.cy = c.cy; in.cx = c.cx;
     if (j < c_end) {
       const long long q_lin = (long long)b * S + c.token;                          // Lq == S
       const float *gp = grad_out + (q_lin * M + m) * 32 + pt * 8;
@@ -122,62 +130,70 @@ __global__ __launch_bounds__(kRowThreads, 6) void scatter_rows_kernel(
     }
     return in;
   };
-  // Batch k takes candidates k, k + n_batches, k + 2 n_batches, ... of the chunk: a batch then samples the whole scan
-  // region.  Neighbouring queries sample alike (the model's offsets are a per-head pattern), so a batch of NEIGHBOURS
-  // lands on a handful of rows of a coarse level -- hundreds of hits per row against a bucket of ~32 (many overflow
-  // rounds with most lanes idle: measured 1.95 ms per backward in the train step against 1.45 ms on random offsets).
-  const int n_batches = (c_end - c_begin + kRowBatchQueries - 1) / kRowBatchQueries;
-  auto cand_index = [&](const int k) { return k < n_batches ? c_begin + k + slot * n_batches : c_end; };
-  RowCandidate c_next = candidate(cand_index(0));
-  Inputs nxt = fetch(cand_index(0), c_next);
-  c_next = candidate(cand_index(1));
+  RowCandidate cur[2], c_next[2];
+  Inputs in[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    cur[u] = candidate(cand_index(0, u));
+    in[u] = fetch(cand_index(0, u), cur[u]);
+    c_next[u] = candidate(cand_index(1, u));
+  }
   lds_barrier();
 
   for (int k = 0; k < n_batches; ++k) {
-    const bool have = cand_index(k) < c_end;
-    const Inputs in = nxt;
-    nxt = fetch(cand_index(k + 1), c_next);
-    c_next = candidate(cand_index(k + 2));
-    // ---- 1. this thread's point ------------------------------------------------------------------------------------
-    unsigned pend = 0;
-    int rows[4] = {0, 0, 0, 0};
-    float coef[4] = {0.f, 0.f, 0.f, 0.f};
-    float lx = in.xy.x, ly = in.xy.y, wt = in.wt;
-    if (FUSED) {
-      // softmax over the pair's 16 logits (quad reductions over the candidate's 4 threads)
-      float mx = fmaxf(fmaxf(in.lg.x, in.lg.y), fmaxf(in.lg.z, in.lg.w));
-      mx = fmaxf(mx, dpp_x<0xB1>(mx)); mx = fmaxf(mx, dpp_x<0x4E>(mx));
-      float sum = expf(in.lg.x - mx) + expf(in.lg.y - mx) + expf(in.lg.z - mx) + expf(in.lg.w - mx);
-      sum += dpp_x<0xB1>(sum); sum += dpp_x<0x4E>(sum);
-      wt = expf(in.wt - mx) / sum;
-      lx = loc_from_offset<4>(in.rs.rx, lx, in.rs.sx, ref_dim);
-      ly = loc_from_offset<4>(in.rs.ry, ly, in.rs.sy, ref_dim);
-    }
-    if (have) {
-      go_lds[slot * 8 + ((pt * 2) ^ (slot & 7))] = in.g0;          // chunk c of slot s at c ^ (s & 7): the gather's lanes read
-      go_lds[slot * 8 + ((pt * 2 + 1) ^ (slot & 7))] = in.g1;      // the same chunk of different rows -> different banks
-      const Tap<float> tp = make_tap<float>(lx, ly, H, W);
-      if (tp.valid && near_point(tp.h_low, tp.w_low, in.cy, in.cx, p.reach)) {
-        const int ry0 = tp.y0 - y0, ry1 = tp.y1 - y0, rx0 = tp.x0 - x0, rx1 = tp.x1 - x0;
-        const bool iy0 = tp.t && (unsigned)ry0 < (unsigned)th, iy1 = tp.b && (unsigned)ry1 < (unsigned)th;
-        const bool ix0 = tp.l && (unsigned)rx0 < (unsigned)tw, ix1 = tp.r && (unsigned)rx1 < (unsigned)tw;
-        rows[0] = ry0 * tw + rx0; rows[1] = ry0 * tw + rx1; rows[2] = ry1 * tw + rx0; rows[3] = ry1 * tw + rx1;
-        coef[0] = tp.w1 * wt; coef[1] = tp.w2 * wt; coef[2] = tp.w3 * wt; coef[3] = tp.w4 * wt;
-        pend = (iy0 && ix0 ? 1u : 0u) | (iy0 && ix1 ? 2u : 0u) | (iy1 && ix0 ? 4u : 0u) | (iy1 && ix1 ? 8u : 0u);
+    // ---- 1. this thread's two points -------------------------------------------------------------------------------
+    unsigned pend = 0;                                     // bit 4 u + c: corner c of sub-slot u still has to be placed
+    int rows[2][4];
+    float coef[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int slot = slot0 + u * (kRowBatchQueries / 2);
+      float lx = in[u].xy.x, ly = in[u].xy.y, wt = in[u].wt;
+      if (FUSED) {
+        // softmax over the pair's 16 logits (quad reductions over the candidate's 4 threads)
+        const float4 lg = in[u].lg;
+        float mx = fmaxf(fmaxf(lg.x, lg.y), fmaxf(lg.z, lg.w));
+        mx = fmaxf(mx, dpp_x<0xB1>(mx)); mx = fmaxf(mx, dpp_x<0x4E>(mx));
+        float sum = expf(lg.x - mx) + expf(lg.y - mx) + expf(lg.z - mx) + expf(lg.w - mx);
+        sum += dpp_x<0xB1>(sum); sum += dpp_x<0x4E>(sum);
+        wt = expf(wt - mx) / sum;
+        lx = loc_from_offset<4>(in[u].rs.rx, lx, in[u].rs.sx, ref_dim);
+        ly = loc_from_offset<4>(in[u].rs.ry, ly, in[u].rs.sy, ref_dim);
       }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { rows[u][c] = 0; coef[u][c] = 0.f; }
+      if (cand_index(k, u) < c_end) {
+        go_lds[slot * 8 + ((pt * 2) ^ (slot & 7))] = in[u].g0;          // chunk c of slot s at c ^ (s & 7): the gather's lanes
+        go_lds[slot * 8 + ((pt * 2 + 1) ^ (slot & 7))] = in[u].g1;      // read one chunk of different rows -> different banks
+        const Tap<float> tp = make_tap<float>(lx, ly, H, W);
+        if (tp.valid && near_point(tp.h_low, tp.w_low, cur[u].cy, cur[u].cx, p.reach)) {
+          const int ry0 = tp.y0 - y0, ry1 = tp.y1 - y0, rx0 = tp.x0 - x0, rx1 = tp.x1 - x0;
+          const bool iy0 = tp.t && (unsigned)ry0 < (unsigned)th, iy1 = tp.b && (unsigned)ry1 < (unsigned)th;
+          const bool ix0 = tp.l && (unsigned)rx0 < (unsigned)tw, ix1 = tp.r && (unsigned)rx1 < (unsigned)tw;
+          rows[u][0] = ry0 * tw + rx0; rows[u][1] = ry0 * tw + rx1; rows[u][2] = ry1 * tw + rx0; rows[u][3] = ry1 * tw + rx1;
+          coef[u][0] = tp.w1 * wt; coef[u][1] = tp.w2 * wt; coef[u][2] = tp.w3 * wt; coef[u][3] = tp.w4 * wt;
+          pend |= ((iy0 && ix0 ? 1u : 0u) | (iy0 && ix1 ? 2u : 0u) | (iy1 && ix0 ? 4u : 0u) | (iy1 && ix1 ? 8u : 0u)) << (4 * u);
+        }
+      }
+      // the next batch's points: requested now, consumed in the next iteration
+      cur[u] = c_next[u];
+      in[u] = fetch(cand_index(k + 1, u), cur[u]);
+      c_next[u] = candidate(cand_index(k + 2, u));
     }
     // ---- 2./3. buckets and row sums; a row whose bucket overflows (many points on one pixel) takes more rounds -----------
     bool again;
     do {
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (pend & (1u << c)) {
-          const unsigned rank = atomicAdd(&count[rows[c]], 1u);
-          if (rank < (unsigned)cap) {
-            bucket[rows[c] * bstride + rank] = make_uint2(__float_as_uint(coef[c]), (unsigned)slot);
-            pend &= ~(1u << c);
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (pend & (1u << (4 * u + c))) {
+            const unsigned rank = atomicAdd(&count[rows[u][c]], 1u);
+            if (rank < (unsigned)cap) {
+              bucket[rows[u][c] * bstride + rank] = make_uint2(__float_as_uint(coef[u][c]), (unsigned)(slot0 + u * (kRowBatchQueries / 2)));
+              pend &= ~(1u << (4 * u + c));
+            }
           }
-        }
       if (pend) overflow = 1;                // rare
       lds_barrier();
       if (r < n_rows) {
@@ -189,14 +205,14 @@ __global__ __launch_bounds__(kRowThreads, 6) void scatter_rows_kernel(
           const float4 *g4 = go_lds + e.y * 8;
           const int sw = (half * 4) ^ (e.y & 7);     // grad_out rows are stored with their 16-byte chunks XOR-swizzled by the slot
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float4 a = g4[k ^ sw];
-            acc[k].x += w * a.x; acc[k].y += w * a.y; acc[k].z += w * a.z; acc[k].w += w * a.w;
+          for (int kk = 0; kk < 4; ++kk) {
+            const float4 a = g4[kk ^ sw];
+            acc[kk].x += w * a.x; acc[kk].y += w * a.y; acc[kk].z += w * a.z; acc[kk].w += w * a.w;
           }
         }
         if (half == 0) count[r] = 0;         // the row's two lanes sit in one wave: both have read it
       }
-      lds_barrier();                       // orders the gather before the next appends / grad_out rows
+      lds_barrier();                         // orders the gather before the next appends / grad_out rows
       again = overflow != 0;                 // written before the first barrier of the round: the same value for everyone
       if (again) {
         lds_barrier();

@@ -164,7 +164,7 @@ def _criterion_case(g, device, fast, rel_loss, rel_grad):
         got = float(ld[k].detach()) if torch.is_tensor(ld[k]) else float(ld[k])
         assert abs(got - want) <= rel_loss * max(abs(want), 1.0), (k, got, want)
     total = weighted_total(ld, weight_dict)
-    assert abs(float(total) - float(g["total"])) <= rel_loss * abs(float(g["total"]))
+    assert abs(float(total.detach()) - float(g["total"])) <= rel_loss * abs(float(g["total"]))
     total.backward()
     for li, o in enumerate(layers):
         for k, v in o.items():
