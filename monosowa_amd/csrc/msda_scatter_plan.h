@@ -15,9 +15,13 @@ namespace msda {
 
 constexpr int kRowTileRows = 256;          // value rows per tile: 512 threads = 256 rows x 2 lanes (16 channels each)
 constexpr int kRowThreads = 512;
-constexpr int kRowBatchQueries = kRowThreads / 2;   // 256 queries x the level's 4 points per batch (two points per thread)
+#ifndef MSDA_ROW_SUB
+#define MSDA_ROW_SUB 2
+#endif
+constexpr int kRowSub = MSDA_ROW_SUB;                 // candidate points per thread and batch
+constexpr int kRowBatchQueries = kRowThreads / 4 * kRowSub;   // candidates x the level's 4 points per batch
 constexpr int kRowMaxAxisTiles = 96;       // sum over levels of (n_ty + n_tx)
-constexpr int kRowBucketEntries = 5632;    // hit records per batch (44 KB), shared equally by the tile's rows
+constexpr int kRowBucketEntries = kRowSub == 1 ? 4096 : 5632;    // hit records per batch (32 / 44 KB), shared equally by the tile's rows
 constexpr int kRowChunkQueries = 3584;     // candidates per workgroup (14 batches); longer scan lists are split
 
 struct RowAxis {

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void row_candidates_kernel(const RowPlan p, Ro
 
 // FUSED: `loc` / `attw` carry raw sampling offsets / attention logits, `ref` the reference points [B, Lq, 4, ref_dim].
 template <bool FUSED>
-__global__ __launch_bounds__(kRowThreads, 4) void scatter_rows_kernel(
+__global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_rows_kernel(
     const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out,
     float *__restrict__ grad_value, const float *__restrict__ ref, int ref_dim, const RowCandidate *__restrict__ table,
     const RowPlan p, int B, int S, int M, int loc_rs, int aw_rs) {
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kRowThreads, 4) void scatter_rows_kernel(
   struct Inputs { float4 g0, g1, lg; float2 xy; float wt; RefScale rs; };
   const int n_batches = (c_end - c_begin + kRowBatchQueries - 1) / kRowBatchQueries;
   auto cand_index = [&](const int k, const int u) {
-    return k < n_batches ? c_begin + k + (slot0 + u * (kRowBatchQueries / 2)) * n_batches : c_end;
+    return k < n_batches ? c_begin + k + (slot0 + u * (kRowThreads / 4)) * n_batches : c_end;
   };
   auto candidate = [&](const int j) {
     RowCandidate c{0, 0, 0};
@@ -130,10 +130,10 @@ __global__ __launch_bounds__(kRowThreads, 4) void scatter_rows_kernel(
     }
     return in;
   };
-  RowCandidate cur[2], c_next[2];
-  Inputs in[2];
+  RowCandidate cur[kRowSub], c_next[kRowSub];
+  Inputs in[kRowSub];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < kRowSub; ++u) {
     cur[u] = candidate(cand_index(0, u));
     in[u] = fetch(cand_index(0, u), cur[u]);
     c_next[u] = candidate(cand_index(1, u));
@@ -143,11 +143,11 @@ __global__ __launch_bounds__(kRowThreads, 4) void scatter_rows_kernel(
   for (int k = 0; k < n_batches; ++k) {
     // ---- 1. this thread's two points -------------------------------------------------------------------------------
     unsigned pend = 0;                                     // bit 4 u + c: corner c of sub-slot u still has to be placed
-    int rows[2][4];
-    float coef[2][4];
+    int rows[kRowSub][4];
+    float coef[kRowSub][4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int slot = slot0 + u * (kRowBatchQueries / 2);
+    for (int u = 0; u < kRowSub; ++u) {
+      const int slot = slot0 + u * (kRowThreads / 4);
       float lx = in[u].xy.x, ly = in[u].xy.y, wt = in[u].wt;
       if (FUSED) {
         // softmax over the pair's 16 logits (quad reductions over the candidate's 4 threads)
@@ -184,13 +184,13 @@ __global__ __launch_bounds__(kRowThreads, 4) void scatter_rows_kernel(
     bool again;
     do {
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < kRowSub; ++u)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
           if (pend & (1u << (4 * u + c))) {
             const unsigned rank = atomicAdd(&count[rows[u][c]], 1u);
             if (rank < (unsigned)cap) {
-              bucket[rows[u][c] * bstride + rank] = make_uint2(__float_as_uint(coef[u][c]), (unsigned)(slot0 + u * (kRowBatchQueries / 2)));
+              bucket[rows[u][c] * bstride + rank] = make_uint2(__float_as_uint(coef[u][c]), (unsigned)(slot0 + u * (kRowThreads / 4)));
               pend &= ~(1u << (4 * u + c));
             }
           }

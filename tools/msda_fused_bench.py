@@ -1,0 +1,104 @@
+"""Micro-benchmark of the operator the train step runs: the FUSED MSDA entry points on a merged projection
+(msda_fused_forward_strided_f32 / msda_fused_backward_strided_f32; ops/modules/ms_deform_attn.py:145-160 inside the
+kernels), B = 16, 1280x384 pyramid.
+
+    python tools/msda_fused_bench.py [--kinds enc,550] [--iters 50] [--offsets init|uniform] [--out file.json]
+
+encoder shape: Lq = S = 10200, reference points = pixel centres (depthaware_transformer.py:363-376), sampling offsets
+either the module's initial pattern (head m along angle 2 pi m / 8, point p at p + 1 pixels, ms_deform_attn.py:106-114,
+plus N(0, 0.3) px of learned drift) or U(-4, 4) px.  decoder shape: Lq = 550 queries, 6-d reference boxes.
+Prints per-op time and achieved algorithmic GB/s against the 8 TB/s HBM peak (SURVEY.md 8d byte counts).  This is the
+command the PMC traffic of profiles/msda_traffic.json is collected on (tools/collect_pmc.sh)."""
+import argparse
+import json
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from monosowa_amd import MultiScaleDeformableAttention as MSDA  # noqa: E402
+
+LEVELS = [(48, 160), (24, 80), (12, 40), (6, 20)]
+HBM_PEAK = 8.0e12
+
+
+def make(B, kind, offsets, dev, seed=0):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    shapes = torch.tensor(LEVELS, dtype=torch.long, device=dev)
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    MSDA.attach_host_geometry(shapes, lsi, LEVELS, lsi.tolist())
+    S, M, D, L, P = 10200, 8, 32, 4, 4
+    value = torch.randn(B, S, M, D, device=dev, generator=g)
+    if kind == "enc":
+        Lq = S
+        centres = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, device=dev) + 0.5) / h, (torch.arange(w, device=dev) + 0.5) / w,
+                                                        indexing="ij")[::-1], -1).reshape(-1, 2) for h, w in LEVELS])
+        ref = centres[None, :, None, :].expand(B, Lq, L, 2).contiguous()
+    else:
+        Lq = int(kind)
+        ref = torch.cat([torch.rand(B, Lq, 1, 2, device=dev, generator=g).expand(B, Lq, L, 2),
+                         torch.rand(B, Lq, 1, 4, device=dev, generator=g).expand(B, Lq, L, 4) * 0.2], -1).contiguous()
+    if offsets == "init":
+        th = torch.arange(M, dtype=torch.float32, device=dev) * (2.0 * math.pi / M)
+        d = torch.stack([th.cos(), th.sin()], -1)
+        d = d / d.abs().max(-1, keepdim=True)[0]
+        off = d[None, None, :, None, None, :] * torch.arange(1, P + 1, device=dev)[None, None, None, None, :, None]
+        off = off + 0.3 * torch.randn(B, Lq, M, L, P, 2, device=dev, generator=g)
+    else:
+        off = torch.rand(B, Lq, M, L, P, 2, device=dev, generator=g) * 8 - 4
+    logits = torch.randn(B, Lq, M, L * P, device=dev, generator=g)
+    proj = torch.cat([off.reshape(B, Lq, M * 32), logits.reshape(B, Lq, M * 16)], -1).contiguous()
+    go = torch.randn(B, Lq, M * D, device=dev, generator=g)
+    return value, shapes, lsi, proj, ref, go
+
+
+def alg_bytes(B, S, M, D, L, P, Lq, bwd):
+    fwd = 4 * (S * M * D + Lq * M * L * P * 3 + Lq * M * D)
+    if not bwd:
+        return B * fwd
+    return B * 4 * (Lq * M * D + S * M * D + Lq * M * L * P * 3 + S * M * D + Lq * M * L * P * 3)
+
+
+def timeit(fn, warmup, iters):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--kinds", default="enc,550")
+    ap.add_argument("--offsets", choices=["init", "uniform"], default="init")
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    res = {}
+    for kind in a.kinds.split(","):
+        value, shapes, lsi, proj, ref, go = make(a.batch, kind, a.offsets, dev)
+        B, S, M, D = value.shape
+        Lq = proj.shape[1]
+        t_f = timeit(lambda: MSDA.ms_deform_attn_fused_forward_merged(value, shapes, lsi, proj, ref), a.warmup, a.iters)
+        t_b = timeit(lambda: MSDA.ms_deform_attn_fused_backward_merged(value, shapes, lsi, proj, ref, go), a.warmup, a.iters)
+        for name, t, bwd in (("fwd", t_f, False), ("bwd", t_b, True)):
+            nbytes = alg_bytes(B, S, M, D, 4, 4, Lq, bwd)
+            res["msda_%s_Lq%d_B%d" % (name, Lq, B)] = {"ms": t, "alg_bytes": nbytes, "GBps": nbytes / t / 1e6, "frac_of_8TBps": nbytes / (t * 1e-3) / HBM_PEAK}
+            print("fused msda_%s Lq=%-6d B=%d offsets=%s: %.3f ms  %.0f GB/s algorithmic = %.1f %% of HBM peak"
+                  % (name, Lq, B, a.offsets, t, nbytes / t / 1e6, 100 * nbytes / (t * 1e-3) / HBM_PEAK), flush=True)
+    if a.out:
+        json.dump(res, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -24,7 +24,8 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
     for (k, c), v in counters("calib_" + C).items():
         calib[(k, c)] = sum(x[1] for x in v) / len(v)
 known = {"calib_stream_f4": {"FETCH_SIZE": (64 << 20) * 16 + (64 << 20) * 4, "WRITE_SIZE": (64 << 20) * 4},
-         "calib_rowgather": {"FETCH_SIZE": (2 << 20) * 128 + (2 << 20) * 4}}
+         "calib_rowgather": {"FETCH_SIZE": (2 << 20) * 128 + (2 << 20) * 4},
+         "calib_seg32": {"FETCH_SIZE": (2 << 20) * 32 + (2 << 20) * 4}}
 factor = {}
 for k, cs in known.items():
     for c, nbytes in cs.items():
@@ -53,20 +54,31 @@ for (k, grid), cs in sorted(msda.items()):
                                                 "raw_fetch_counter_bytes": cs.get("FETCH_SIZE", 0.0),
                                                 "raw_write_counter_bytes": cs.get("WRITE_SIZE", 0.0)}
     print("%-70s fetch %8.1f MB  write %8.1f MB" % (k + " grid=" + grid, fetch / 1e6, write / 1e6))
-# op-level sums in the keys bench.py looks up: the micro-benchmark runs the encoder shape (larger grids)
-# and the decoder-train shape (smaller grids) at B=16
+# op-level sums in the keys bench.py looks up.  The fused micro-benchmark runs the encoder shape (Lq = S: tile-window gather
+# + row-tile scatter) and the 550-query decoder shape (record gather + tile-owner scatter); a kernel template that serves both
+# shapes is told apart by its grid (the encoder launch is the larger one).
 by_kernel = defaultdict(list)
 for (k, grid), cs in msda.items():
     by_kernel[k].append((int(grid), k, grid))
-ops = {"msda_fwd": ["fwd_d32_kernel", "gather_rec_kernel<false"],
-       "msda_bwd": ["bwd_prep_kernel", "bwd_bounds_kernel", "bwd_scatter_kernel", "bwd_gather_kernel", "gather_rec_kernel<true"]}
-for shape_i, tag in ((-1, "Lq10200_B16"), (0, "Lq550_B16")):
-    for op, names in ops.items():
-        tot = 0.0
+ops = {
+    "msda_fwd_Lq10200_B16": [("gather_win_kernel<false", -1)],
+    "msda_bwd_Lq10200_B16": [("row_candidates_kernel", -1), ("scatter_rows_kernel", -1), ("gather_win_kernel<true", -1)],
+    "msda_fwd_Lq550_B16": [("gather_rec_kernel<false", 0)],
+    "msda_bwd_Lq550_B16": [("bwd_prep_kernel", 0), ("bwd_bounds_kernel", 0), ("bwd_scatter_kernel", 0), ("gather_rec_kernel<true", 0)],
+}
+res["_source"] = {"command": "bash tools/collect_pmc.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on "
+                             "tools/msda_fused_bench.py --kinds enc,550: the fused strided operator of the train step, B = 16)",
+                  "corrections": "FETCH_SIZE x %.3f (128-byte row gathers, tools/ubench/pmc_calib.hip), WRITE_SIZE x %.3f" % (f_gather, f_write),
+                  "kernels": {}}
+for op, parts in ops.items():
+    tot, used = 0.0, []
+    for name, which in parts:
         for k, lst in by_kernel.items():
-            if any(n in k for n in names):
-                _, kk, grid = sorted(lst)[shape_i]
+            if name in k:
+                _, kk, grid = sorted(lst)[which]
                 tot += res["kernels"]["%s grid=%s" % (kk, grid)]["hbm_bytes"]
-        res["%s_%s" % (op, tag)] = tot
-        print("%-28s %8.1f MB per launch (fetch x%.2f + write x%.2f corrected)" % (op + "_" + tag, tot / 1e6, f_gather, f_write))
+                used.append("%s grid=%s" % (kk, grid))
+    res[op] = tot
+    res["_source"]["kernels"][op] = used
+    print("%-28s %8.1f MB per launch (fetch x%.2f + write x%.2f corrected) <- %s" % (op, tot / 1e6, f_gather, f_write, ", ".join(u.split("(")[0] for u in used)))
 json.dump(res, open(os.path.join(d, "msda_traffic.json"), "w"), indent=1)

@@ -4,6 +4,8 @@
 //   calib_stream_f4 : every lane reads consecutive float4 (1 KiB per wave instruction), writes 1/16 of it
 //   calib_rowgather : 8 lanes x float4 fetch one random 128-B row of a 1-KiB-strided table (the MSDA
 //                     corner fetch), each row fetched exactly once
+//   calib_seg32     : 4 lanes x 8 bytes fetch one 32-byte segment of a random 1-KiB token (the row-tile scatter's read of
+//                     one level's four sampling points): which request size does the counter see per segment?
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -41,6 +43,17 @@ __global__ __launch_bounds__(256) void calib_rowgather(const float *table, const
   out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+__global__ __launch_bounds__(256) void calib_seg32(const float *table, const int *rows, float2 *out, int n_rows) {
+  const int sub = threadIdx.x & 3;
+  const int stride = gridDim.x * 64;
+  float2 acc = make_float2(0, 0);
+  for (int r = blockIdx.x * 64 + (threadIdx.x >> 2); r < n_rows; r += stride) {
+    const float2 v = *reinterpret_cast<const float2 *>(table + (size_t)rows[r] * 256 + 40 + sub * 2);   // bytes 160..191 of the token
+    acc.x += v.x; acc.y += v.y;
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 int main() {
   const size_t n_f4 = (size_t)64 << 20;               // 1 GiB stream
   float4 *in, *out;
@@ -59,7 +72,11 @@ int main() {
   (void)hipMemcpy(rows, h.data(), n_rows * 4, hipMemcpyHostToDevice);
   calib_rowgather<<<2048, 256>>>(table, rows, out2, n_rows);
   (void)hipDeviceSynchronize();
+  (void)hipMemset(in, 0, n_f4 * 16);                  // push the table out of the Infinity Cache again
+  calib_seg32<<<2048, 256>>>(table, rows, reinterpret_cast<float2 *>(out2), n_rows);
+  (void)hipDeviceSynchronize();
   printf("calib_stream_f4: read %zu bytes, wrote %zu bytes\n", n_f4 * 16 + n_f4 * 4, n_f4 * 4);
   printf("calib_rowgather: read %zu bytes of rows (+%d index bytes)\n", (size_t)n_rows * 128, n_rows * 4);
+  printf("calib_seg32: read %zu bytes of 32-byte segments (+%d index bytes)\n", (size_t)n_rows * 32, n_rows * 4);
   return 0;
 }
