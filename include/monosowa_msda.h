@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 5
+#define MSDA_ABI_VERSION 6
 
 #define MSDA_E_NULLPTR (-1)   /* a required pointer is NULL                        */
 #define MSDA_E_SHAPE (-2)     /* a dimension is <= 0 or exceeds the indexing range */
@@ -140,6 +140,26 @@ int msda_fused_backward_strided_f32(const float *value, const int64_t *shapes, c
                                     int B, int S, int M, int D, int L, int Lq, int P, int offsets_row_stride,
                                     int logits_row_stride, const int64_t *shapes_host, const int64_t *level_start_host,
                                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* ABI v6 (training): the fused forward stores what it evaluated -- loc_save [B, Lq, M, L, P, 2] sampling locations and
+ * attn_save [B, Lq, M, L, P] softmax weights, both contiguous -- and the backward of the self-attention shape
+ * (Lq == S: msda_gather_win.hip / msda_scatter_rows.hip) reads those instead of re-evaluating the prologue in its two
+ * kernels (the row-tile scatter evaluates every point ~2.3x: measured 0.94 -> 0.66 ms per launch at B = 16).
+ * grad_offsets / grad_logits still refer to the RAW projection outputs (row strides as in v5).
+ * msda_fused_save_supported() -> 1 when msda_fused_backward_saved_f32 covers the geometry (else use the v5 backward). */
+int msda_fused_save_supported(int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
+                              const int64_t *level_start_host);
+int msda_fused_forward_save_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                                const float *offsets, const float *logits, const float *ref, int ref_dim, float *out,
+                                float *loc_save, float *attn_save, int B, int S, int M, int D, int L, int Lq, int P,
+                                int offsets_row_stride, int logits_row_stride, const int64_t *shapes_host,
+                                const int64_t *level_start_host, void *stream);
+int msda_fused_backward_saved_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                                  const float *loc_saved, const float *attn_saved, const float *ref, int ref_dim,
+                                  const float *grad_out, float *grad_value, float *grad_offsets, float *grad_logits,
+                                  int B, int S, int M, int D, int L, int Lq, int P, int offsets_row_stride,
+                                  int logits_row_stride, const int64_t *shapes_host, const int64_t *level_start_host,
+                                  void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -305,3 +305,68 @@ def ms_deform_attn_fused_backward_merged(value, spatial_shapes, level_start_inde
             e1.record(stream)
     _lib.check(code, "ms_deform_attn_fused_backward_merged")
     return grad_value, grad_proj
+
+
+def fused_save_supported(value, spatial_shapes, level_start_index, Lq):
+    """True when the training pair msda_fused_forward_save_f32 / msda_fused_backward_saved_f32 (ABI v6) covers this call:
+    the self-attention shape (Lq == S) on the window / row-tile kernels."""
+    B, S, M, D = value.shape
+    geom = host_geometry(spatial_shapes, level_start_index)
+    return bool(_lib.load().msda_fused_save_supported(S, M, D, 4, Lq, 4, geom[0], geom[1]))
+
+
+def ms_deform_attn_fused_forward_merged_save(value, spatial_shapes, level_start_index, proj, reference_points):
+    """As ``ms_deform_attn_fused_forward_merged``; also returns the sampling locations [B, Lq, M, 4, 4, 2] and attention
+    weights [B, Lq, M, 4, 4] the kernel evaluated, for ``ms_deform_attn_fused_backward_merged_saved``."""
+    B, S, M, D = value.shape
+    Lq = proj.shape[1]
+    L = P = 4
+    _assert(proj.is_contiguous() and proj.shape[2] == M * 48 and proj.dtype == torch.float32, "proj must be [B, Lq, M*48] float32")
+    geom = host_geometry(spatial_shapes, level_start_index)
+    out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    loc = torch.empty((B, Lq, M, L, P, 2), dtype=value.dtype, device=value.device)
+    attw = torch.empty((B, Lq, M, L, P), dtype=value.dtype, device=value.device)
+    timer = LaunchTimer.active
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream()
+        if timer is not None:
+            e0, e1 = timer.bracket("fwd", (B, S, M, D, L, Lq, P))
+            e0.record(stream)
+        code = _lib.load().msda_fused_forward_save_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
+            proj.data_ptr() + M * 32 * 4, reference_points.data_ptr(), reference_points.size(3), out.data_ptr(),
+            loc.data_ptr(), attw.data_ptr(), B, S, M, D, L, Lq, P, M * 48, M * 48, geom[0], geom[1], stream.cuda_stream)
+        if timer is not None:
+            e1.record(stream)
+    _lib.check(code, "ms_deform_attn_fused_forward_merged_save")
+    return out, loc, attw
+
+
+def ms_deform_attn_fused_backward_merged_saved(value, spatial_shapes, level_start_index, loc, attw, reference_points,
+                                               grad_output):
+    """-> grad_value, grad_proj [B, Lq, M*48] (grad offsets | grad logits), from the saved locations / weights."""
+    B, S, M, D = value.shape
+    Lq = loc.shape[1]
+    L = P = 4
+    _assert(grad_output.is_contiguous() and grad_output.numel() == B * Lq * M * D, "grad_output shape mismatch")
+    lib = _lib.load()
+    geom = host_geometry(spatial_shapes, level_start_index)
+    grad_value = torch.empty_like(value)
+    grad_proj = torch.empty((B, Lq, M * 48), dtype=value.dtype, device=value.device)
+    ws_bytes = lib.msda_backward_workspace_bytes(B, S, M, D, L, Lq, P, 4)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
+    timer = LaunchTimer.active
+    with torch.cuda.device(value.device):
+        stream = torch.cuda.current_stream()
+        if timer is not None:
+            e0, e1 = timer.bracket("bwd", (B, S, M, D, L, Lq, P))
+            e0.record(stream)
+        code = lib.msda_fused_backward_saved_f32(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), loc.data_ptr(), attw.data_ptr(),
+            reference_points.data_ptr(), reference_points.size(3), grad_output.data_ptr(), grad_value.data_ptr(),
+            grad_proj.data_ptr(), grad_proj.data_ptr() + M * 32 * 4, B, S, M, D, L, Lq, P, M * 48, M * 48, geom[0], geom[1],
+            ws.data_ptr(), ws_bytes, stream.cuda_stream)
+        if timer is not None:
+            e1.record(stream)
+    _lib.check(code, "ms_deform_attn_fused_backward_merged_saved")
+    return grad_value, grad_proj

@@ -153,7 +153,7 @@ inline bool window_applies(bool bwd, const int64_t *shapes_host, const int64_t *
 
 // Launch of the record-based gather kernels (forward or the backward's grad_loc / grad_attn_w pass), staged when
 // the tail of the pyramid fits LDS and the option allows it.
-template <bool BWD, bool FUSED>
+template <bool BWD, bool FUSED, bool SAVED = false>
 void launch_gather(const float *value, const float *loc, const float *attw, const float *grad_out, float *out,
                    float *grad_loc, float *grad_attw, const float *ref, int ref_dim, const int64_t *shapes_host,
                    const int64_t *lsi_host, int B, int S, int M, int Lq, hipStream_t stream, int loc_rs = 0, int aw_rs = 0,
@@ -167,7 +167,7 @@ void launch_gather(const float *value, const float *loc, const float *attw, cons
       const int bm_groups = (B * M + 7) / 8;
       msda::WinTable wt;
       msda::fill_window_table(wg, wt);
-      msda::gather_win_kernel<BWD, FUSED><<<8 * wg.n_ty * wg.n_tx * bm_groups, msda::kWinThreads, 0, stream>>>(
+      msda::gather_win_kernel<BWD, FUSED, SAVED><<<8 * wg.n_ty * wg.n_tx * bm_groups, msda::kWinThreads, 0, stream>>>(
           value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, wt, B, S, M, loc_rs, aw_rs,
           grad_value, far_reach);
       return;
@@ -281,7 +281,9 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
                   const T *attw, const T *grad_out, T *grad_value, T *grad_loc, T *grad_attw,
                   int B, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
                   const int64_t *lsi_host, void *workspace, size_t workspace_bytes, void *stream_,
-                  const float *fused_ref = nullptr, int fused_ref_dim = 0, int loc_rs = 0, int aw_rs = 0) {
+                  const float *fused_ref = nullptr, int fused_ref_dim = 0, int loc_rs = 0, int aw_rs = 0, bool saved = false) {
+  // saved: `loc` / `attw` are the sampling locations / attention weights the fused forward stored (contiguous); the
+  // gradients still go back to raw offsets / logits through `fused_ref` and the row strides (self-attention shape only)
   if (!value || !shapes || !lsi || !loc || !attw || !grad_out || !grad_value || !grad_loc || !grad_attw)
     return MSDA_E_NULLPTR;
   if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
@@ -320,13 +322,16 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
           }
           const int groups = (B * M + 7) / 8;
           const int lrs = loc_rs ? loc_rs : M * 32, ars = aw_rs ? aw_rs : M * 16;
-          if (fused_ref)
+          if (fused_ref && !saved)
             msda::scatter_rows_kernel<true><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
                 loc, attw, grad_out, grad_value, fused_ref, fused_ref_dim, table, rp, B, S, M, lrs, ars);
           else
             msda::scatter_rows_kernel<false><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
-                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, lrs, ars);
-          if (fused_ref)
+                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, saved ? M * 32 : lrs, saved ? M * 16 : ars);
+          if (fused_ref && saved)
+            launch_gather<true, true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
+                                            shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, rp.reach);
+          else if (fused_ref)
             launch_gather<true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
                                       shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, rp.reach);
           else
@@ -335,6 +340,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
           return (int)hipGetLastError();
         }
       }
+      if (saved) return MSDA_E_UNSUPPORTED;          // msda_fused_save_supported() said otherwise
       const msda::BwdPlan plan = make_plan(shapes_host, lsi_host, L, Lq, P);
       if ((long long)Lq * P >= (1LL << (62 - msda::kFixBits))) return MSDA_E_SHAPE;   // fixed-point headroom
       const TiledWorkspace ws = tiled_workspace(B, M, L, Lq, P);
@@ -507,6 +513,51 @@ int msda_fused_backward_strided_f32(const float *value, const int64_t *shapes, c
   return backward_impl<float>(value, shapes, level_start, offsets, logits, grad_out, grad_value, grad_offsets,
                               grad_logits, B, S, M, D, L, Lq, P, shapes_host, level_start_host, workspace,
                               workspace_bytes, stream, ref, ref_dim, offsets_row_stride, logits_row_stride);
+}
+
+// ---- ABI v6: the fused forward hands the backward the locations / weights it evaluated -------------------------------
+int msda_fused_save_supported(int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
+                              const int64_t *level_start_host) {
+  if (!shapes_host || !level_start_host || !(D == 32 && L == 4 && P == 4) || M * L * 8 > 1024) return 0;
+  if (check_host_geometry(shapes_host, level_start_host, L, S)) return 0;
+  msda::RowPlan rp;
+  return options().scatter_rows && window_applies(true, shapes_host, level_start_host, Lq, S) &&
+         window_applies(false, shapes_host, level_start_host, Lq, S) &&
+         msda::make_row_plan(shapes_host, level_start_host, options().scatter_reach, rp) ? 1 : 0;
+}
+
+int msda_fused_forward_save_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                                const float *offsets, const float *logits, const float *ref, int ref_dim, float *out,
+                                float *loc_save, float *attn_save, int B, int S, int M, int D, int L, int Lq, int P,
+                                int offsets_row_stride, int logits_row_stride, const int64_t *shapes_host,
+                                const int64_t *level_start_host, void *stream) {
+  if (!value || !shapes || !level_start || !offsets || !logits || !ref || !out || !loc_save || !attn_save || !shapes_host ||
+      !level_start_host)
+    return MSDA_E_NULLPTR;
+  if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
+  if (!(D == 32 && L == 4 && P == 4) || (ref_dim != 2 && ref_dim != 6)) return MSDA_E_UNSUPPORTED;
+  if (offsets_row_stride < M * 32 || logits_row_stride < M * 16 || (offsets_row_stride & 3) || (logits_row_stride & 3))
+    return MSDA_E_SHAPE;
+  if (int e = check_host_geometry(shapes_host, level_start_host, L, S)) return e;
+  launch_gather<false, true, true>(value, offsets, logits, nullptr, out, loc_save, attn_save, ref, ref_dim, shapes_host,
+                                   level_start_host, B, S, M, Lq, (hipStream_t)stream, offsets_row_stride, logits_row_stride);
+  return (int)hipGetLastError();
+}
+
+int msda_fused_backward_saved_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
+                                  const float *loc_saved, const float *attn_saved, const float *ref, int ref_dim,
+                                  const float *grad_out, float *grad_value, float *grad_offsets, float *grad_logits,
+                                  int B, int S, int M, int D, int L, int Lq, int P, int offsets_row_stride,
+                                  int logits_row_stride, const int64_t *shapes_host, const int64_t *level_start_host,
+                                  void *workspace, size_t workspace_bytes, void *stream) {
+  if (!ref || !shapes_host || !level_start_host) return MSDA_E_NULLPTR;
+  if (!msda_fused_save_supported(S, M, D, L, Lq, P, shapes_host, level_start_host) || (ref_dim != 2 && ref_dim != 6))
+    return MSDA_E_UNSUPPORTED;
+  if (offsets_row_stride < M * 32 || logits_row_stride < M * 16 || (offsets_row_stride & 3) || (logits_row_stride & 3))
+    return MSDA_E_SHAPE;
+  return backward_impl<float>(value, shapes, level_start, loc_saved, attn_saved, grad_out, grad_value, grad_offsets,
+                              grad_logits, B, S, M, D, L, Lq, P, shapes_host, level_start_host, workspace,
+                              workspace_bytes, stream, ref, ref_dim, offsets_row_stride, logits_row_stride, true);
 }
 
 int msda_backward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,

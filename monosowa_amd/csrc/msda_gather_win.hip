@@ -36,7 +36,10 @@ typedef __attribute__((address_space(1))) const void global_cvoid_t;
 
 // BWD = false: out[pair] = sum of sampled rows.   BWD = true: grad_loc / grad_attn_w of the pair.
 // FUSED: `loc` / `attw` carry raw sampling offsets / attention logits, `ref` the reference points [B, Lq, 4, ref_dim].
-template <bool BWD, bool FUSED>
+// SAVED (with FUSED): forward -- also store the sampling locations / attention weights it evaluated (`grad_loc` / `grad_attw`
+// double as the contiguous save buffers); backward -- `loc` / `attw` ARE those saved tensors (contiguous), only the chain
+// rule back to offsets / logits is evaluated here: no softmax, no reference-point arithmetic in the backward's hot loops.
+template <bool BWD, bool FUSED, bool SAVED = false>
 __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
     const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attw,
     const float *__restrict__ grad_out, float *__restrict__ out, float *__restrict__ grad_loc,
@@ -103,8 +106,8 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
         cf_x[ps] = centre_floor(axq.q0 + dx, g.W[ql], g.W[sub >> 1]);
       }
       const long long ql64 = q_lin[ps];
-      lc[ps] = ld4(loc + ql64 * loc_rs + m * 32 + sub * 4);
-      aw[ps] = *reinterpret_cast<const float2 *>(attw + ql64 * aw_rs + m * 16 + sub * 2);
+      lc[ps] = ld4(loc + ql64 * (BWD && SAVED ? M * 32 : loc_rs) + m * 32 + sub * 4);
+      aw[ps] = *reinterpret_cast<const float2 *>(attw + ql64 * (BWD && SAVED ? M * 16 : aw_rs) + m * 16 + sub * 2);
     }
   }
 
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
     float2 a2 = aw[ps];
     float4 l4 = lc[ps];
     float2 ref_scale = make_float2(1.f, 1.f);                             // FUSED backward: d location / d offset
-    if (FUSED) {
+    if (FUSED && !(BWD && SAVED)) {
       // softmax over the pair's 16 logits (2 per lane), then this lane's two sampling locations (msda_common.h)
       const float mx = group_max(fmaxf(a2.x, a2.y));
       const float e0 = expf(a2.x - mx), e1 = expf(a2.y - mx);
@@ -159,7 +162,15 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
         ref_scale = make_float2(rs.sx, rs.sy);
         l4 = make_float4(loc_from_offset<4>(rs.rx, l4.x, rs.sx, ref_dim), loc_from_offset<4>(rs.ry, l4.y, rs.sy, ref_dim),
                          loc_from_offset<4>(rs.rx, l4.z, rs.sx, ref_dim), loc_from_offset<4>(rs.ry, l4.w, rs.sy, ref_dim));
+        if (!BWD && SAVED) {                                            // hand the backward what was evaluated here
+          st4(grad_loc + (ql64 * M + m) * 32 + sub * 4, l4);
+          *reinterpret_cast<float2 *>(grad_attw + (ql64 * M + m) * 16 + sub * 2) = a2;
+        }
       }
+    }
+    if (FUSED && BWD && SAVED && live[ps]) {
+      const RefScale rs = load_ref(ref + (ql64 * 4 + l_mine) * ref_dim, ref_dim, Hm, Wm);
+      ref_scale = make_float2(rs.sx, rs.sy);
     }
     int off[2][4];
     float cw[2][4];          // forward: corner weights x attn_w.  backward: lh, lw, W attn_w, H attn_w

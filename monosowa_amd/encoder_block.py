@@ -36,12 +36,21 @@ class _AttnBlock(torch.autograd.Function):
             q = src + q
         v = F.linear(src, wv, bv).view(N, S, M, D)
         ctx.merged = MERGED_PROJ and L == 4 and P == 4 and D == 32
+        ctx.saved_prologue = False
         if ctx.merged:
             # one GEMM for both projections of q; the operator reads (offsets | logits) in place through row strides
             w_ol, b_ol = torch.cat([wo, wa]), torch.cat([bo, ba])
             proj = F.linear(q, w_ol, b_ol)                                        # [N, S, M*48]
-            a = MSDA.ms_deform_attn_fused_forward_merged(v, shapes, lsi, proj, ref)
-            off = logit = None
+            from .ms_deform_attn_func import SAVE_PROLOGUE
+            ctx.saved_prologue = SAVE_PROLOGUE and MSDA.fused_save_supported(v, shapes, lsi, S)
+            if ctx.saved_prologue:
+                # keep the sampling locations / attention weights the kernel evaluated instead of the raw projection
+                # (same bytes): the backward's two kernels then skip softmax + location arithmetic (ABI v6)
+                a, off, logit = MSDA.ms_deform_attn_fused_forward_merged_save(v, shapes, lsi, proj, ref)
+                proj = None
+            else:
+                a = MSDA.ms_deform_attn_fused_forward_merged(v, shapes, lsi, proj, ref)
+                off = logit = None
         else:
             off = F.linear(q, wo, bo).view(N, S, M, L, P, 2)
             logit = F.linear(q, wa, ba).view(N, S, M, L * P)
@@ -67,7 +76,10 @@ class _AttnBlock(torch.autograd.Function):
         src2, q2 = src.reshape(-1, C), q.reshape(-1, C)
         n_off = wo.shape[0]
         if ctx.merged:
-            gv, gproj = MSDA.ms_deform_attn_fused_backward_merged(v, shapes, lsi, proj, ref, ga.contiguous())
+            if ctx.saved_prologue:          # `off` / `logit` hold the saved sampling locations / attention weights
+                gv, gproj = MSDA.ms_deform_attn_fused_backward_merged_saved(v, shapes, lsi, off, logit, ref, ga.contiguous())
+            else:
+                gv, gproj = MSDA.ms_deform_attn_fused_backward_merged(v, shapes, lsi, proj, ref, ga.contiguous())
             gp2 = gproj.view(-1, gproj.shape[-1])
             # per-level column sums of d proj serve twice: their total is the bias gradient, times W they are d level_embed
             level_sums = colsum_levels(gproj, ctx.levels) if ctx.levels is not None else None

@@ -11,6 +11,9 @@ from torch.autograd.function import once_differentiable
 from . import MultiScaleDeformableAttention as MSDA
 
 
+SAVE_PROLOGUE = True     # training, Lq == S: the fused forward saves locations / weights for the backward (ABI v6)
+
+
 class MSDeformAttnFunction(Function):
     @staticmethod
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
@@ -64,14 +67,29 @@ class MSDeformAttnFusedMergedFunction(Function):
 
     @staticmethod
     def forward(ctx, value, spatial_shapes, level_start_index, proj, reference_points):
-        output = MSDA.ms_deform_attn_fused_forward_merged(value, spatial_shapes, level_start_index, proj, reference_points)
-        ctx.save_for_backward(value, spatial_shapes, level_start_index, proj, reference_points)
         ctx.host_geom = MSDA.host_geometry(spatial_shapes, level_start_index)
+        needs_grad = value.requires_grad or proj.requires_grad
+        ctx.saved_prologue = SAVE_PROLOGUE and needs_grad and MSDA.fused_save_supported(value, spatial_shapes, level_start_index,
+                                                                                         proj.shape[1])
+        if ctx.saved_prologue:
+            # self-attention shape in training: keep the sampling locations / attention weights the kernel evaluated
+            # (250 MB per encoder layer at B = 16) so that neither backward kernel re-evaluates softmax + location math
+            output, loc, attw = MSDA.ms_deform_attn_fused_forward_merged_save(value, spatial_shapes, level_start_index, proj,
+                                                                              reference_points)
+            ctx.save_for_backward(value, spatial_shapes, level_start_index, loc, attw, reference_points)
+        else:
+            output = MSDA.ms_deform_attn_fused_forward_merged(value, spatial_shapes, level_start_index, proj, reference_points)
+            ctx.save_for_backward(value, spatial_shapes, level_start_index, proj, reference_points)
         return output
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
+        if ctx.saved_prologue:
+            value, shapes, lsi, loc, attw, ref = ctx.saved_tensors
+            MSDA.attach_host_geometry(shapes, lsi, *_unpack_geom(ctx.host_geom))
+            gv, gproj = MSDA.ms_deform_attn_fused_backward_merged_saved(value, shapes, lsi, loc, attw, ref, grad_output.contiguous())
+            return gv, None, None, gproj, None
         value, shapes, lsi, proj, ref = ctx.saved_tensors
         MSDA.attach_host_geometry(shapes, lsi, *_unpack_geom(ctx.host_geom))
         gv, gproj = MSDA.ms_deform_attn_fused_backward_merged(value, shapes, lsi, proj, ref, grad_output.contiguous())

@@ -201,6 +201,35 @@ def test_fused_strided_operator_at_the_kitti_pyramid_vs_c_oracle(B, check, offse
         assert (got_log - g_log[b:b + 1]).abs().max() <= 1e-4 * g_log[b].abs().max(), "grad_logits[%d]" % b
 
 
+def test_saved_prologue_backward_equals_the_recomputing_backward():
+    """ABI v6: msda_fused_forward_save_f32 + msda_fused_backward_saved_f32 (the backward reads the sampling locations /
+    attention weights the forward stored) against the v5 pair that re-evaluates the prologue -- same output bit for bit,
+    gradients to 2e-6 of their max; the saved tensors against the PyTorch-evaluated prologue."""
+    MSDA = _msda()
+    B = 2
+    shapes, lsi, ref, offsets, logits, value, go = _kitti_encoder_inputs(B, 77, 6.5)        # some far / out-of-window points too
+    S, M = value.shape[1], value.shape[2]
+    s, i = _dev(shapes), _dev(lsi)
+    MSDA.attach_host_geometry(s, i, shapes.tolist(), lsi.tolist())
+    proj = torch.cat([_dev(offsets).reshape(B, S, M * 32), _dev(logits).reshape(B, S, M * 16)], -1).contiguous()
+    refp = _dev(np.broadcast_to(ref[None, :, None, :], (B, S, 4, 2)).copy())
+    v, g = _dev(value), _dev(go)
+    assert MSDA.fused_save_supported(v, s, i, S)
+    out_a = MSDA.ms_deform_attn_fused_forward_merged(v, s, i, proj, refp)
+    gv_a, gp_a = MSDA.ms_deform_attn_fused_backward_merged(v, s, i, proj, refp, g)
+    out_b, loc, attw = MSDA.ms_deform_attn_fused_forward_merged_save(v, s, i, proj, refp)
+    gv_b, gp_b = MSDA.ms_deform_attn_fused_backward_merged_saved(v, s, i, loc, attw, refp, g)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+    norm = torch.stack([s[:, 1], s[:, 0]], -1).float()
+    loc_t = refp[:, :, None, :, None, :] + _dev(offsets) / norm[None, None, None, :, None, :]
+    aw_t = torch.softmax(_dev(logits), -1).view(B, S, M, 4, 4)
+    assert (loc - loc_t).abs().max() <= 1e-6 and (attw - aw_t).abs().max() <= 1e-6
+    for name, a, b in (("grad_value", gv_a, gv_b), ("grad_proj", gp_a, gp_b)):
+        assert (a - b).abs().max() <= 2e-6 * a.abs().max(), (name, ((a - b).abs().max() / a.abs().max()).item())
+    assert not MSDA.fused_save_supported(v, s, i, 550)                    # decoder shape: the v5 pair
+
+
 def test_unfused_production_forward_b16_two_samples_vs_c_oracle():
     """ms_deform_attn_forward / _backward with the host pyramid attached at BASELINE configs[1] (B = 16)."""
     MSDA = _msda()
