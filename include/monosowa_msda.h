@@ -141,8 +141,9 @@ int msda_fused_backward_strided_f32(const float *value, const int64_t *shapes, c
                                     int logits_row_stride, const int64_t *shapes_host, const int64_t *level_start_host,
                                     void *workspace, size_t workspace_bytes, void *stream);
 
-/* ABI v6 (training): the fused forward stores what it evaluated -- loc_save [B, Lq, M, L, P, 2] sampling locations and
- * attn_save [B, Lq, M, L, P] softmax weights, both contiguous -- and the backward of the self-attention shape
+/* ABI v6 (training): the fused forward stores what it evaluated -- loc_save [B, M, L, Lq, P, 2] sampling locations and
+ * attn_save [B, M, L, Lq, P] softmax weights, LEVEL-MAJOR (a level's points of neighbouring queries are neighbours in
+ * memory: the scatter's scan reads whole lines) -- and the backward of the self-attention shape
  * (Lq == S: msda_gather_win.hip / msda_scatter_rows.hip) reads those instead of re-evaluating the prologue in its two
  * kernels (the row-tile scatter evaluates every point ~2.3x: measured 0.94 -> 0.66 ms per launch at B = 16).
  * grad_offsets / grad_logits still refer to the RAW projection outputs (row strides as in v5).

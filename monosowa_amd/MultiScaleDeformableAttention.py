@@ -316,16 +316,16 @@ def fused_save_supported(value, spatial_shapes, level_start_index, Lq):
 
 
 def ms_deform_attn_fused_forward_merged_save(value, spatial_shapes, level_start_index, proj, reference_points):
-    """As ``ms_deform_attn_fused_forward_merged``; also returns the sampling locations [B, Lq, M, 4, 4, 2] and attention
-    weights [B, Lq, M, 4, 4] the kernel evaluated, for ``ms_deform_attn_fused_backward_merged_saved``."""
+    """As ``ms_deform_attn_fused_forward_merged``; also returns the sampling locations [B, M, 4, Lq, 4, 2] and attention
+    weights [B, M, 4, Lq, 4] (level-major) the kernel evaluated, for ``ms_deform_attn_fused_backward_merged_saved``."""
     B, S, M, D = value.shape
     Lq = proj.shape[1]
     L = P = 4
     _assert(proj.is_contiguous() and proj.shape[2] == M * 48 and proj.dtype == torch.float32, "proj must be [B, Lq, M*48] float32")
     geom = host_geometry(spatial_shapes, level_start_index)
     out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
-    loc = torch.empty((B, Lq, M, L, P, 2), dtype=value.dtype, device=value.device)
-    attw = torch.empty((B, Lq, M, L, P), dtype=value.dtype, device=value.device)
+    loc = torch.empty((B, M, L, Lq, P, 2), dtype=value.dtype, device=value.device)
+    attw = torch.empty((B, M, L, Lq, P), dtype=value.dtype, device=value.device)
     timer = LaunchTimer.active
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream()
@@ -346,7 +346,7 @@ def ms_deform_attn_fused_backward_merged_saved(value, spatial_shapes, level_star
                                                grad_output):
     """-> grad_value, grad_proj [B, Lq, M*48] (grad offsets | grad logits), from the saved locations / weights."""
     B, S, M, D = value.shape
-    Lq = loc.shape[1]
+    Lq = loc.shape[3]
     L = P = 4
     _assert(grad_output.is_contiguous() and grad_output.numel() == B * Lq * M * D, "grad_output shape mismatch")
     lib = _lib.load()

@@ -325,9 +325,12 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
           if (fused_ref && !saved)
             msda::scatter_rows_kernel<true><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
                 loc, attw, grad_out, grad_value, fused_ref, fused_ref_dim, table, rp, B, S, M, lrs, ars);
+          else if (saved)
+            msda::scatter_rows_kernel<false, true><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
+                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, 0, 0);
           else
             msda::scatter_rows_kernel<false><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
-                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, saved ? M * 32 : lrs, saved ? M * 16 : ars);
+                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, lrs, ars);
           if (fused_ref && saved)
             launch_gather<true, true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
                                             shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, rp.reach);
@@ -538,7 +541,7 @@ int msda_fused_forward_save_f32(const float *value, const int64_t *shapes, const
   if (!(D == 32 && L == 4 && P == 4) || (ref_dim != 2 && ref_dim != 6)) return MSDA_E_UNSUPPORTED;
   if (offsets_row_stride < M * 32 || logits_row_stride < M * 16 || (offsets_row_stride & 3) || (logits_row_stride & 3))
     return MSDA_E_SHAPE;
-  if (int e = check_host_geometry(shapes_host, level_start_host, L, S)) return e;
+  if (!msda_fused_save_supported(S, M, D, L, Lq, P, shapes_host, level_start_host)) return MSDA_E_UNSUPPORTED;
   launch_gather<false, true, true>(value, offsets, logits, nullptr, out, loc_save, attn_save, ref, ref_dim, shapes_host,
                                    level_start_host, B, S, M, Lq, (hipStream_t)stream, offsets_row_stride, logits_row_stride);
   return (int)hipGetLastError();

@@ -125,10 +125,6 @@ void gather_rec_kernel(
       rs = load_ref(ref + (q_lin * 4 + l_mine) * ref_dim, ref_dim, H, W);
       lc = make_float4(loc_from_offset<4>(rs.rx, lc.x, rs.sx, ref_dim), loc_from_offset<4>(rs.ry, lc.y, rs.sy, ref_dim),
                        loc_from_offset<4>(rs.rx, lc.z, rs.sx, ref_dim), loc_from_offset<4>(rs.ry, lc.w, rs.sy, ref_dim));
-      if (!BWD && grad_loc != nullptr) {                // forward with save buffers (msda_fused_forward_save_f32)
-        st4(grad_loc + pair * 32 + sub * 4, lc);
-        *reinterpret_cast<float2 *>(grad_attw + pair * 16 + sub * 2) = aw;
-      }
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {

@@ -106,8 +106,16 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
         cf_x[ps] = centre_floor(axq.q0 + dx, g.W[ql], g.W[sub >> 1]);
       }
       const long long ql64 = q_lin[ps];
-      lc[ps] = ld4(loc + ql64 * (BWD && SAVED ? M * 32 : loc_rs) + m * 32 + sub * 4);
-      aw[ps] = *reinterpret_cast<const float2 *>(attw + ql64 * (BWD && SAVED ? M * 16 : aw_rs) + m * 16 + sub * 2);
+      if (BWD && SAVED) {
+        // the forward's saved tensors are LEVEL-MAJOR, [B, M, L, Lq, P(, 2)]: a level's points of neighbouring queries are
+        // neighbours in memory, which is what the row-tile scatter's scan wants (whole lines instead of 32-byte quarters)
+        const long long pl = (((long long)(b * M + m) * 4 + (sub >> 1)) * S + (q_lin[ps] - b * S)) * 4 + (sub & 1) * 2;
+        lc[ps] = ld4(loc + pl * 2);
+        aw[ps] = *reinterpret_cast<const float2 *>(attw + pl);
+      } else {
+        lc[ps] = ld4(loc + ql64 * loc_rs + m * 32 + sub * 4);
+        aw[ps] = *reinterpret_cast<const float2 *>(attw + ql64 * aw_rs + m * 16 + sub * 2);
+      }
     }
   }
 
@@ -162,9 +170,10 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
         ref_scale = make_float2(rs.sx, rs.sy);
         l4 = make_float4(loc_from_offset<4>(rs.rx, l4.x, rs.sx, ref_dim), loc_from_offset<4>(rs.ry, l4.y, rs.sy, ref_dim),
                          loc_from_offset<4>(rs.rx, l4.z, rs.sx, ref_dim), loc_from_offset<4>(rs.ry, l4.w, rs.sy, ref_dim));
-        if (!BWD && SAVED) {                                            // hand the backward what was evaluated here
-          st4(grad_loc + (ql64 * M + m) * 32 + sub * 4, l4);
-          *reinterpret_cast<float2 *>(grad_attw + (ql64 * M + m) * 16 + sub * 2) = a2;
+        if (!BWD && SAVED) {                                            // hand the backward what was evaluated here (level-major)
+          const long long pl = (((long long)(b * M + m) * 4 + l_mine) * S + (q_lin[ps] - b * S)) * 4 + (sub & 1) * 2;
+          st4(grad_loc + pl * 2, l4);
+          *reinterpret_cast<float2 *>(grad_attw + pl) = a2;
         }
       }
     }

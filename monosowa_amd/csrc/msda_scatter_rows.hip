@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void row_candidates_kernel(const RowPlan p, Ro
 }
 
 // FUSED: `loc` / `attw` carry raw sampling offsets / attention logits, `ref` the reference points [B, Lq, 4, ref_dim].
-template <bool FUSED>
+// LEVEL_MAJOR (not FUSED): `loc` / `attw` are the fused forward's saved tensors, [B, M, L, Lq, P(, 2)].
+template <bool FUSED, bool LEVEL_MAJOR = false>
 __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_rows_kernel(
     const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out,
     float *__restrict__ grad_value, const float *__restrict__ ref, int ref_dim, const RowCandidate *__restrict__ table,
@@ -118,14 +119,16 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
       const float *gp = grad_out + (q_lin * M + m) * 32 + pt * 8;
       in.g0 = ld4(gp);
       in.g1 = ld4(gp + 4);
-      in.xy = *reinterpret_cast<const float2 *>(loc + q_lin * loc_rs + ((m * 4 + l) * 4 + pt) * 2);
+      const long long pl = (((long long)(b * M + m) * 4 + l) * S + c.token) * 4 + pt;          // level-major point index
+      in.xy = LEVEL_MAJOR ? *reinterpret_cast<const float2 *>(loc + pl * 2)
+                          : *reinterpret_cast<const float2 *>(loc + q_lin * loc_rs + ((m * 4 + l) * 4 + pt) * 2);
       if (FUSED) {
         const float *lg = attw + q_lin * aw_rs + m * 16;
         in.lg = ld4(lg + pt * 4);                  // the candidate's 4 threads take one level's four logits each
         in.wt = lg[l * 4 + pt];                    // own logit
         in.rs = load_ref(ref + (q_lin * 4 + l) * ref_dim, ref_dim, H, W);
       } else {
-        in.wt = attw[q_lin * aw_rs + (m * 4 + l) * 4 + pt];
+        in.wt = LEVEL_MAJOR ? attw[pl] : attw[q_lin * aw_rs + (m * 4 + l) * 4 + pt];
       }
     }
     return in;

@@ -224,7 +224,8 @@ def test_saved_prologue_backward_equals_the_recomputing_backward():
     norm = torch.stack([s[:, 1], s[:, 0]], -1).float()
     loc_t = refp[:, :, None, :, None, :] + _dev(offsets) / norm[None, None, None, :, None, :]
     aw_t = torch.softmax(_dev(logits), -1).view(B, S, M, 4, 4)
-    assert (loc - loc_t).abs().max() <= 1e-6 and (attw - aw_t).abs().max() <= 1e-6
+    # saved layout: level-major [B, M, L, Lq, P(, 2)]
+    assert (loc.permute(0, 3, 1, 2, 4, 5) - loc_t).abs().max() <= 1e-6 and (attw.permute(0, 3, 1, 2, 4) - aw_t).abs().max() <= 1e-6
     for name, a, b in (("grad_value", gv_a, gv_b), ("grad_proj", gp_a, gp_b)):
         assert (a - b).abs().max() <= 2e-6 * a.abs().max(), (name, ((a - b).abs().max() / a.abs().max()).item())
     assert not MSDA.fused_save_supported(v, s, i, 550)                    # decoder shape: the v5 pair
