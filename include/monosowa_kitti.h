@@ -1,4 +1,5 @@
-/* monosowa_kitti.h -- C ABI of the rotated-box overlap kernels of the KITTI evaluation.
+/* monosowa_kitti.h -- C ABI of the inference / evaluation side: the rotated-box overlap kernels of the KITTI evaluation
+ *  and the detection extraction of the inference loop (row f3).
  *
  * Replaces lib/datasets/kitti/kitti_eval_python/rotate_iou.py:263-330 (`rotate_iou_gpu_eval`, a numba-CUDA kernel) and
  * the CPU loop of eval.py:197-230 (`d3_box_overlap`).  Device pointers, asynchronous on `stream`.
@@ -18,6 +19,13 @@ int mono_rotate_iou_f32(const float *boxes, const float *query, float *out, long
 /* Camera-frame 3D boxes [*, 7] = (x, y, z, d3, d4, d5, ry): BEV rectangle (x, z, d3, d5, ry), bottom at y, height d4;
  * out [N, K] = 3D overlap (criterion 0: / volume of the box, 1: / volume of the query box, as eval.py:210-221). */
 int mono_box3d_overlap_f32(const float *boxes, const float *query, float *out, long long N, long long K, int criterion, void *stream);
+
+/* Inference post-process: lib/helpers/decode_helper.py:58-111 `extract_dets_from_outputs` as one kernel.
+ * logits [B, Q, C], boxes [B, Q, 6] (cx, cy, l, r, t, b), angle [B, Q, 24], size3d [B, Q, 3], depth [B, Q, 2] ->
+ * out [B, K, 37] = [cls, score, x2d, y2d, w2d, h2d, depth, heading(24), size3d(3), x3d, y3d, sigma], the K best
+ * sigmoid(logit) scores of each image in descending order (exact ties: smaller flat index first).  Q * C <= 8192. */
+int mono_extract_dets_f32(const float *logits, const float *boxes, const float *angle, const float *size3d, const float *depth,
+                          float *out, int B, int Q, int C, int K, void *stream);
 
 #ifdef __cplusplus
 }

@@ -138,7 +138,77 @@ __global__ __launch_bounds__(64) void overlap_kernel(const float *__restrict__ b
 
 }  // namespace kitti
 
+// ---- detections from network outputs: lib/helpers/decode_helper.py:58-111 (extract_dets_from_outputs) as ONE kernel ----
+// prob = sigmoid(logits); top-K over the Q * C scores of an image; query = index / C, class = index % C; gather of the
+// query's box / heading / depth / size; cxcylrtb -> xyxy -> cxcywh; sigma = exp(-log variance).  One workgroup per image.
+// The rank of a score is counted directly (N = Q * C is 150 in inference): rank = #(larger scores) + #(equal scores with a
+// smaller index) -- the order torch.topk produces on distinct scores, and a fixed, documented order on exact ties (where
+// torch's is unspecified).  Row layout (37 floats): [cls, score, x2d, y2d, w2d, h2d, depth, heading(24), size3d(3), x3d,
+// y3d, sigma].  Every arithmetic step is the reference's own expression, individually rounded (no fused multiply-add).
+namespace dets {
+
+constexpr int kThreads = 1024;
+constexpr int kMaxScores = 8192;        // Q * C the kernel accepts (32 KB of LDS)
+
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
+__global__ __launch_bounds__(kThreads) void extract_dets_kernel(
+    const float *__restrict__ logits, const float *__restrict__ boxes, const float *__restrict__ angle,
+    const float *__restrict__ size3d, const float *__restrict__ depth, float *__restrict__ out, int Q, int C, int K) {
+  __shared__ float score[kMaxScores];
+  const int b = blockIdx.x, N = Q * C;
+  const float *lg = logits + (long long)b * N;
+  for (int i = threadIdx.x; i < N; i += kThreads) score[i] = 1.0f / (1.0f + expf(-lg[i]));      // at::sigmoid
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += kThreads) {
+    const float s = score[i];
+    int rank = 0;
+    for (int j = 0; j < N; ++j) {
+      const float t = score[j];
+      rank += (t > s) || (t == s && j < i);
+    }
+    if (rank >= K) continue;
+    const int q = i / C, cls = i - q * C;
+    const float *bx = boxes + ((long long)b * Q + q) * 6;
+    const float cx = bx[0], cy = bx[1];
+    const float x0 = sub_rn(cx, bx[2]), y0 = sub_rn(cy, bx[4]), x1 = add_rn(cx, bx[3]), y1 = add_rn(cy, bx[5]);   // box_cxcylrtb_to_xyxy
+    float *o = out + ((long long)b * K + rank) * 37;
+    o[0] = (float)cls;
+    o[1] = s;
+    o[2] = add_rn(x0, x1) / 2;                                                                                   // box_xyxy_to_cxcywh
+    o[3] = add_rn(y0, y1) / 2;
+    o[4] = sub_rn(x1, x0);
+    o[5] = sub_rn(y1, y0);
+    const float *dp = depth + ((long long)b * Q + q) * 2;
+    o[6] = dp[0];
+    const float *an = angle + ((long long)b * Q + q) * 24;
+    for (int k = 0; k < 24; ++k) o[7 + k] = an[k];
+    const float *sz = size3d + ((long long)b * Q + q) * 3;
+    o[31] = sz[0]; o[32] = sz[1]; o[33] = sz[2];
+    o[34] = cx;
+    o[35] = cy;
+    o[36] = expf(-dp[1]);
+  }
+}
+
+}  // namespace dets
+
 extern "C" {
+
+int mono_extract_dets_f32(const float *logits, const float *boxes, const float *angle, const float *size3d, const float *depth,
+                          float *out, int B, int Q, int C, int K, void *stream_) {
+  if (!logits || !boxes || !angle || !size3d || !depth || !out) return -1;
+  if (B <= 0 || Q <= 0 || C <= 0 || K <= 0 || K > Q * C || (long long)Q * C > dets::kMaxScores) return -2;
+  dets::extract_dets_kernel<<<B, dets::kThreads, 0, (hipStream_t)stream_>>>(logits, boxes, angle, size3d, depth, out, Q, C, K);
+  return (int)hipGetLastError();
+}
 
 int mono_rotate_iou_f32(const float *boxes, const float *query, float *out, long long N, long long K, int criterion, void *stream_) {
   if (!boxes || !query || !out) return -1;

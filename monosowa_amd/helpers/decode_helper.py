@@ -52,8 +52,15 @@ class PinholeCalib:
         return ry
 
 
+DEVICE_KERNEL = True      # float32 CUDA outputs: one HIP launch (csrc/rotate_iou.hip, dets::extract_dets_kernel)
+
+
 def extract_dets_from_outputs(outputs, K=50, topk=50):
     out_logits, out_bbox = outputs["pred_logits"], outputs["pred_boxes"]
+    if DEVICE_KERNEL and out_logits.is_cuda and out_logits.dtype == torch.float32 and out_logits.shape[1] * out_logits.shape[2] <= 8192 \
+            and all(outputs[k].dtype == torch.float32 for k in ("pred_boxes", "pred_angle", "pred_3d_dim", "pred_depth")):
+        from ..kitti_eval import extract_dets_device
+        return extract_dets_device(outputs, topk)
     batch, _, num_cls = out_logits.shape
     prob = out_logits.sigmoid()
     scores, topk_indexes = torch.topk(prob.view(batch, -1), topk, dim=1)

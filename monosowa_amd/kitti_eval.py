@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_kitti.so")
-SYMBOLS = ("mono_rotate_iou_f32", "mono_box3d_overlap_f32")
+SYMBOLS = ("mono_rotate_iou_f32", "mono_box3d_overlap_f32", "mono_extract_dets_f32")
 _lib = None
 
 
@@ -23,10 +23,12 @@ def load():
             raise RuntimeError("HIP extension %s is missing: run `python -m monosowa_amd.build`" % _PATH)
         lib = ctypes.CDLL(_PATH)
         P, I, LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
-        for name in SYMBOLS:
+        for name in SYMBOLS[:2]:
             fn = getattr(lib, name)
             fn.restype = I
             fn.argtypes = [P, P, P, LL, LL, I, P]
+        lib.mono_extract_dets_f32.restype = I
+        lib.mono_extract_dets_f32.argtypes = [P] * 6 + [I] * 4 + [P]
         _lib = lib
     return _lib
 
@@ -62,3 +64,18 @@ def bev_box_overlap(boxes, qboxes, criterion=-1):
 def d3_box_overlap(boxes, qboxes, criterion=-1, device_id=0):
     """Camera-frame 3D boxes [*,7] -> 3D overlap [N,K] (BEV intersection x height overlap, one kernel)."""
     return _overlap("mono_box3d_overlap_f32", boxes, qboxes, 7, criterion, device_id)
+
+
+def extract_dets_device(outputs, topk=50):
+    """decode_helper.py:58-111 in one launch: outputs dict of float32 CUDA tensors -> detections [B, topk, 37]."""
+    logits = outputs["pred_logits"].contiguous()
+    B, Q, C = logits.shape
+    t = lambda k: outputs[k].contiguous()
+    out = torch.empty((B, topk, 37), dtype=torch.float32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        code = load().mono_extract_dets_f32(logits.data_ptr(), t("pred_boxes").data_ptr(), t("pred_angle").data_ptr(),
+                                            t("pred_3d_dim").data_ptr(), t("pred_depth").data_ptr(), out.data_ptr(), B, Q, C,
+                                            int(topk), torch.cuda.current_stream().cuda_stream)
+    if code:
+        raise RuntimeError("mono_extract_dets_f32 failed with code %d" % code)
+    return out

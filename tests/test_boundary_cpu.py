@@ -98,3 +98,15 @@ def test_attention_library_exports_declared_symbols():
         flash_attn.attention(q, q, q)
     mha = torch.nn.MultiheadAttention(64, 2)
     assert not flash_attn.mha_supported(mha, torch.randn(5, 1, 64), torch.randn(5, 1, 64), torch.randn(5, 1, 64))
+
+
+def test_kitti_library_exports_declared_symbols():
+    from monosowa_amd import kitti_eval
+    text = open(os.path.join(ROOT, "include", "monosowa_kitti.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(mono_[a-z0-9_]+)\s*\(", text)))
+    assert names == sorted(kitti_eval.SYMBOLS)
+    lib = ctypes.CDLL(kitti_eval._PATH)
+    for n in names:
+        assert hasattr(lib, n)
+    assert lib.mono_extract_dets_f32(None, None, None, None, None, None, 1, 1, 1, 1, None) == -1

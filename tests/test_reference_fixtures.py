@@ -128,8 +128,34 @@ def test_decode_equals_reference_functions(golden_dir):
 
 
 @pytest.mark.gpu
-def test_decode_equals_reference_functions_gpu(golden_dir):
+@pytest.mark.parametrize("device_kernel", [True, False])
+def test_decode_equals_reference_functions_gpu(golden_dir, device_kernel, monkeypatch):
+    """device_kernel=True: mono_extract_dets_f32 (one launch); False: the torch formulation on the GPU."""
+    from monosowa_amd.helpers import decode_helper
+    monkeypatch.setattr(decode_helper, "DEVICE_KERNEL", device_kernel)
     _decode_case(_npz(golden_dir, "decode"), "cuda")
+
+
+@pytest.mark.gpu
+def test_extract_dets_kernel_on_training_sized_outputs():
+    """Q * C = 1650 scores per image (550 queries), K = 50: ranks by counting against torch.topk, rows against the torch
+    formulation (no exact ties in random data)."""
+    from monosowa_amd.helpers import decode_helper
+    g = torch.Generator().manual_seed(5)
+    B, Q = 4, 550
+    outputs = {"pred_logits": torch.randn(B, Q, 3, generator=g), "pred_boxes": torch.rand(B, Q, 6, generator=g),
+               "pred_angle": torch.randn(B, Q, 24, generator=g), "pred_3d_dim": torch.randn(B, Q, 3, generator=g),
+               "pred_depth": torch.randn(B, Q, 2, generator=g)}
+    dev = {k: v.cuda() for k, v in outputs.items()}
+    decode_helper.DEVICE_KERNEL = False
+    try:
+        want = decode_helper.extract_dets_from_outputs(dev)
+    finally:
+        decode_helper.DEVICE_KERNEL = True
+    got = decode_helper.extract_dets_from_outputs(dev)
+    gathered = [0, 6] + list(range(7, 36))
+    assert torch.equal(got[:, :, gathered], want[:, :, gathered])
+    assert torch.allclose(got, want, rtol=2e-6, atol=1e-7)
 
 
 # ------------------------------------------------------------------------------------------------ criterion
