@@ -106,6 +106,20 @@ int mono_groupnorm_nhwc_bwd_f32(const float *gy, const float *x, const float *pr
                                 const float *mean_rstd, const float *gamma, float *gx, double *part, float *gbias,
                                 float *gbias_partials, int B, int HW, int C, int G, int relu, void *stream);
 
+/* DDN depth-map loss (depth_predictor/ddn_loss/ddn_loss.py:12-127 + balancer.py + focalloss.py) in one kernel per
+ * direction.  logits [B, C = num_bins + 1, H, W] addressed with (batch, channel, pixel) strides in floats (NCHW or
+ * channels-last in place); boxes [B, N, 4] xyxy in depth-map pixels, depth [B, N], valid [B, N] (bytes).
+ * forward: partial[mono_ddn_loss_blocks(B, H, W)] block sums of weight * pixel loss; loss = sum(partial) / (B H W).
+ * backward: grad_logits (same strides) = grad_total[0] * d loss / d logits. */
+int mono_ddn_loss_blocks(int B, int H, int W);
+int mono_ddn_loss_fwd_f32(const float *logits, const float *boxes, const float *depth, const unsigned char *valid, float *partial,
+                          int B, int C, int H, int W, int N, long long sb, long long sc, long long sp, float alpha, float gamma,
+                          float fg_weight, float bg_weight, float depth_min, float depth_max, void *stream);
+int mono_ddn_loss_bwd_f32(const float *logits, const float *boxes, const float *depth, const unsigned char *valid,
+                          const float *grad_total, float *grad_logits, int B, int C, int H, int W, int N, long long sb, long long sc,
+                          long long sp, float alpha, float gamma, float fg_weight, float bg_weight, float depth_min, float depth_max,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

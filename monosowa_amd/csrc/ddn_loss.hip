@@ -1,0 +1,112 @@
+// Depth-map supervision of MonoDETR (DDNLoss: depth_predictor/ddn_loss/ddn_loss.py:12-127, balancer.py:7-81,
+// focalloss.py:55-136) as one forward and one backward kernel, one thread per depth-map pixel:
+//   target depth  = centre depth of the NEAREST ground-truth box covering the pixel (the reference paints boxes far to
+//                   near, ddn_loss.py:56-62; box = floor(top-left) .. ceil(bottom-right), :48-50), 0 without a box;
+//   target bin    = LID index floor(-0.5 + 0.5 sqrt(1 + 8 (d - d_min) / bin_size)), out of range / not finite -> num_bins
+//                   (:85-100);
+//   pixel loss    = sum_c (one_hot_c + eps) * (-alpha (1 - p_c)^gamma log p_c), p = softmax over the 81 bin logits;
+//   weighting     = fg_weight on pixels inside some box, bg_weight elsewhere; total = sum / number of pixels.
+// PyTorch needs ~35 launches over [B, 81, H, W] for this; here the logits are read once per direction.
+// Logits are addressed with (batch, channel, pixel) strides, so NCHW and channels-last maps are used in place.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace mono {
+
+struct DdnParams {
+  int B, C, H, W, N;                 // C = num_bins + 1 logits per pixel, N = padded boxes per image
+  long long sb, sc, sp;              // strides of the logits (floats): batch, channel, pixel (row-major h * W + w)
+  float alpha, gamma, fg_weight, bg_weight, depth_min, depth_max, eps;
+};
+
+// target bin and weight of pixel (b, y, x): boxes [B, N, 4] = xyxy in depth-map pixels (float), depth [B, N], valid [B, N]
+__device__ __forceinline__ void ddn_target(const DdnParams &p, const float *__restrict__ boxes, const float *__restrict__ depth,
+                                           const unsigned char *__restrict__ valid, int b, int y, int x, int &bin, float &weight) {
+  float nearest = INFINITY;
+  bool fg = false;
+  for (int i = 0; i < p.N; ++i) {
+    if (!valid[b * p.N + i]) continue;
+    const float *bx = boxes + ((long long)b * p.N + i) * 4;
+    // Python slicing [v1:v2, u1:u2] of the integer box: a negative start counts from the end, then clamp into [0, n]
+    long long u1 = (long long)floorf(bx[0]), v1 = (long long)floorf(bx[1]), u2 = (long long)ceilf(bx[2]), v2 = (long long)ceilf(bx[3]);
+    auto norm = [](long long a, int n) { a = a < 0 ? a + n : a; return a < 0 ? 0LL : (a > n ? (long long)n : a); };
+    u1 = norm(u1, p.W); u2 = norm(u2, p.W); v1 = norm(v1, p.H); v2 = norm(v2, p.H);
+    if (y >= v1 && y < v2 && x >= u1 && x < u2) {
+      fg = true;
+      nearest = fminf(nearest, depth[b * p.N + i]);
+    }
+  }
+  const float d = fg ? nearest : 0.f;
+  const int num_bins = p.C - 1;
+  const float bin_size = 2.f * (p.depth_max - p.depth_min) / (float)(num_bins * (1 + num_bins));
+  const float idx = -0.5f + 0.5f * sqrtf(1.f + 8.f * (d - p.depth_min) / bin_size);
+  const bool bad = (idx < 0.f) || (idx > (float)num_bins) || !isfinite(idx);
+  bin = bad ? num_bins : (int)idx;
+  weight = fg ? p.fg_weight : p.bg_weight;
+}
+
+// partial[block] = sum over the block's pixels of weight * pixel loss   (the host sums the partials and divides)
+__global__ __launch_bounds__(256) void ddn_loss_fwd_kernel(const float *__restrict__ logits, const float *__restrict__ boxes,
+                                                           const float *__restrict__ depth, const unsigned char *__restrict__ valid,
+                                                           float *__restrict__ partial, const DdnParams p) {
+  __shared__ float red[4];
+  const int pix = blockIdx.x * 256 + threadIdx.x, n_pix = p.B * p.H * p.W;
+  float loss = 0.f;
+  if (pix < n_pix) {
+    const int b = pix / (p.H * p.W), hw = pix - b * p.H * p.W, y = hw / p.W, x = hw - y * p.W;
+    int bin; float weight;
+    ddn_target(p, boxes, depth, valid, b, y, x, bin, weight);
+    const float *z = logits + b * p.sb + hw * p.sp;
+    float mx = -INFINITY;
+    for (int c = 0; c < p.C; ++c) mx = fmaxf(mx, z[c * p.sc]);
+    float sum = 0.f;
+    for (int c = 0; c < p.C; ++c) sum += expf(z[c * p.sc] - mx);
+    const float lse = mx + logf(sum);
+    for (int c = 0; c < p.C; ++c) {
+      const float ls = z[c * p.sc] - lse, pc = expf(ls);
+      const float focal = -p.alpha * powf(1.f - pc, p.gamma) * ls;
+      loss += ((c == bin ? 1.f : 0.f) + p.eps) * focal;
+    }
+    loss *= weight;
+  }
+  for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = loss;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// grad_logits = g_scale * weight * d(pixel loss) / d logits, g_scale = grad of the total / number of pixels (device scalar)
+__global__ __launch_bounds__(256) void ddn_loss_bwd_kernel(const float *__restrict__ logits, const float *__restrict__ boxes,
+                                                           const float *__restrict__ depth, const unsigned char *__restrict__ valid,
+                                                           const float *__restrict__ grad_total, float *__restrict__ grad_logits,
+                                                           const DdnParams p) {
+  const int pix = blockIdx.x * 256 + threadIdx.x, n_pix = p.B * p.H * p.W;
+  if (pix >= n_pix) return;
+  const int b = pix / (p.H * p.W), hw = pix - b * p.H * p.W, y = hw / p.W, x = hw - y * p.W;
+  int bin; float weight;
+  ddn_target(p, boxes, depth, valid, b, y, x, bin, weight);
+  const float *z = logits + b * p.sb + hw * p.sp;
+  float *gz = grad_logits + b * p.sb + hw * p.sp;
+  float mx = -INFINITY;
+  for (int c = 0; c < p.C; ++c) mx = fmaxf(mx, z[c * p.sc]);
+  float sum = 0.f;
+  for (int c = 0; c < p.C; ++c) sum += expf(z[c * p.sc] - mx);
+  const float lse = mx + logf(sum);
+  // L = sum_c a_c f(p_c), f = -alpha (1 - p)^gamma log p;  dL/dz_k = t_k - p_k sum_c t_c  with  t_c = a_c f'(p_c) p_c
+  float T = 0.f;
+  for (int c = 0; c < p.C; ++c) {
+    const float ls = z[c * p.sc] - lse, pc = expf(ls), om = 1.f - pc;
+    const float dfdp = -p.alpha * (-p.gamma * powf(om, p.gamma - 1.f) * ls + powf(om, p.gamma) / pc);
+    T += ((c == bin ? 1.f : 0.f) + p.eps) * dfdp * pc;
+  }
+  const float scale = grad_total[0] * weight / (float)n_pix;
+  for (int c = 0; c < p.C; ++c) {
+    const float ls = z[c * p.sc] - lse, pc = expf(ls), om = 1.f - pc;
+    const float dfdp = -p.alpha * (-p.gamma * powf(om, p.gamma - 1.f) * ls + powf(om, p.gamma) / pc);
+    const float t = ((c == bin ? 1.f : 0.f) + p.eps) * dfdp * pc;
+    gz[c * p.sc] = scale * (t - pc * T);
+  }
+}
+
+}  // namespace mono

@@ -7,6 +7,7 @@
 
 #include "groupnorm.hip"
 #include "matched_losses.hip"
+#include "ddn_loss.hip"
 #include <stdint.h>
 
 namespace mono {
@@ -596,6 +597,42 @@ int mono_groupnorm_nhwc_bwd_f32(const float *gy, const float *x, const float *pr
     mono::gn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(gy, x, pre_bias, y, mean_rstd, gamma, part, gx, gp, HW);
   }
   if (pre_bias) mono::partial_sum_kernel<<<1, 1024, 0, st>>>(gbias_partials, gbias, (int)(grid.x * grid.y), mono::kGnC);
+  return (int)hipGetLastError();
+}
+
+
+// ---- DDN depth-map loss (ddn_loss.hip) ---------------------------------------------------------------------------------
+int mono_ddn_loss_blocks(int B, int H, int W) { return (B * H * W + 255) / 256; }
+
+static mono::DdnParams ddn_params(int B, int C, int H, int W, int N, long long sb, long long sc, long long sp, float alpha,
+                                  float gamma, float fg_weight, float bg_weight, float depth_min, float depth_max) {
+  mono::DdnParams p;
+  p.B = B; p.C = C; p.H = H; p.W = W; p.N = N;
+  p.sb = sb; p.sc = sc; p.sp = sp;
+  p.alpha = alpha; p.gamma = gamma; p.fg_weight = fg_weight; p.bg_weight = bg_weight;
+  p.depth_min = depth_min; p.depth_max = depth_max; p.eps = 1e-6f;
+  return p;
+}
+
+int mono_ddn_loss_fwd_f32(const float *logits, const float *boxes, const float *depth, const unsigned char *valid, float *partial,
+                          int B, int C, int H, int W, int N, long long sb, long long sc, long long sp, float alpha, float gamma,
+                          float fg_weight, float bg_weight, float depth_min, float depth_max, void *stream) {
+  if (!logits || !boxes || !depth || !valid || !partial) return -1;
+  if (B <= 0 || C <= 1 || H <= 0 || W <= 0 || N <= 0) return -2;
+  const mono::DdnParams p = ddn_params(B, C, H, W, N, sb, sc, sp, alpha, gamma, fg_weight, bg_weight, depth_min, depth_max);
+  mono::ddn_loss_fwd_kernel<<<mono_ddn_loss_blocks(B, H, W), 256, 0, (hipStream_t)stream>>>(logits, boxes, depth, valid, partial, p);
+  return (int)hipGetLastError();
+}
+
+int mono_ddn_loss_bwd_f32(const float *logits, const float *boxes, const float *depth, const unsigned char *valid,
+                          const float *grad_total, float *grad_logits, int B, int C, int H, int W, int N, long long sb, long long sc,
+                          long long sp, float alpha, float gamma, float fg_weight, float bg_weight, float depth_min, float depth_max,
+                          void *stream) {
+  if (!logits || !boxes || !depth || !valid || !grad_total || !grad_logits) return -1;
+  if (B <= 0 || C <= 1 || H <= 0 || W <= 0 || N <= 0) return -2;
+  const mono::DdnParams p = ddn_params(B, C, H, W, N, sb, sc, sp, alpha, gamma, fg_weight, bg_weight, depth_min, depth_max);
+  mono::ddn_loss_bwd_kernel<<<mono_ddn_loss_blocks(B, H, W), 256, 0, (hipStream_t)stream>>>(logits, boxes, depth, valid, grad_total,
+                                                                                           grad_logits, p);
   return (int)hipGetLastError();
 }
 

@@ -45,6 +45,9 @@ def lid_bin_indices(depth_map, depth_min=1e-3, depth_max=60, num_bins=80, target
     return indices
 
 
+FUSED_DDN = True      # float32 CUDA logits: the depth-map loss as one kernel per direction
+
+
 def _int_boxes(gt_boxes2d):
     """floor the top-left, ceil the bottom-right (ddn_loss.py:48-50, balancer.py:68-71)."""
     b = gt_boxes2d.clone()
@@ -89,6 +92,11 @@ class DDNLoss(nn.Module):
         ``forward`` exactly; downsample_factor must be 1 (the only value the reference uses)."""
         assert self.downsample_factor == 1
         B, _, H, W = depth_logits.shape
+        if FUSED_DDN:
+            from ..pointwise import ddn_loss, ddn_loss_supported
+            if ddn_loss_supported(depth_logits, boxes_padded, depth_padded, valid):
+                # rasterisation, LID binning, softmax focal loss and balancing: one HIP kernel each way (csrc/ddn_loss.hip)
+                return ddn_loss(depth_logits, boxes_padded, depth_padded, valid, self.alpha, self.gamma, self.fg_weight, self.bg_weight)
         b = boxes_padded.clone()
         b[..., :2] = torch.floor(b[..., :2])
         b[..., 2:] = torch.ceil(b[..., 2:])

@@ -8,7 +8,8 @@ import torch
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
-           "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32")
+           "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
+           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32")
 _lib = None
 
 
@@ -60,6 +61,12 @@ def load():
         lib.mono_colsum_strided_f32.argtypes = [P, P, P, I, LL, LL, I, P]
         lib.mono_colsum_f32.restype = I
         lib.mono_colsum_f32.argtypes = [P, P, P, LL, I, P]
+        lib.mono_ddn_loss_blocks.restype = I
+        lib.mono_ddn_loss_blocks.argtypes = [I, I, I]
+        lib.mono_ddn_loss_fwd_f32.restype = I
+        lib.mono_ddn_loss_fwd_f32.argtypes = [P] * 5 + [I] * 5 + [LL] * 3 + [F] * 6 + [P]
+        lib.mono_ddn_loss_bwd_f32.restype = I
+        lib.mono_ddn_loss_bwd_f32.argtypes = [P] * 6 + [I] * 5 + [LL] * 3 + [F] * 6 + [P]
         _lib = lib
     return _lib
 
@@ -552,3 +559,54 @@ def matched_losses(boxes, depth, dims, angle, idx, t_box, t_depth, t_size, t_bin
     f = torch.float32
     return _MatchedLosses.apply(c(boxes, f), c(depth, f), c(dims, f), c(angle, f), c(idx, torch.int64), c(t_box, f),
                                 c(t_depth.reshape(-1), f), c(t_size, f), c(t_bin.reshape(-1), torch.int64), c(t_res.reshape(-1), f))
+
+
+# ---- DDN depth-map loss (csrc/ddn_loss.hip) ---------------------------------------------------------------------------
+def _ddn_strides(logits):
+    """(batch, channel, pixel) strides in floats of a [B, C, H, W] map whose pixels are row-major with one stride:
+    NCHW-contiguous and channels-last both qualify."""
+    sb, sc, sh, sw = logits.stride()
+    return (sb, sc, sw) if sh == sw * logits.shape[3] else None
+
+
+def ddn_loss_supported(logits, boxes, depth, valid):
+    return (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 4 and _ddn_strides(logits) is not None
+            and boxes.dtype == torch.float32 and depth.dtype == torch.float32 and valid.dtype == torch.bool)
+
+
+class _DDNLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, boxes, depth, valid, alpha, gamma, fg_weight, bg_weight, depth_min, depth_max):
+        B, C, H, W = logits.shape
+        N = boxes.shape[1]
+        boxes, depth, valid = boxes.contiguous(), depth.contiguous(), valid.contiguous()
+        sb, sc, sp = _ddn_strides(logits)
+        lib = load()
+        partial = torch.empty(lib.mono_ddn_loss_blocks(B, H, W), dtype=torch.float32, device=logits.device)
+        code = lib.mono_ddn_loss_fwd_f32(logits.data_ptr(), boxes.data_ptr(), depth.data_ptr(), valid.data_ptr(), partial.data_ptr(),
+                                         B, C, H, W, N, sb, sc, sp, alpha, gamma, fg_weight, bg_weight, depth_min, depth_max,
+                                         torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_ddn_loss_fwd_f32 failed with code %d" % code)
+        ctx.save_for_backward(logits, boxes, depth, valid)
+        ctx.consts = (alpha, gamma, fg_weight, bg_weight, depth_min, depth_max)
+        return partial.sum() / (B * H * W)
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, boxes, depth, valid = ctx.saved_tensors
+        B, C, H, W = logits.shape
+        sb, sc, sp = _ddn_strides(logits)
+        grad = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=logits.device)
+        g = g.reshape(1).to(torch.float32).contiguous()
+        code = load().mono_ddn_loss_bwd_f32(logits.data_ptr(), boxes.data_ptr(), depth.data_ptr(), valid.data_ptr(), g.data_ptr(),
+                                            grad.data_ptr(), B, C, H, W, boxes.shape[1], sb, sc, sp, *ctx.consts,
+                                            torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_ddn_loss_bwd_f32 failed with code %d" % code)
+        return (grad,) + (None,) * 9
+
+
+def ddn_loss(logits, boxes, depth, valid, alpha, gamma, fg_weight, bg_weight, depth_min=1e-3, depth_max=60.0):
+    return _DDNLoss.apply(logits, boxes, depth, valid, float(alpha), float(gamma), float(fg_weight), float(bg_weight),
+                          float(depth_min), float(depth_max))

@@ -293,3 +293,78 @@ def test_monodetr_heads_equal_reference_class_gpu(golden_dir):
     g = _npz(golden_dir, "monodetr_heads")
     _heads_case(g, "cuda", torch.float64, 2e-6)
     _heads_case(g, "cuda", torch.float32, 3e-4)
+
+
+# ---- DDN depth-map loss kernels (csrc/ddn_loss.hip) vs the reference DDNLoss fixture --------------------------------------
+def _ddn_fixture(golden_dir):
+    g = _npz(golden_dir, "losses")
+    boxes, depth = torch.from_numpy(g["boxes"]), torch.from_numpy(g["depth"])
+    pad, dpad, valid = torch.zeros(2, 4, 4), torch.zeros(2, 4), torch.zeros(2, 4, dtype=torch.bool)
+    pad[0, :3], pad[1, 1:3] = boxes[:3], boxes[3:]              # a padding slot BEFORE the second image's boxes as well
+    dpad[0, :3], dpad[1, 1:3] = depth[:3], depth[3:]
+    valid[0, :3], valid[1, 1:3] = True, True
+    return g, pad, dpad, valid
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_ddn_loss_kernels_equal_the_reference_class_and_the_torch_formulation(golden_dir, channels_last):
+    """Forward value against the reference DDNLoss (ddn_loss.py:64-127, fixture made by oracle/gen_golden.py); gradient
+    against autograd through this package's PyTorch formulation of the same loss in float64."""
+    from monosowa_amd.monodetr import losses as L
+    g, pad, dpad, valid = _ddn_fixture(golden_dir)
+    crit = L.DDNLoss()
+    logits_cpu = torch.from_numpy(g["depth_logits"])
+    ref = logits_cpu.double().requires_grad_(True)
+    saved = L.FUSED_DDN
+    try:
+        L.FUSED_DDN = False
+        expect = crit.forward_padded(ref, pad.double(), dpad.double(), valid)
+        (expect * 3.0).backward()
+    finally:
+        L.FUSED_DDN = saved
+    assert abs(expect.item() - float(g["ddn_loss"])) <= 1e-5 * abs(float(g["ddn_loss"]))
+    z = logits_cpu.cuda()
+    if channels_last:
+        z = z.contiguous(memory_format=torch.channels_last)
+    z.requires_grad_(True)
+    assert L.FUSED_DDN
+    got = crit.forward_padded(z, pad.cuda(), dpad.cuda(), valid.cuda())
+    assert got.grad_fn is not None and "DDNLoss" in type(got.grad_fn).__name__, "the HIP kernel did not run"
+    assert abs(got.item() - float(g["ddn_loss"])) <= 1e-5 * abs(float(g["ddn_loss"]))
+    (got * 3.0).backward()
+    assert z.grad.stride() == z.stride()
+    err = (z.grad.cpu().double() - ref.grad).abs().max().item()
+    assert err <= 2e-6 * ref.grad.abs().max().item(), err
+
+
+@pytest.mark.gpu
+def test_ddn_loss_kernels_at_the_training_shape_with_extreme_logits():
+    """B = 16, 24 x 80 map, 50 padded boxes per image, logits up to +-30 (p -> 0 and p -> 1: the focal term's log and
+    1/p stay finite through the log-softmax form), boxes partly outside the map."""
+    from monosowa_amd.monodetr import losses as L
+    gen = torch.Generator().manual_seed(5)
+    B, C, H, W, N = 16, 81, 24, 80, 50
+    logits = torch.randn(B, C, H, W, generator=gen) * 8
+    logits[:, 3] += 30 * (torch.rand(B, H, W, generator=gen) < 0.1)
+    xy = torch.rand(B, N, 2, generator=gen) * torch.tensor([W + 10.0, H + 6.0]) - torch.tensor([8.0, 4.0])
+    wh = torch.rand(B, N, 2, generator=gen) * torch.tensor([20.0, 10.0])
+    boxes = torch.cat([xy, xy + wh], -1)
+    depth = torch.rand(B, N, generator=gen) * 70                 # some beyond depth_max: bin 80
+    valid = torch.rand(B, N, generator=gen) < 0.3
+    crit = L.DDNLoss()
+    ref = logits.double().requires_grad_(True)
+    saved = L.FUSED_DDN
+    try:
+        L.FUSED_DDN = False
+        expect = crit.forward_padded(ref, boxes.double(), depth.double(), valid)
+        expect.backward()
+    finally:
+        L.FUSED_DDN = saved
+    z = logits.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    got = crit.forward_padded(z, boxes.cuda(), depth.cuda(), valid.cuda())
+    got.backward()
+    assert torch.isfinite(z.grad).all()
+    assert abs(got.item() - expect.item()) <= 2e-5 * abs(expect.item()), (got.item(), expect.item())
+    err = (z.grad.cpu().double() - ref.grad).abs().max().item()
+    assert err <= 1e-5 * ref.grad.abs().max().item(), err
