@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--kinds", default="enc,550")
     ap.add_argument("--offsets", choices=["init", "uniform"], default="init")
+    ap.add_argument("--recompute", action="store_true", help="ABI v5 pair (backward re-evaluates the prologue)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -89,8 +90,15 @@ def main():
         value, shapes, lsi, proj, ref, go = make(a.batch, kind, a.offsets, dev)
         B, S, M, D = value.shape
         Lq = proj.shape[1]
-        t_f = timeit(lambda: MSDA.ms_deform_attn_fused_forward_merged(value, shapes, lsi, proj, ref), a.warmup, a.iters)
-        t_b = timeit(lambda: MSDA.ms_deform_attn_fused_backward_merged(value, shapes, lsi, proj, ref, go), a.warmup, a.iters)
+        if MSDA.fused_save_supported(value, shapes, lsi, Lq) and not a.recompute:
+            # what the train step runs at the self-attention shape (ABI v6): the forward stores locations / weights
+            # level-major, the backward reads them
+            _, loc, attw = MSDA.ms_deform_attn_fused_forward_merged_save(value, shapes, lsi, proj, ref)
+            t_f = timeit(lambda: MSDA.ms_deform_attn_fused_forward_merged_save(value, shapes, lsi, proj, ref), a.warmup, a.iters)
+            t_b = timeit(lambda: MSDA.ms_deform_attn_fused_backward_merged_saved(value, shapes, lsi, loc, attw, ref, go), a.warmup, a.iters)
+        else:
+            t_f = timeit(lambda: MSDA.ms_deform_attn_fused_forward_merged(value, shapes, lsi, proj, ref), a.warmup, a.iters)
+            t_b = timeit(lambda: MSDA.ms_deform_attn_fused_backward_merged(value, shapes, lsi, proj, ref, go), a.warmup, a.iters)
         for name, t, bwd in (("fwd", t_f, False), ("bwd", t_b, True)):
             nbytes = alg_bytes(B, S, M, D, 4, 4, Lq, bwd)
             res["msda_%s_Lq%d_B%d" % (name, Lq, B)] = {"ms": t, "alg_bytes": nbytes, "GBps": nbytes / t / 1e6, "frac_of_8TBps": nbytes / (t * 1e-3) / HBM_PEAK}
