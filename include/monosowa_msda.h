@@ -147,8 +147,9 @@ int msda_fused_backward_strided_f32(const float *value, const int64_t *shapes, c
  * (Lq == S: msda_gather_win.hip / msda_scatter_rows.hip) reads those instead of re-evaluating the prologue in its two
  * kernels (the row-tile scatter evaluates every point ~2.3x: measured 0.94 -> 0.66 ms per launch at B = 16).
  * grad_offsets / grad_logits still refer to the RAW projection outputs (row strides as in v5).
- * msda_fused_save_supported() -> 1 when msda_fused_backward_saved_f32 covers the geometry (else use the v5 backward). */
-int msda_fused_save_supported(int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
+ * msda_fused_save_supported() -> 1 when msda_fused_backward_saved_f32 covers the geometry and the reference-point form
+ * (2-d reference points on the self-attention shape); else use the v5 pair. */
+int msda_fused_save_supported(int S, int M, int D, int L, int Lq, int P, int ref_dim, const int64_t *shapes_host,
                               const int64_t *level_start_host);
 int msda_fused_forward_save_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
                                 const float *offsets, const float *logits, const float *ref, int ref_dim, float *out,

@@ -307,12 +307,12 @@ def ms_deform_attn_fused_backward_merged(value, spatial_shapes, level_start_inde
     return grad_value, grad_proj
 
 
-def fused_save_supported(value, spatial_shapes, level_start_index, Lq):
+def fused_save_supported(value, spatial_shapes, level_start_index, Lq, ref_dim=2):
     """True when the training pair msda_fused_forward_save_f32 / msda_fused_backward_saved_f32 (ABI v6) covers this call:
     the self-attention shape (Lq == S) on the window / row-tile kernels."""
     B, S, M, D = value.shape
     geom = host_geometry(spatial_shapes, level_start_index)
-    return bool(_lib.load().msda_fused_save_supported(S, M, D, 4, Lq, 4, geom[0], geom[1]))
+    return bool(_lib.load().msda_fused_save_supported(S, M, D, 4, Lq, 4, ref_dim, geom[0], geom[1]))
 
 
 def ms_deform_attn_fused_forward_merged_save(value, spatial_shapes, level_start_index, proj, reference_points):

@@ -25,11 +25,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("MONOSOWA_MSDA_LIB", LIB_PATH)        # another BUILD of the same library (A/B measurements)
+    if not os.path.exists(path):
         raise MSDALibraryError(
             "HIP extension %s is missing: build it with `python -m monosowa_amd.build` "
-            "(needs hipcc; there is no CPU fallback)" % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            "(needs hipcc; there is no CPU fallback)" % path)
+    lib = ctypes.CDLL(path)
     P, I, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     lib.msda_abi_version.restype = I
     lib.msda_strerror.restype = ctypes.c_char_p
@@ -54,7 +55,7 @@ def load():
     lib.msda_fused_backward_strided_f32.restype = I
     lib.msda_fused_backward_strided_f32.argtypes = [P] * 6 + [I] + [P] * 4 + [I] * 9 + [P, P, P, Z, P]
     lib.msda_fused_save_supported.restype = I
-    lib.msda_fused_save_supported.argtypes = [I] * 6 + [P, P]
+    lib.msda_fused_save_supported.argtypes = [I] * 7 + [P, P]
     lib.msda_fused_forward_save_f32.restype = I
     lib.msda_fused_forward_save_f32.argtypes = [P] * 6 + [I, P, P, P] + [I] * 9 + [P, P, P]
     lib.msda_fused_backward_saved_f32.restype = I

@@ -56,6 +56,7 @@ struct Options {
   int gather_chunks_fwd = 16, gather_chunks_bwd = 8;      // query slices per (batch, head) of the staged gather kernels
   int window = 3;              // tile-window gather kernels when Lq == S (msda_gather_win.hip): bit 0 forward, bit 1 backward
   int window_halo = 5;         // pixels of the sampled level a window extends beyond its tile's queries
+  int window_persistent = 1;   // 1 (default): one workgroup per CU walks the items, inputs prefetched a unit ahead; 0: one per item
   int scatter_rows = 1;        // 1 (default): row-tile scatter (msda_scatter_rows.hip) with the window backward when Lq == S
   int scatter_reach = 6;       // its near-point reach in pixels (farther points: global atomics in the gather kernel)
   Options() {                                               // the environment is read ONCE, at first use
@@ -65,6 +66,7 @@ struct Options {
     if (const char *e = std::getenv("MSDA_GATHER_CHUNKS")) gather_chunks_fwd = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("MSDA_GATHER_CHUNKS_BWD")) gather_chunks_bwd = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("MSDA_WINDOW")) window = std::atoi(e) & 3;
+    if (const char *e = std::getenv("MSDA_WINDOW_PERSISTENT")) window_persistent = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSDA_SCATTER_ROWS")) scatter_rows = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSDA_SCATTER_REACH")) scatter_reach = std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("MSDA_WINDOW_HALO")) window_halo = std::min(32, std::max(0, std::atoi(e)));
@@ -128,27 +130,41 @@ bool make_gather_geom(const int64_t *shapes_host, const int64_t *lsi_host, int B
 
 
 // Tiling of the tile-window kernels for a pyramid (searched once per geometry and halo, then cached).
-bool window_tiling(const int64_t *shapes_host, const int64_t *lsi_host, int halo, msda::WinGeom &out) {
+bool window_tiling(const int64_t *shapes_host, const int64_t *lsi_host, int halo, bool bwd, msda::WinGeom &out) {
   static std::mutex mu;
   static std::map<std::vector<int64_t>, std::pair<bool, msda::WinGeom>> cache;
   std::vector<int64_t> key(shapes_host, shapes_host + 8);
   key.insert(key.end(), lsi_host, lsi_host + 4);
   key.push_back(halo);
+  key.push_back(bwd);
   std::lock_guard<std::mutex> lock(mu);
   auto it = cache.find(key);
   if (it == cache.end()) {
     msda::WinGeom g{};
-    const bool ok = msda::choose_window_tiling(shapes_host, lsi_host, halo, g);
+    // the backward keeps a block of grad_out rows per wave behind the windows
+    const bool ok = msda::choose_window_tiling(shapes_host, lsi_host, halo, bwd ? msda::kWinMaxRowsBwd : msda::kWinMaxRows, g);
     it = cache.emplace(key, std::make_pair(ok, g)).first;
   }
   out = it->second.second;
   return it->second.first;
 }
 
+// One workgroup per CU for the persistent kernels (a multiple of 8: the XCD-aware item order relies on it).
+inline int persistent_grid() {
+  static const int n = [] {
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    return std::max(8, cus / 8 * 8);
+  }();
+  return n;
+}
+
 inline bool window_applies(bool bwd, const int64_t *shapes_host, const int64_t *lsi_host, int Lq, int S) {
   msda::WinGeom wg;
   return Lq == S && (options().window & (bwd ? 2 : 1)) && gather_mode() > 1 &&
-         window_tiling(shapes_host, lsi_host, options().window_halo, wg);
+         window_tiling(shapes_host, lsi_host, options().window_halo, bwd, wg);
 }
 
 // Launch of the record-based gather kernels (forward or the backward's grad_loc / grad_attn_w pass), staged when
@@ -160,16 +176,19 @@ void launch_gather(const float *value, const float *loc, const float *attw, cons
                    float *grad_value = nullptr, int far_reach = -1) {
   if (!loc_rs) loc_rs = M * 32;
   if (!aw_rs) aw_rs = M * 16;
-  if (Lq == S && (options().window & (BWD ? 2 : 1)) && gather_mode() > 1) {
-    // self-attention shape: query i sits at token i's pixel -> tile-local value windows (msda_gather_win.hip)
+  if (Lq == S && (options().window & (BWD ? 2 : 1)) && gather_mode() > 1 && (!FUSED || ref_dim == 2)) {
+    // self-attention shape (the window kernels evaluate the 2-d reference-point formula only): query i sits at token i's pixel -> tile-local value windows (msda_gather_win.hip)
     msda::WinGeom wg;
-    if (window_tiling(shapes_host, lsi_host, options().window_halo, wg)) {
+    if (window_tiling(shapes_host, lsi_host, options().window_halo, BWD, wg)) {
       const int bm_groups = (B * M + 7) / 8;
       msda::WinTable wt;
       msda::fill_window_table(wg, wt);
-      msda::gather_win_kernel<BWD, FUSED, SAVED><<<8 * wg.n_ty * wg.n_tx * bm_groups, msda::kWinThreads, 0, stream>>>(
+      // persistent: one workgroup per CU walks the (batch * head, tile) items (window_persistent = 0: one workgroup per item)
+      const int n_virtual = 8 * wg.n_ty * wg.n_tx * bm_groups;
+      const int grid = options().window_persistent ? std::min(n_virtual, persistent_grid()) : n_virtual;
+      msda::gather_win_kernel<BWD, FUSED, SAVED><<<grid, BWD ? msda::kWinThreadsBwd : msda::kWinThreads, 0, stream>>>(
           value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, wt, B, S, M, loc_rs, aw_rs,
-          grad_value, far_reach);
+          grad_value, far_reach, n_virtual);
       return;
     }
   }
@@ -306,7 +325,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       }
       if (int e = check_host_geometry(shapes_host, lsi_host, L, S)) return e;
       // self-attention shape: row-tile scatter + window gather (no transposed lists, no LDS atomics per channel)
-      if (options().scatter_rows && window_applies(true, shapes_host, lsi_host, Lq, S)) {
+      if (options().scatter_rows && window_applies(true, shapes_host, lsi_host, Lq, S) && (!fused_ref || fused_ref_dim == 2)) {
         msda::RowPlan rp;
         if (msda::make_row_plan(shapes_host, lsi_host, options().scatter_reach, rp) &&
             msda::row_plan_table_bytes(rp) <= workspace_bytes) {
@@ -415,6 +434,7 @@ int msda_set_option(const char *name, int value) {
   if (n == "scatter_sorted" && value >= 0 && value <= 2) { options().scatter_sorted = value; return 0; }
   if (n == "window" && value >= 0 && value <= 3) { options().window = value; return 0; }
   if (n == "window_halo" && value >= 0 && value <= 32) { options().window_halo = value; return 0; }
+  if (n == "window_persistent" && (value == 0 || value == 1)) { options().window_persistent = value; return 0; }
   if (n == "scatter_rows" && (value == 0 || value == 1)) { options().scatter_rows = value; return 0; }
   if (n == "scatter_reach" && value >= 1 && value <= 16) { options().scatter_reach = value; return 0; }
   return MSDA_E_UNSUPPORTED;
@@ -519,9 +539,10 @@ int msda_fused_backward_strided_f32(const float *value, const int64_t *shapes, c
 }
 
 // ---- ABI v6: the fused forward hands the backward the locations / weights it evaluated -------------------------------
-int msda_fused_save_supported(int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
+int msda_fused_save_supported(int S, int M, int D, int L, int Lq, int P, int ref_dim, const int64_t *shapes_host,
                               const int64_t *level_start_host) {
-  if (!shapes_host || !level_start_host || !(D == 32 && L == 4 && P == 4) || M * L * 8 > 1024) return 0;
+  // (the tile-window kernels evaluate the 2-d reference-point formula only; 6-d reference points stay on the v5 pair)
+  if (!shapes_host || !level_start_host || !(D == 32 && L == 4 && P == 4) || M * L * 8 > 1024 || ref_dim != 2) return 0;
   if (check_host_geometry(shapes_host, level_start_host, L, S)) return 0;
   msda::RowPlan rp;
   return options().scatter_rows && window_applies(true, shapes_host, level_start_host, Lq, S) &&
@@ -541,7 +562,7 @@ int msda_fused_forward_save_f32(const float *value, const int64_t *shapes, const
   if (!(D == 32 && L == 4 && P == 4) || (ref_dim != 2 && ref_dim != 6)) return MSDA_E_UNSUPPORTED;
   if (offsets_row_stride < M * 32 || logits_row_stride < M * 16 || (offsets_row_stride & 3) || (logits_row_stride & 3))
     return MSDA_E_SHAPE;
-  if (!msda_fused_save_supported(S, M, D, L, Lq, P, shapes_host, level_start_host)) return MSDA_E_UNSUPPORTED;
+  if (!msda_fused_save_supported(S, M, D, L, Lq, P, ref_dim, shapes_host, level_start_host)) return MSDA_E_UNSUPPORTED;
   launch_gather<false, true, true>(value, offsets, logits, nullptr, out, loc_save, attn_save, ref, ref_dim, shapes_host,
                                    level_start_host, B, S, M, Lq, (hipStream_t)stream, offsets_row_stride, logits_row_stride);
   return (int)hipGetLastError();
@@ -554,7 +575,7 @@ int msda_fused_backward_saved_f32(const float *value, const int64_t *shapes, con
                                   int logits_row_stride, const int64_t *shapes_host, const int64_t *level_start_host,
                                   void *workspace, size_t workspace_bytes, void *stream) {
   if (!ref || !shapes_host || !level_start_host) return MSDA_E_NULLPTR;
-  if (!msda_fused_save_supported(S, M, D, L, Lq, P, shapes_host, level_start_host) || (ref_dim != 2 && ref_dim != 6))
+  if (!msda_fused_save_supported(S, M, D, L, Lq, P, ref_dim, shapes_host, level_start_host))
     return MSDA_E_UNSUPPORTED;
   if (offsets_row_stride < M * 32 || logits_row_stride < M * 16 || (offsets_row_stride & 3) || (logits_row_stride & 3))
     return MSDA_E_SHAPE;

@@ -29,161 +29,183 @@
 #include "msda_window.h"
 #include <type_traits>
 
+#ifndef MSDA_WIN_SKIP
+#define MSDA_WIN_SKIP 0          // measurement builds only: 1 no fill, 2 no row reads (forward), 4 no output stores (forward), 8 no prefetch, 16 no saves
+#endif
+
 namespace msda {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void global_cvoid_t;
 
 // BWD = false: out[pair] = sum of sampled rows.   BWD = true: grad_loc / grad_attn_w of the pair.
-// FUSED: `loc` / `attw` carry raw sampling offsets / attention logits, `ref` the reference points [B, Lq, 4, ref_dim].
+// FUSED: `loc` / `attw` carry raw sampling offsets / attention logits, `ref` the reference points [B, Lq, 4, 2] (the host
+// keeps 6-d reference points on the record kernels: ref_dim must be 2 here).
 // SAVED (with FUSED): forward -- also store the sampling locations / attention weights it evaluated (`grad_loc` / `grad_attw`
 // double as the contiguous save buffers); backward -- `loc` / `attw` ARE those saved tensors (contiguous), only the chain
 // rule back to offsets / logits is evaluated here: no softmax, no reference-point arithmetic in the backward's hot loops.
+//
+// PERSISTENT workgroups: the grid is one workgroup per CU (the host passes n_virtual = the number of (batch * head, tile)
+// items); a workgroup walks items blockIdx.x, blockIdx.x + gridDim.x, ... and, within an item, passes of 128 (query, head)
+// pairs.  The unit of the software pipeline is one (item, pass): while a unit's corner rows are read from LDS, the NEXT
+// unit's per-lane inputs (offsets / logits / reference point, the lane's 16 bytes of grad_out) are already in flight, so
+// the only exposed memory phase of an item is the LDS-DMA fill of its windows -- and this lane's tap arithmetic runs under
+// that.  With one workgroup per item (the previous form) launch, input latency, fill and row reads ran back to back, 20
+// times per CU: measured 0.35 ms forward of which ~0.10 ms was that prologue.
 template <bool BWD, bool FUSED, bool SAVED = false>
-__global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
+__global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? kWinThreadsBwd / 256 : 4) void gather_win_kernel(
     const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attw,
     const float *__restrict__ grad_out, float *__restrict__ out, float *__restrict__ grad_loc,
     float *__restrict__ grad_attw, const float *__restrict__ ref, int ref_dim, const WinTable g, int B, int S, int M,
-    int loc_rs, int aw_rs, float *__restrict__ grad_value, int far_reach) {
+    int loc_rs, int aw_rs, float *__restrict__ grad_value, int far_reach, int n_virtual) {
   // far_reach >= 0 (backward, with msda_scatter_rows.hip): points that are not near_point(.., far_reach) add their
   // grad_value contributions here with global atomics -- the row-tile scatter handles exactly the near ones
   __shared__ float4 win[(kWinMaxRows + 1) * 8];                 // value windows, 8 float4 = one 128-byte row; + the zero row
   constexpr int kZeroOff = kWinMaxRows * 128;                   // byte offset of the zero row
+  // backward: the last kWinGoRows rows hold grad_out rows, one 1-KiB block per wave (its 8 pairs); the host's tiling
+  // leaves them free (kWinMaxRowsBwd)
+  constexpr int kGoOff = (kWinMaxRows - kWinGoRows) * 128;
+  constexpr int kThreads = BWD ? kWinThreadsBwd : kWinThreads, kPairs = kThreads / 8;       // (query, head) pairs per pass
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = threadIdx.x & 7;
   const int tok = M * 32;
-
-  // workgroup -> (batch * head, tile); the tiles of one (batch, head) share blockIdx % 8 = one XCD's L2 (speed only)
   const int n_tiles = g.n_ty * g.n_tx;
-  const int bm = (int)(blockIdx.x % 8) + 8 * (int)(blockIdx.x / (8 * n_tiles));
-  if (bm >= B * M) return;
-  const int tile = (int)((blockIdx.x / 8) % n_tiles);
-  const int ty = tile / g.n_tx, tx = tile - ty * g.n_tx;
-  const int b = bm / M, m = bm - b * M;
-
-  // ---- tile geometry from the host's separable table (kernel argument: no division, no register arrays)
-  const AxisSpec *ay_tab = g.ax[ty], *ax_tab = g.ax[g.n_ty + tx];
-  const float *value_bm = value + ((long long)b * S * M + m) * 32;
   if (threadIdx.x < 8) win[kWinMaxRows * 8 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  int base1 = 0, base2 = 0, base3 = 0, first1 = 0, first2 = 0, first3 = 0, n_queries = 0;
-  {
-    int rows = 0;
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      if (l == 1) { base1 = rows; first1 = n_queries; }
-      if (l == 2) { base2 = rows; first2 = n_queries; }
-      if (l == 3) { base3 = rows; first3 = n_queries; }
-      rows += ((int)ay_tab[l].wn * (int)ax_tab[l].wn + 7) & ~7;
-      n_queries += (int)ay_tab[l].qn * (int)ax_tab[l].qn;
-    }
-  }
+  // ---- an item's scalars: virtual index -> (batch * head, tile); the tiles of one (batch, head) share v % 8, which is
+  // blockIdx.x % 8 for every item of this workgroup (gridDim.x is a multiple of 8) = one XCD's L2 (speed only)
+  struct Item { int b, m, ty, tx, first1, first2, first3, n_queries; };
+  auto make_item = [&](const int v) {
+    Item it;
+    const int bm = (v & 7) + 8 * (v / (8 * n_tiles));
+    const int tile = (v >> 3) % n_tiles;
+    it.ty = tile / g.n_tx;
+    it.tx = tile - it.ty * g.n_tx;
+    it.b = bm / M;
+    it.m = bm - it.b * M;
+    const AxisSpec *ay_tab = g.ax[it.ty], *ax_tab = g.ax[g.n_ty + it.tx];
+    int n = 0;
+    n += (int)ay_tab[0].qn * (int)ax_tab[0].qn; it.first1 = n;
+    n += (int)ay_tab[1].qn * (int)ax_tab[1].qn; it.first2 = n;
+    n += (int)ay_tab[2].qn * (int)ax_tab[2].qn; it.first3 = n;
+    n += (int)ay_tab[3].qn * (int)ax_tab[3].qn; it.n_queries = n;
+    return it;
+  };
+  auto item_valid = [&](const int v) { return v < n_virtual && (v & 7) + 8 * (v / (8 * n_tiles)) < B * M; };
 
-  // ---- (1a) per-pair inputs of both passes: issued BEFORE the window fill so that their wait does not sit behind it ------
+  // ---- a unit's per-lane inputs (lane j of a pair holds points 2j, 2j + 1 after the coalesced load) -----------------------
   const int l_mine = sub >> 1;                                           // level of this lane's two points
-  float4 lc[kWinMaxPasses];
-  float2 aw[kWinMaxPasses];
-  int q_lin[kWinMaxPasses];                                              // b * S + q (host: B * S < 2^31)
-  int cf_y[kWinMaxPasses], cf_x[kWinMaxPasses];                          // the query's centre floor at this lane's level
-  bool live[kWinMaxPasses];
-#pragma unroll
-  for (int ps = 0; ps < kWinMaxPasses; ++ps) {
-    const int i = ps * kWinPairsPerPass + (threadIdx.x >> 3);             // query of the tile
-    live[ps] = i < n_queries;
-    lc[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-    aw[ps] = make_float2(0.f, 0.f);
-    q_lin[ps] = cf_y[ps] = cf_x[ps] = 0;
-    if (live[ps]) {
+  const int Hm = g.H[l_mine], Wm = g.W[l_mine], start_m = g.start[l_mine];
+  struct In {
+    float4 lc, go;           // offsets / locations of the two points; this lane's 16 bytes of the pair's grad_out row
+    float2 aw;
+    float2 rf;               // FUSED forward: the reference point (x, y) of this lane's level (ref_dim == 2 only, see the host)
+    int q_lin, cf_y, cf_x;   // b * S + q (host: B * S < 2^31), -1 for a lane without a query; its centre floor at this lane's level
+  };
+  auto load_unit = [&](const Item &it, const int ps) {
+    In in{};
+    const AxisSpec *ay_tab = g.ax[it.ty], *ax_tab = g.ax[g.n_ty + it.tx];
+    const int i = ps * kPairs + (threadIdx.x >> 3);             // query of the tile
+    in.q_lin = -1;
+    if (i < it.n_queries) {
       // query i of the tile -> (level, row, column): the level by three compares, then ONE small division
-      const int ql = (i >= first1) + (i >= first2) + (i >= first3);
-      const AxisSpec ayq = ay_tab[ql], axq = ax_tab[ql];
-      const int k = i - (ql == 0 ? 0 : (ql == 1 ? first1 : (ql == 2 ? first2 : first3)));
-      const int dy = (int)(((float)k + 0.5f) / (float)axq.qn), dx = k - dy * axq.qn;          // exact: k < 256
-      q_lin[ps] = b * S + g.start[ql] + (ayq.q0 + dy) * g.W[ql] + axq.q0 + dx;                // Lq == S
+      // (the per-level table entries are wave-uniform scalars picked by compares: indexing the kernel-argument table with a
+      // per-lane level would be a dependent vector load in front of the input loads)
+      const int ql = (i >= it.first1) + (i >= it.first2) + (i >= it.first3);
+      auto pick = [&](const int a0, const int a1, const int a2, const int a3) { return ql == 0 ? a0 : (ql == 1 ? a1 : (ql == 2 ? a2 : a3)); };
+      auto qpart = [](const AxisSpec a) { return (int)(unsigned short)a.q0 | ((int)(unsigned short)a.qn << 16); };
+      const int yq = pick(qpart(ay_tab[0]), qpart(ay_tab[1]), qpart(ay_tab[2]), qpart(ay_tab[3]));
+      const int xq = pick(qpart(ax_tab[0]), qpart(ax_tab[1]), qpart(ax_tab[2]), qpart(ax_tab[3]));
+      const int qy0 = yq & 0xFFFF, qx0 = xq & 0xFFFF, qxn = xq >> 16;
+      const int Wq = pick(g.W[0], g.W[1], g.W[2], g.W[3]);
+      const int k = i - pick(0, it.first1, it.first2, it.first3);
+      const int dy = (int)(((float)k + 0.5f) / (float)qxn), dx = k - dy * qxn;                // exact: k < 256
+      const int q = pick(g.start[0], g.start[1], g.start[2], g.start[3]) + (qy0 + dy) * Wq + qx0 + dx;       // Lq == S
+      in.q_lin = it.b * S + q;
       if (BWD && far_reach >= 0) {
-        cf_y[ps] = centre_floor(ayq.q0 + dy, g.H[ql], g.H[sub >> 1]);
-        cf_x[ps] = centre_floor(axq.q0 + dx, g.W[ql], g.W[sub >> 1]);
+        in.cf_y = centre_floor(qy0 + dy, pick(g.H[0], g.H[1], g.H[2], g.H[3]), Hm);
+        in.cf_x = centre_floor(qx0 + dx, Wq, Wm);
       }
-      const long long ql64 = q_lin[ps];
+      const long long ql64 = in.q_lin;
       if (BWD && SAVED) {
         // the forward's saved tensors are LEVEL-MAJOR, [B, M, L, Lq, P(, 2)]: a level's points of neighbouring queries are
         // neighbours in memory, which is what the row-tile scatter's scan wants (whole lines instead of 32-byte quarters)
-        const long long pl = (((long long)(b * M + m) * 4 + (sub >> 1)) * S + (q_lin[ps] - b * S)) * 4 + (sub & 1) * 2;
-        lc[ps] = ld4(loc + pl * 2);
-        aw[ps] = *reinterpret_cast<const float2 *>(attw + pl);
+        const long long pl = (((long long)(it.b * M + it.m) * 4 + l_mine) * S + q) * 4 + (sub & 1) * 2;
+        in.lc = ld4(loc + pl * 2);
+        in.aw = *reinterpret_cast<const float2 *>(attw + pl);
       } else {
-        lc[ps] = ld4(loc + ql64 * loc_rs + m * 32 + sub * 4);
-        aw[ps] = *reinterpret_cast<const float2 *>(attw + ql64 * aw_rs + m * 16 + sub * 2);
+        in.lc = ld4(loc + ql64 * loc_rs + it.m * 32 + sub * 4);
+        in.aw = *reinterpret_cast<const float2 *>(attw + ql64 * aw_rs + it.m * 16 + sub * 2);
       }
+      if (FUSED && !(BWD && SAVED)) in.rf = *reinterpret_cast<const float2 *>(ref + (ql64 * 4 + l_mine) * 2);
+      if (BWD) in.go = ld4(grad_out + (ql64 * M + it.m) * 32 + sub * 4);
     }
-  }
+    return in;
+  };
 
-  // ---- (1b) LDS-DMA fill of the four windows: thread -> (row, 16-byte slot); a wave instruction lands 8 consecutive rows.
-  // Level l's window starts at LDS row base_l (multiple of 8), levels in order.
-  {
-    int rows = 0;
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      const AxisSpec ay = ay_tab[l], ax = ax_tab[l];
-      const int ww = ax.wn, n_rows = (int)ay.wn * ww, Wl = g.W[l];
-      const int first_tok = g.start[l] + (int)ay.w0 * Wl + ax.w0;
-      const float inv_ww = 1.0f / (float)ww;
-      for (int r0 = wave * 8; r0 < n_rows; r0 += kWinThreads / 8) {
-        const int r = r0 + (lane >> 3);
-        float4 *dst = win + (size_t)(rows + r0) * 8;                           // wave-uniform; lane i lands at dst + i
-        if (r < n_rows) {
-          const int y = (int)(((float)r + 0.5f) * inv_ww), x = r - y * ww;     // exact: r < 2^11, ww <= 2^7
-          const float *src = value_bm + (long long)(first_tok + y * Wl + x) * tok + sub * 4;
-          __builtin_amdgcn_global_load_lds((global_cvoid_t *)src, (lds_void_t *)dst, 16, 0, 0);
-        }
-      }
-      rows += (n_rows + 7) & ~7;
-    }
-  }
-
-  // this lane's level: extent, window, LDS base
-  const int Hm = g.H[l_mine], Wm = g.W[l_mine], start_m = g.start[l_mine];
-  const AxisSpec aym = ay_tab[l_mine], axm = ax_tab[l_mine];
-  const int wy_lo = aym.w0, wy_hi = wy_lo + aym.wn - 1, wx_lo = axm.w0, wx_hi = wx_lo + axm.wn - 1, ww_m = axm.wn;
-  const int base_m = l_mine == 0 ? 0 : (l_mine == 1 ? base1 : (l_mine == 2 ? base2 : base3));
-  const char *wbytes = reinterpret_cast<const char *>(win);
+  char *wbytes = reinterpret_cast<char *>(win);
   const int rot = sub ^ (lane >> 3);                                     // see row() below
 
-  bool waited = false;
-#pragma unroll
-  for (int ps = 0; ps < kWinMaxPasses; ++ps) {
-    if (ps * kWinPairsPerPass >= n_queries) break;                        // wave-uniform
-    const long long ql64 = q_lin[ps];
-    // ---- this lane's two taps ------------------------------------------------------------------------------------------
-    float2 a2 = aw[ps];
-    float4 l4 = lc[ps];
-    float2 ref_scale = make_float2(1.f, 1.f);                             // FUSED backward: d location / d offset
+  int v = blockIdx.x;
+  while (v < n_virtual && !item_valid(v)) v += gridDim.x;
+  if (v >= n_virtual) return;
+  Item it = make_item(v);
+  int ps = 0;
+  In nxt = load_unit(it, 0);
+  bool first = true;
+
+  while (true) {
+    In in = (MSDA_WIN_SKIP & 8) ? load_unit(it, ps) : nxt;
+    // the unit's inputs have arrived long ago; consuming them HERE keeps their wait (which the compiler can only express as
+    // vmcnt(0) once the fill below is in flight) in front of the fill
+    asm volatile("" : "+v"(in.lc.x), "+v"(in.lc.y), "+v"(in.lc.z), "+v"(in.lc.w), "+v"(in.aw.x), "+v"(in.aw.y), "+v"(in.rf.x),
+                 "+v"(in.rf.y) : : "memory");
+    if (BWD) asm volatile("" : "+v"(in.go.x), "+v"(in.go.y), "+v"(in.go.z), "+v"(in.go.w) : : "memory");
+    const AxisSpec *ay_tab = g.ax[it.ty], *ax_tab = g.ax[g.n_ty + it.tx];
+    const float *value_bm = value + ((long long)it.b * S * M + it.m) * 32;
+    int base1, base2, base3;
+    {
+      int rows = 0;
+      rows += ((int)ay_tab[0].wn * (int)ax_tab[0].wn + 7) & ~7; base1 = rows;
+      rows += ((int)ay_tab[1].wn * (int)ax_tab[1].wn + 7) & ~7; base2 = rows;
+      rows += ((int)ay_tab[2].wn * (int)ax_tab[2].wn + 7) & ~7; base3 = rows;
+    }
+
+    // ---- this lane's two taps: pure VALU, evaluated UNDER the fill when the unit starts an item.  Fill, taps and the fill's wait
+    // sit in one branch: with the wait in a second `if (ps == 0)` the compiler's wait-count pass sees a path from the fill to the
+    // LDS reads that skips it and puts its own vmcnt(0) in front of the first row read -- behind the next unit's input loads.
+    const bool live = in.q_lin >= 0;
+    const long long ql64 = live ? in.q_lin : 0;
+    // the tile's window of this lane's level: the four levels' specs are wave-uniform (scalar loads), picked per lane
+    int wy_lo, wy_hi, wx_lo, wx_hi, ww_m;
+    {
+      auto packed = [](const AxisSpec a) { return (int)(unsigned short)a.w0 | ((int)(unsigned short)a.wn << 16); };
+      const int y0 = packed(ay_tab[0]), y1 = packed(ay_tab[1]), y2 = packed(ay_tab[2]), y3 = packed(ay_tab[3]);
+      const int x0 = packed(ax_tab[0]), x1 = packed(ax_tab[1]), x2 = packed(ax_tab[2]), x3 = packed(ax_tab[3]);
+      const int yp = l_mine == 0 ? y0 : (l_mine == 1 ? y1 : (l_mine == 2 ? y2 : y3));
+      const int xp = l_mine == 0 ? x0 : (l_mine == 1 ? x1 : (l_mine == 2 ? x2 : x3));
+      wy_lo = yp & 0xFFFF; wy_hi = wy_lo + (yp >> 16) - 1;
+      wx_lo = xp & 0xFFFF; ww_m = xp >> 16; wx_hi = wx_lo + ww_m - 1;
+    }
+    const int base_m = l_mine == 0 ? 0 : (l_mine == 1 ? base1 : (l_mine == 2 ? base2 : base3));
+    float2 a2 = in.aw;
+    float4 l4 = in.lc;
+    const float2 ref_scale = make_float2((float)Wm, (float)Hm);          // FUSED backward: d location / d offset (ref_dim == 2)
     if (FUSED && !(BWD && SAVED)) {
       // softmax over the pair's 16 logits (2 per lane), then this lane's two sampling locations (msda_common.h)
       const float mx = group_max(fmaxf(a2.x, a2.y));
       const float e0 = expf(a2.x - mx), e1 = expf(a2.y - mx);
       const float denom = group_sum(e0 + e1);
       a2 = make_float2(e0 / denom, e1 / denom);
-      if (live[ps]) {
-        const RefScale rs = load_ref(ref + (ql64 * 4 + l_mine) * ref_dim, ref_dim, Hm, Wm);
-        ref_scale = make_float2(rs.sx, rs.sy);
-        l4 = make_float4(loc_from_offset<4>(rs.rx, l4.x, rs.sx, ref_dim), loc_from_offset<4>(rs.ry, l4.y, rs.sy, ref_dim),
-                         loc_from_offset<4>(rs.rx, l4.z, rs.sx, ref_dim), loc_from_offset<4>(rs.ry, l4.w, rs.sy, ref_dim));
-        if (!BWD && SAVED) {                                            // hand the backward what was evaluated here (level-major)
-          const long long pl = (((long long)(b * M + m) * 4 + l_mine) * S + (q_lin[ps] - b * S)) * 4 + (sub & 1) * 2;
-          st4(grad_loc + pl * 2, l4);
-          *reinterpret_cast<float2 *>(grad_attw + pl) = a2;
-        }
-      }
-    }
-    if (FUSED && BWD && SAVED && live[ps]) {
-      const RefScale rs = load_ref(ref + (ql64 * 4 + l_mine) * ref_dim, ref_dim, Hm, Wm);
-      ref_scale = make_float2(rs.sx, rs.sy);
+      if (live)
+        l4 = make_float4(loc_from_offset<4>(in.rf.x, l4.x, (float)Wm, 2), loc_from_offset<4>(in.rf.y, l4.y, (float)Hm, 2),
+                         loc_from_offset<4>(in.rf.x, l4.z, (float)Wm, 2), loc_from_offset<4>(in.rf.y, l4.w, (float)Hm, 2));
     }
     int off[2][4];
     float cw[2][4];          // forward: corner weights x attn_w.  backward: lh, lw, W attn_w, H attn_w
     int far_points = 0;      // backward with the row-tile scatter: which of the two points it does not cover
+    auto taps = [&]() {
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
       const float lx = k2 ? l4.z : l4.x, ly = k2 ? l4.w : l4.y, wt = k2 ? a2.y : a2.x;
@@ -197,7 +219,7 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
                 ldy = (tp.y1 - tp.y0) * ww_m * 128;
       const int mem00 = start_m + tp.y0 * Wm + tp.x0, mdx = tp.x1 - tp.x0, mdy = (tp.y1 - tp.y0) * Wm;
       auto pick = [&](const int in_lds, const int in_mem, const bool keep) {
-        return (keep && live[ps]) ? (inwin ? in_lds : ((in_mem << 4) | 1)) : kZeroOff;
+        return (keep && live) ? (inwin ? in_lds : ((in_mem << 4) | 1)) : kZeroOff;
       };
       off[k2][0] = pick(lds00, mem00, tp.t && tp.l);
       off[k2][1] = pick(lds00 + ldx, mem00 + mdx, tp.t && tp.r);
@@ -205,13 +227,64 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
       off[k2][3] = pick(lds00 + ldy + ldx, mem00 + mdy + mdx, tp.b && tp.r);
       if (BWD) { cw[k2][0] = tp.lh; cw[k2][1] = tp.lw; cw[k2][2] = (float)Wm * wt; cw[k2][3] = (float)Hm * wt; }
       else { cw[k2][0] = tp.w1 * wt; cw[k2][1] = tp.w2 * wt; cw[k2][2] = tp.w3 * wt; cw[k2][3] = tp.w4 * wt; }
-      if (BWD && far_reach >= 0 && live[ps] && tp.valid && !near_point(tp.h_low, tp.w_low, cf_y[ps], cf_x[ps], far_reach))
+      if (BWD && far_reach >= 0 && live && tp.valid && !near_point(tp.h_low, tp.w_low, in.cf_y, in.cf_x, far_reach))
         far_points |= 1 << k2;
     }
-    if (!waited) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's share of the windows has landed
+      // the taps are final HERE (the asm statements consume them): otherwise the compiler sinks the tap arithmetic into the
+      // row loops below -- behind the fill's wait instead of under it, with all its intermediates alive across the loops
+      asm volatile("" : "+v"(off[0][0]), "+v"(off[0][1]), "+v"(off[0][2]), "+v"(off[0][3]), "+v"(off[1][0]), "+v"(off[1][1]),
+                   "+v"(off[1][2]), "+v"(off[1][3]) : : "memory");
+      asm volatile("" : "+v"(cw[0][0]), "+v"(cw[0][1]), "+v"(cw[0][2]), "+v"(cw[0][3]), "+v"(cw[1][0]), "+v"(cw[1][1]),
+                   "+v"(cw[1][2]), "+v"(cw[1][3]) : : "memory");
+    };
+    if (ps == 0) {
+      // ---- LDS-DMA fill of the four windows: thread -> (row, 16-byte slot); a wave instruction lands 8 consecutive rows.
+      // Level l's window starts at LDS row base_l (multiple of 8), levels in order.
+      if (!first) __syncthreads();                                        // every wave has finished with the previous windows
+      int rows = 0;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const AxisSpec ay = ay_tab[l], ax = ax_tab[l];
+        const int ww = ax.wn, n_rows = (int)ay.wn * ww, Wl = g.W[l];
+        const int first_tok = g.start[l] + (int)ay.w0 * Wl + ax.w0;
+        const float inv_ww = 1.0f / (float)ww;
+        for (int r0 = wave * 8; r0 < n_rows; r0 += kThreads / 8) {
+          const int r = r0 + (lane >> 3);
+          float4 *dst = win + (size_t)(rows + r0) * 8;                           // wave-uniform; lane i lands at dst + i
+          if (r < n_rows && !(MSDA_WIN_SKIP & 1)) {
+            const int y = (int)(((float)r + 0.5f) * inv_ww), x = r - y * ww;     // exact: r < 2^11, ww <= 2^7
+            const float *src = value_bm + (long long)(first_tok + y * Wl + x) * tok + sub * 4;
+            __builtin_amdgcn_global_load_lds((global_cvoid_t *)src, (lds_void_t *)dst, 16, 0, 0);
+          }
+        }
+        rows += (n_rows + 7) & ~7;
+      }
+      taps();
+      // this wave's share of the windows has landed.  The builtin, not inline asm: the wait-count pass must KNOW that nothing
+      // is outstanding here.   (vmcnt 0, expcnt 7, lgkmcnt 15)
+      __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();                                                    // ... and everyone else's
-      waited = true;
+      first = false;
+    } else {
+      taps();
+    }
+
+    // ---- the next unit's inputs: requested now, consumed at the top of the next iteration --------------------------------------
+    int v_next = v, ps_next = ps + 1;
+    Item it_next = it;
+    if (ps_next * kPairs >= it.n_queries) {
+      ps_next = 0;
+      v_next = v + gridDim.x;
+      while (v_next < n_virtual && !item_valid(v_next)) v_next += gridDim.x;
+      if (v_next < n_virtual) it_next = make_item(v_next);
+    }
+    const bool more = v_next < n_virtual;
+    if (more && !(MSDA_WIN_SKIP & 8)) nxt = load_unit(it_next, ps_next);
+
+    if (!BWD && FUSED && SAVED && live && !(MSDA_WIN_SKIP & 16)) {        // hand the backward what was evaluated here (level-major)
+      const long long pl = (((long long)(it.b * M + it.m) * 4 + l_mine) * S + (in.q_lin - it.b * S)) * 4 + (sub & 1) * 2;
+      st4(grad_loc + pl * 2, l4);
+      *reinterpret_cast<float2 *>(grad_attw + pl) = a2;
     }
 
     // one corner: the whole 128-byte row; register s receives 16-byte slot s ^ rot with rot = sub ^ (pair of the wave): the
@@ -219,16 +292,14 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
     // neighbouring queries sample alike: same bank half) -- and the forward's reduce-scatter needs no lane-dependent selects.
     // A corner outside its window reads the zero row here and is fetched from global memory by `row_outside` (rare; the
     // branch is skipped unless some lane of the wave needs it).
-    auto row = [&](const int o, float4 (&v)[8]) {
+    // Half a row (4 x ds_read_b128) at a time: 16 registers of row data in flight instead of 32 -- the prefetched inputs of
+    // the next unit need the room (launch bound: 128 VGPRs at 16 waves per CU).
+    auto half_row = [&](const int o, const int h, float4 (&vv)[4]) {
       const int a = ((o & 1) ? kZeroOff : o) + rot * 16;                  // LDS offsets are multiples of 128
 #pragma unroll
-      for (int s = 0; s < 8; ++s) v[s] = *reinterpret_cast<const float4 *>(wbytes + (a ^ (s * 16)));
+      for (int s = 0; s < 4; ++s) vv[s] = *reinterpret_cast<const float4 *>(wbytes + (a ^ ((4 * h + s) * 16)));
     };
-    auto row_outside = [&](const int o, float4 (&v)[8]) {
-      const float *p = value_bm + (long long)(o >> 4) * tok;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) v[s] = ld4(p + 4 * (s ^ rot));
-    };
+    const bool outside = ((off[0][0] | off[0][1] | off[0][2] | off[0][3] | off[1][0] | off[1][1] | off[1][2] | off[1][3]) & 1) != 0;
 
     if (!BWD) {
       float4 acc[8];
@@ -239,29 +310,43 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float w = cw[k2][c];
-          float4 v[8];
-          row(off[k2][c], v);
 #pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            acc[s].x += w * v[s].x; acc[s].y += w * v[s].y; acc[s].z += w * v[s].z; acc[s].w += w * v[s].w;
-          }
-          if (off[k2][c] & 1) {
-            row_outside(off[k2][c], v);
+          for (int h = 0; h < 2; ++h) {
+            float4 vv[4];
+            if (MSDA_WIN_SKIP & 2) { for (int s = 0; s < 4; ++s) vv[s] = make_float4(w, w, w, w); } else
+            half_row(off[k2][c], h, vv);
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-              acc[s].x += w * v[s].x; acc[s].y += w * v[s].y; acc[s].z += w * v[s].z; acc[s].w += w * v[s].w;
+            for (int s = 0; s < 4; ++s) {
+              acc[4 * h + s].x += w * vv[s].x; acc[4 * h + s].y += w * vv[s].y; acc[4 * h + s].z += w * vv[s].z; acc[4 * h + s].w += w * vv[s].w;
             }
+            // one half row (4 loads) at a time: the accumulation has to be finished HERE (the asm statement consumes it),
+            // before the next loads -- otherwise the compiler loads many rows first and spills
+            asm volatile("" : "+v"(acc[4 * h].x), "+v"(acc[4 * h].y), "+v"(acc[4 * h].z), "+v"(acc[4 * h].w), "+v"(acc[4 * h + 1].x),
+                         "+v"(acc[4 * h + 1].y), "+v"(acc[4 * h + 1].z), "+v"(acc[4 * h + 1].w), "+v"(acc[4 * h + 2].x),
+                         "+v"(acc[4 * h + 2].y), "+v"(acc[4 * h + 2].z), "+v"(acc[4 * h + 2].w), "+v"(acc[4 * h + 3].x),
+                         "+v"(acc[4 * h + 3].y), "+v"(acc[4 * h + 3].z), "+v"(acc[4 * h + 3].w) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
           }
-          // one corner row (8 loads) at a time: the accumulation has to be finished HERE (the asm statements consume it),
-          // before the next row's loads -- otherwise the compiler loads all 8 rows first and spills
-          asm volatile("" : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[0].z), "+v"(acc[0].w), "+v"(acc[1].x), "+v"(acc[1].y),
-                       "+v"(acc[1].z), "+v"(acc[1].w), "+v"(acc[2].x), "+v"(acc[2].y), "+v"(acc[2].z), "+v"(acc[2].w),
-                       "+v"(acc[3].x), "+v"(acc[3].y), "+v"(acc[3].z), "+v"(acc[3].w) : : "memory");
-          asm volatile("" : "+v"(acc[4].x), "+v"(acc[4].y), "+v"(acc[4].z), "+v"(acc[4].w), "+v"(acc[5].x), "+v"(acc[5].y),
-                       "+v"(acc[5].z), "+v"(acc[5].w), "+v"(acc[6].x), "+v"(acc[6].y), "+v"(acc[6].z), "+v"(acc[6].w),
-                       "+v"(acc[7].x), "+v"(acc[7].y), "+v"(acc[7].z), "+v"(acc[7].w) : : "memory");
-          __builtin_amdgcn_sched_barrier(0);
         }
+      // corners outside their window (they read the zero row above): from global memory, one 16-byte slot at a time.  A pass
+      // of its own, so that its addresses and loads do not occupy registers across the row loops; skipped by a wave without
+      // such a corner (the usual case)
+      if (outside) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (off[k2][c] & 1) {
+              const float w = cw[k2][c];
+              const float *p = value_bm + (long long)(off[k2][c] >> 4) * tok;
+#pragma unroll
+              for (int s = 0; s < 8; ++s) {
+                const float4 x = ld4(p + 4 * (s ^ rot));
+                acc[s].x += w * x.x; acc[s].y += w * x.y; acc[s].z += w * x.z; acc[s].w += w * x.w;
+                asm volatile("" : "+v"(acc[s].x), "+v"(acc[s].y), "+v"(acc[s].z), "+v"(acc[s].w) : : "memory");
+              }
+            }
+      }
       // reduce-scatter over the pair's 8 lanes.  acc[s] holds slot s ^ rot, so in the butterfly with partner sub ^ 4 every
       // lane keeps registers 0..3 and hands over 4..7 (the partner's register s ^ 4 is the same slot), then sub ^ 2, sub ^ 1:
       // acc[0] ends as slot rot = channels 4 rot .. 4 rot + 3 summed over the pair -- a permutation of the pair's lanes, still
@@ -282,17 +367,24 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
       }
       const float4 res = make_float4(acc[0].x + dpp_x<0xB1>(acc[1].x), acc[0].y + dpp_x<0xB1>(acc[1].y),
                                      acc[0].z + dpp_x<0xB1>(acc[1].z), acc[0].w + dpp_x<0xB1>(acc[1].w));
-      if (live[ps]) st4(out + (ql64 * M + m) * 32 + rot * 4, res);
+      if (live && (!(MSDA_WIN_SKIP & 4) || res.x == 123.456f)) st4(out + (ql64 * M + it.m) * 32 + rot * 4, res);
     } else {
-      // grad_out of the pair, all 32 channels in every lane (8 x 16-byte broadcast loads from L1), rotated as row()
+      // grad_out of the pair, all 32 channels in every lane, rotated as row(): each lane fetched 16 bytes of the row a unit
+      // ahead; the pair's 8 lanes exchange them through the wave's private 1-KiB LDS block (no workgroup barrier: only this
+      // wave touches it, and its previous reads are ordered before these writes by the LDS queue)
       float4 gq[8];
-      const float *gp = grad_out + (ql64 * M + m) * 32;
+      {
+        char *gow = wbytes + kGoOff + wave * 1024 + (lane >> 3) * 128;
+        *reinterpret_cast<float4 *>(gow + sub * 16) = in.go;              // zeros for a lane that is not live
+        wave_lds_order();
 #pragma unroll
-      for (int s = 0; s < 8; ++s) gq[s] = live[ps] ? ld4(gp + 4 * (s ^ rot)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < 8; ++s) gq[s] = *reinterpret_cast<const float4 *>(gow + ((s ^ rot) * 16));
+        wave_lds_order();
+      }
       if (far_points) {
         // far points (rare): their corner contributions w_corner attn_w grad_out[q, m, :] (cuh:125-152), which the row-tile
         // scatter leaves out, with global atomics
-        float *gv = grad_value + ((long long)b * S * M + m) * 32;
+        float *gv = grad_value + ((long long)it.b * S * M + it.m) * 32;
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
           if (!(far_points & (1 << k2))) continue;
@@ -314,55 +406,74 @@ __global__ __launch_bounds__(kWinThreads, 4) void gather_win_kernel(
           corner_add(tp.y1, tp.x1, tp.b && tp.r, tp.w4);
         }
       }
+      float d[2][4];
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          d[k2][c] = 0.f;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float4 vv[4];
+            half_row(off[k2][c], h, vv);
+            float dx = 0.f, dy = 0.f;                                     // two partial sums: independent FMA chains
+#pragma unroll
+            for (int s = 0; s < 4; s += 2) {
+              const float4 ga = gq[4 * h + s], gb = gq[4 * h + s + 1];
+              dx += ga.x * vv[s].x + ga.y * vv[s].y + ga.z * vv[s].z + ga.w * vv[s].w;
+              dy += gb.x * vv[s + 1].x + gb.y * vv[s + 1].y + gb.z * vv[s + 1].z + gb.w * vv[s + 1].w;
+            }
+            d[k2][c] += dx + dy;                                          // dropped corner: zero row -> 0 (cuh:114-152)
+            // one half row (4 loads) at a time: the dot product has to be finished HERE (the asm consumes it), before the
+            // next loads -- otherwise the compiler loads many rows first and packs the products across corners
+            asm volatile("" : "+v"(d[k2][c]) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      if (outside) {                                                      // see the forward
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (off[k2][c] & 1) {
+              const float *p = value_bm + (long long)(off[k2][c] >> 4) * tok;
+#pragma unroll
+              for (int s = 0; s < 8; ++s) {
+                const float4 x = ld4(p + 4 * (s ^ rot));
+                d[k2][c] += gq[s].x * x.x + gq[s].y * x.y + gq[s].z * x.z + gq[s].w * x.w;
+                asm volatile("" : "+v"(d[k2][c]) : : "memory");
+              }
+            }
+      }
       float4 ol = make_float4(0.f, 0.f, 0.f, 0.f);
       float2 oa = make_float2(0.f, 0.f);
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
-        float d[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          auto dot8 = [&](const float4 (&v)[8]) {
-            float dx = 0.f, dy = 0.f;                                     // two partial sums: independent FMA chains
-#pragma unroll
-            for (int s = 0; s < 8; s += 2) {
-              dx += gq[s].x * v[s].x + gq[s].y * v[s].y + gq[s].z * v[s].z + gq[s].w * v[s].w;
-              dy += gq[s + 1].x * v[s + 1].x + gq[s + 1].y * v[s + 1].y + gq[s + 1].z * v[s + 1].z + gq[s + 1].w * v[s + 1].w;
-            }
-            return dx + dy;
-          };
-          float4 v[8];
-          row(off[k2][c], v);
-          d[c] = dot8(v);                                                 // dropped corner: zero row -> 0 (cuh:114-152)
-          if (off[k2][c] & 1) {
-            row_outside(off[k2][c], v);
-            d[c] += dot8(v);
-          }
-          // one corner row (8 loads) at a time: the dot product has to be finished HERE (the asm consumes it), before the
-          // next row's loads -- otherwise the compiler loads all 8 rows first, packs the products across corners and spills
-          asm volatile("" : "+v"(d[c]) : : "memory");
-          __builtin_amdgcn_sched_barrier(0);
-        }
         // grad_attn_w = sum_i w_i d_i;  grad_x = W wt (hh (d2 - d1) + lh (d4 - d3));  grad_y = H wt (hw (d3 - d1) + lw (d4 - d2))
         const float lh = cw[k2][0], lw = cw[k2][1], hh = 1.f - lh, hw = 1.f - lw;
-        const float ga = hh * (hw * d[0] + lw * d[1]) + lh * (hw * d[2] + lw * d[3]);
-        const float gx = cw[k2][2] * (hh * (d[1] - d[0]) + lh * (d[3] - d[2]));
-        const float gy = cw[k2][3] * (hw * (d[2] - d[0]) + lw * (d[3] - d[1]));
+        const float ga = hh * (hw * d[k2][0] + lw * d[k2][1]) + lh * (hw * d[k2][2] + lw * d[k2][3]);
+        const float gx = cw[k2][2] * (hh * (d[k2][1] - d[k2][0]) + lh * (d[k2][3] - d[k2][2]));
+        const float gy = cw[k2][3] * (hw * (d[k2][2] - d[k2][0]) + lw * (d[k2][3] - d[k2][1]));
         if (k2 == 0) { ol.x = gx; ol.y = gy; oa.x = ga; } else { ol.z = gx; ol.w = gy; oa.y = ga; }
       }
       if (FUSED) {
         // chain rule through the prologue for this lane's own two points: softmax backward and the offset scale
         const float dot = group_sum(oa.x * a2.x + oa.y * a2.y);
         oa = make_float2((oa.x - dot) * a2.x, (oa.y - dot) * a2.y);
-        ol = make_float4(offset_grad<4>(ol.x, ref_scale.x, ref_dim), offset_grad<4>(ol.y, ref_scale.y, ref_dim),
-                         offset_grad<4>(ol.z, ref_scale.x, ref_dim), offset_grad<4>(ol.w, ref_scale.y, ref_dim));
+        ol = make_float4(offset_grad<4>(ol.x, ref_scale.x, 2), offset_grad<4>(ol.y, ref_scale.y, 2),
+                         offset_grad<4>(ol.z, ref_scale.x, 2), offset_grad<4>(ol.w, ref_scale.y, 2));
       }
-      if (live[ps]) {
-        st4(grad_loc + ql64 * loc_rs + m * 32 + sub * 4, ol);
-        *reinterpret_cast<float2 *>(grad_attw + ql64 * aw_rs + m * 16 + sub * 2) = oa;
+      if (live) {
+        st4(grad_loc + ql64 * loc_rs + it.m * 32 + sub * 4, ol);
+        *reinterpret_cast<float2 *>(grad_attw + ql64 * aw_rs + it.m * 16 + sub * 2) = oa;
       }
     }
+
+    if (!more) break;
+    v = v_next;
+    ps = ps_next;
+    it = it_next;
   }
-  if (!waited) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // never leave with LDS-DMA in flight
 }
 
 }  // namespace msda

@@ -15,11 +15,17 @@
 namespace msda {
 
 constexpr int kWinLevels = 4;
-constexpr int kWinThreads = 1024;                    // 16 waves: one workgroup per CU owns the LDS
+constexpr int kWinThreads = 1024;                    // forward: 16 waves, one workgroup per CU owns the LDS
+#ifndef MSDA_WIN_THREADS_BWD
+#define MSDA_WIN_THREADS_BWD 512
+#endif
+constexpr int kWinThreadsBwd = MSDA_WIN_THREADS_BWD;  // backward: 8 waves = 256 VGPRs per lane (grad_out row + prefetch do not fit 128)
 constexpr int kWinPairsPerPass = kWinThreads / 8;    // 128 (query, head) pairs in flight
 constexpr int kWinMaxPasses = 2;                     // queries of a tile <= 256
 constexpr int kWinLdsBudget = 160 * 1024 - 128 - 256;    // - the zero row
 constexpr int kWinMaxRows = kWinLdsBudget / 128;     // value rows (32 floats) the windows of one tile may hold
+constexpr int kWinGoRows = kWinThreadsBwd / 64 * 8;   // backward: one 1-KiB block of grad_out rows per wave (its 8 pairs), at the end
+constexpr int kWinMaxRowsBwd = kWinMaxRows - kWinGoRows;
 
 struct WinGeom {
   int H[kWinLevels], W[kWinLevels], start[kWinLevels];
@@ -79,7 +85,7 @@ inline void fill_window_table(const WinGeom &g, WinTable &t) {
 // Host: choose the tiling.  Cost model (LDS cycles per tile, measured orders of magnitude): ~5 per staged row (L2 -> LDS),
 // ~80 per (query, head) pair slot of a pass (16 points x 4 row reads + records), so halo rows are cheap next to idle pair
 // slots.  Returns false when no tiling fits (tiny or huge levels): the caller keeps the plain gather kernels.
-inline bool choose_window_tiling(const int64_t *shapes_host, const int64_t *lsi_host, int halo, WinGeom &best) {
+inline bool choose_window_tiling(const int64_t *shapes_host, const int64_t *lsi_host, int halo, int max_rows, WinGeom &best) {
   WinGeom g;
   for (int l = 0; l < kWinLevels; ++l) {
     g.H[l] = (int)shapes_host[2 * l];
@@ -111,7 +117,7 @@ inline bool choose_window_tiling(const int64_t *shapes_host, const int64_t *lsi_
             rows += (ys[ty][l].wn * xs[tx][l].wn + 7) / 8 * 8;     // windows start on 8-row (1 KiB) boundaries
             queries += ys[ty][l].qn * xs[tx][l].qn;
           }
-          if (rows > kWinMaxRows || queries > kWinPairsPerPass * kWinMaxPasses) { ok = false; break; }
+          if (rows > max_rows || queries > kWinPairsPerPass * kWinMaxPasses) { ok = false; break; }
           const int passes = (queries + kWinPairsPerPass - 1) / kWinPairsPerPass;
           cost += 5.0 * rows + 80.0 * passes * kWinPairsPerPass + 400.0;      // + fixed per-tile overhead (barriers)
         }

@@ -42,7 +42,7 @@ class _AttnBlock(torch.autograd.Function):
             w_ol, b_ol = torch.cat([wo, wa]), torch.cat([bo, ba])
             proj = F.linear(q, w_ol, b_ol)                                        # [N, S, M*48]
             from .ms_deform_attn_func import SAVE_PROLOGUE
-            ctx.saved_prologue = SAVE_PROLOGUE and MSDA.fused_save_supported(v, shapes, lsi, S)
+            ctx.saved_prologue = SAVE_PROLOGUE and MSDA.fused_save_supported(v, shapes, lsi, S, ref.shape[-1])
             if ctx.saved_prologue:
                 # keep the sampling locations / attention weights the kernel evaluated instead of the raw projection
                 # (same bytes): the backward's two kernels then skip softmax + location arithmetic (ABI v6)

@@ -69,8 +69,8 @@ class MSDeformAttnFusedMergedFunction(Function):
     def forward(ctx, value, spatial_shapes, level_start_index, proj, reference_points):
         ctx.host_geom = MSDA.host_geometry(spatial_shapes, level_start_index)
         needs_grad = value.requires_grad or proj.requires_grad
-        ctx.saved_prologue = SAVE_PROLOGUE and needs_grad and MSDA.fused_save_supported(value, spatial_shapes, level_start_index,
-                                                                                         proj.shape[1])
+        ctx.saved_prologue = SAVE_PROLOGUE and needs_grad and MSDA.fused_save_supported(
+            value, spatial_shapes, level_start_index, proj.shape[1], reference_points.shape[-1])
         if ctx.saved_prologue:
             # self-attention shape in training: keep the sampling locations / attention weights the kernel evaluated
             # (250 MB per encoder layer at B = 16) so that neither backward kernel re-evaluates softmax + location math

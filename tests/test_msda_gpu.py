@@ -518,6 +518,49 @@ def test_fused_prologue_matches_the_unfused_operator(ref_dim):
     assert _lib.load().msda_fused_forward_f32(1, 1, 1, 1, 1, 1, 3, 1, 1, 1, 1, 32, 4, 1, 4, 1, 1, None) == -3
 
 
+@pytest.mark.parametrize("B,M,ref_dim", [(3, 5, 2), (1, 3, 2), (2, 8, 6)])
+def test_fused_self_attention_shape_odd_planes_and_6d_reference_points(B, M, ref_dim):
+    """Lq == S (the window / row-tile kernels' shape) with (batch x head) counts that are not multiples of 8 -- the persistent
+    workgroups walk a padded item list -- and with 6-d reference points, which the window kernels do not evaluate: the
+    library must fall back to the record kernels, and msda_fused_save_supported() must say so.  Against the unfused
+    operator fed with the PyTorch prologue."""
+    from monosowa_amd.ms_deform_attn_func import MSDeformAttnFunction, MSDeformAttnFusedFunction
+    MSDA = _msda()
+    torch.manual_seed(B * 100 + M)
+    levels = [(24, 40), (12, 20), (6, 10), (3, 5)]
+    D, L, P = 32, 4, 4
+    shapes = torch.tensor(levels, dtype=torch.long, device="cuda")
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    MSDA.attach_host_geometry(shapes, lsi, levels, lsi.tolist())
+    S = Lq = int(shapes.prod(1).sum())
+    centres = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, device="cuda") + 0.5) / h, (torch.arange(w, device="cuda") + 0.5) / w,
+                                                    indexing="ij")[::-1], -1).reshape(-1, 2) for h, w in levels])
+    value = torch.randn(B, S, M, D, device="cuda", requires_grad=True)
+    offsets = (torch.randn(B, Lq, M, L, P, 2, device="cuda") * 2.5).requires_grad_(True)
+    logits = torch.randn(B, Lq, M, L * P, device="cuda", requires_grad=True)
+    ref = centres[None, :, None, :].expand(B, Lq, L, 2)
+    if ref_dim == 6:
+        ref = torch.cat([ref, torch.rand(B, Lq, L, 4, device="cuda") * 0.2], -1)
+    ref = ref.contiguous()
+    assert MSDA.fused_save_supported(value, shapes, lsi, Lq, ref_dim) == (ref_dim == 2 and M * L * 8 <= 1024)
+    go = torch.randn(B, Lq, M * D, device="cuda")
+    out_f = MSDeformAttnFusedFunction.apply(value, shapes, lsi, offsets, logits, ref)
+    out_f.backward(go)
+    got = [out_f.detach().clone(), value.grad.clone(), offsets.grad.clone(), logits.grad.clone()]
+    value.grad = offsets.grad = logits.grad = None
+    aw = torch.softmax(logits, -1).view(B, Lq, M, L, P)
+    if ref_dim == 2:
+        norm = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+        loc = ref[:, :, None, :, None, :] + offsets / norm[None, None, None, :, None, :]
+    else:
+        loc = ref[:, :, None, :, None, :2] + offsets / P * (ref[:, :, None, :, None, 2::2] + ref[:, :, None, :, None, 3::2]) * 0.5
+    out_u = MSDeformAttnFunction.apply(value, shapes, lsi, loc.contiguous(), aw.contiguous(), 64)
+    out_u.backward(go)
+    want = [out_u.detach(), value.grad, offsets.grad, logits.grad]
+    for name, a, b in zip(("out", "grad_value", "grad_offsets", "grad_logits"), got, want):
+        assert (a - b).abs().max() <= 2e-5 * b.abs().max(), (name, ((a - b).abs().max() / b.abs().max()).item())
+
+
 def test_train_val_cli_runs_an_epoch_and_writes_kitti_results(tmp_path):
     """tools/train_val.py (the reference's CLI): one tiny epoch on synthetic data through Trainer -> checkpoint ->
     Tester.inference -> KITTI result files, then `-e` evaluation-only from the saved checkpoint."""

@@ -1,0 +1,12 @@
+#!/bin/bash
+# usage: tools/debug/prof_fused.sh <tag> [env assignments...]  -- per-kernel times of the fused operator pair (encoder shape)
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp
+for kv in "$@"; do export "$kv"; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pf_$tag -- python3 $GRAFT_REPO_ROOT/tools/msda_fused_bench.py --kinds enc --iters 30 --warmup 5 > $GRAFT_REPO_ROOT/gpurun_out/pf_$tag.log 2>&1
+python3 - <<PY
+import csv, glob
+f = glob.glob("$GRAFT_REPO_ROOT/gpurun_out/pf_$tag/*/*kernel_stats.csv")[0]
+for r in list(csv.DictReader(open(f)))[:8]:
+    if "msda" in r["Name"]: print("$tag %-60s calls %4s avg %9.1f us" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3))
+PY

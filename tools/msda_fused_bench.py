@@ -90,7 +90,7 @@ def main():
         value, shapes, lsi, proj, ref, go = make(a.batch, kind, a.offsets, dev)
         B, S, M, D = value.shape
         Lq = proj.shape[1]
-        if MSDA.fused_save_supported(value, shapes, lsi, Lq) and not a.recompute:
+        if MSDA.fused_save_supported(value, shapes, lsi, Lq, ref.shape[-1]) and not a.recompute:
             # what the train step runs at the self-attention shape (ABI v6): the forward stores locations / weights
             # level-major, the backward reads them
             _, loc, attw = MSDA.ms_deform_attn_fused_forward_merged_save(value, shapes, lsi, proj, ref)
