@@ -227,3 +227,5 @@ int mono_box3d_overlap_f32(const float *boxes, const float *query, float *out, l
 }
 
 }  // extern "C"
+
+#include "kitti_ap.h"      // host-side AP accumulation of the same library (mono_kitti_tp_scores_f64, mono_kitti_pr_f64)

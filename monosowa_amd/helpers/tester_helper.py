@@ -127,5 +127,26 @@ class Tester(object):
         dataset = self.dataloader.dataset
         if hasattr(dataset, "eval"):
             return dataset.eval(results_dir=results_dir, logger=self.logger)
-        self.logger.info("dataset has no KITTI AP evaluator (numba kitti_eval_python is out of scope); returning 0")
+        if getattr(dataset, "label_dir", None) and hasattr(dataset, "idx_list"):
+            return evaluate_kitti_results(results_dir, dataset.label_dir, [int(i) for i in dataset.idx_list],
+                                          getattr(dataset, "writelist", ["Car"]), self.logger)
+        self.logger.info("dataset has no ground-truth label directory: nothing to evaluate; returning 0")
         return 0.0
+
+
+def evaluate_kitti_results(results_dir, label_dir, img_ids, categories, logger):
+    """What KITTI_Dataset.eval does with the written results (kitti_dataset.py:144-159): the official report per category
+    through monosowa_amd.kitti_eval (HIP overlap kernels + native matching); returns Car-moderate 3D AP_R40."""
+    from .. import kitti_eval as kitti
+    logger.info("==> Loading detections and GTs...")
+    dt_annos = kitti.get_label_annos(results_dir, img_ids)
+    gt_annos = kitti.get_label_annos(label_dir, img_ids)
+    test_id = {"Car": 0, "Pedestrian": 1, "Cyclist": 2}
+    logger.info("==> Evaluating (official) ...")
+    car_moderate = 0
+    for category in categories:
+        text, _, ap3d_r40 = kitti.get_official_eval_result(gt_annos, dt_annos, test_id[category])
+        if category == "Car":
+            car_moderate = ap3d_r40
+        logger.info(text)
+    return car_moderate

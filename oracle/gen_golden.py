@@ -3,7 +3,7 @@
 Run in the build container only (``/root/reference`` does not exist on the GPU box):
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [msda] [module] [transformer] [depth] [misc]
-                                                       [adamw] [decode] [criterion] [heads]
+                                                       [adamw] [decode] [criterion] [heads] [kitti_eval]
 
 The reference tree is imported read-only, unmodified.  Third-party symbols that are absent
 from this image are shimmed (never reference code): the unbuilt CUDA extension module
@@ -538,6 +538,153 @@ def gen_heads():
                 arrays["%s_aux%d_%s" % (mode, i, k)] = v.float()
     _save("monodetr_heads", calibs=calibs.float(), img_sizes=img_sizes.float(), group_num=G, manifest=manifest(model), **arrays)
 
+
+
+# ----------------------------------------------------------------------------- KITTI evaluation (kitti_eval_python)
+def _numba_shim():
+    """numba is absent from this image.  The reference's evaluation code is plain Python under its decorators, so an
+    identity ``jit`` runs it unchanged (slowly); ``cuda.local.array`` becomes a float32 numpy array, which makes the
+    rotated-IoU DEVICE FUNCTIONS (rotate_iou.py:17-259) callable pair by pair in float32 numpy arithmetic.  The CUDA
+    kernel / launch code of that file is never called."""
+    if "numba" in sys.modules:
+        return
+    def deco(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+    nb = types.ModuleType("numba")
+    nb.jit = deco
+    nb.float32 = np.float32
+    cuda = types.ModuleType("numba.cuda")
+    cuda.jit = deco
+    cuda.local = types.SimpleNamespace(array=lambda shape, dtype: np.zeros(shape, dtype=np.float32))
+    nb.cuda = cuda
+    sys.modules.update({"numba": nb, "numba.cuda": cuda})
+
+
+def ref_kitti_eval():
+    _numba_shim()
+    import importlib
+    if "kepkg" not in sys.modules:
+        pkg = types.ModuleType("kepkg")
+        pkg.__path__ = [REF + "/lib/datasets/kitti/kitti_eval_python"]
+        sys.modules["kepkg"] = pkg
+    ev = importlib.import_module("kepkg.eval")
+    riou = importlib.import_module("kepkg.rotate_iou")
+
+    def all_pairs(boxes, query_boxes, criterion=-1, device_id=0):
+        """rotate_iou_gpu_eval's contract (rotate_iou.py:295-330) by calling the reference DEVICE function per pair."""
+        b = np.ascontiguousarray(boxes, dtype=np.float32)
+        q = np.ascontiguousarray(query_boxes, dtype=np.float32)
+        out = np.zeros((b.shape[0], q.shape[0]), dtype=np.float32)
+        for n in range(b.shape[0]):
+            for k in range(q.shape[0]):
+                out[n, k] = riou.devRotateIoUEval(q[k].copy(), b[n].copy(), criterion)    # kernel argument order: rotate_iou.py:291-293
+        return out.astype(boxes.dtype)
+    ev.rotate_iou_gpu_eval = all_pairs
+    return ev, riou, all_pairs
+
+
+def _synthetic_annos(rng, n_images):
+    names_gt = ["Car", "Car", "Car", "Pedestrian", "Cyclist", "Van", "DontCare", "Person_sitting", "Truck"]
+    gts, dts = [], []
+    for img in range(n_images):
+        n = int(rng.integers(3, 9))
+        name = [names_gt[int(rng.integers(0, len(names_gt)))] for _ in range(n)]
+        z = rng.uniform(6, 45, n)
+        x = rng.uniform(-12, 12, n)
+        y = rng.uniform(1.2, 2.0, n)
+        dims = np.stack([rng.normal(3.9, 0.4, n), rng.normal(1.55, 0.1, n), rng.normal(1.65, 0.1, n)], 1)   # l, h, w (camera order)
+        small = np.array([nm in ("Pedestrian", "Person_sitting", "Cyclist") for nm in name])
+        dims[small] = np.stack([rng.normal(0.9, 0.2, small.sum()), rng.normal(1.75, 0.1, small.sum()), rng.normal(0.65, 0.1, small.sum())], 1)
+        ry = rng.uniform(-np.pi, np.pi, n)
+        hpx = 721.5 * dims[:, 1] / z
+        wpx = 721.5 * np.maximum(dims[:, 0], dims[:, 2]) / z * rng.uniform(0.5, 1.0, n)
+        cu, cv = 609.5 + 721.5 * x / z, 172.8 + 721.5 * (y - dims[:, 1] / 2) / z
+        bbox = np.stack([cu - wpx / 2, cv - hpx / 2, cu + wpx / 2, cv + hpx / 2], 1)
+        gt = {"name": np.array(name), "truncated": np.round(rng.choice([0.0, 0.0, 0.0, 0.1, 0.2, 0.4, 0.6], n), 2),
+              "occluded": rng.choice([0, 0, 0, 1, 2, 3], n), "alpha": ry - np.arctan2(x, z), "bbox": bbox, "dimensions": dims,
+              "location": np.stack([x, y, z], 1), "rotation_y": ry, "score": np.zeros(n)}
+        gts.append(gt)
+        # detections: noisy copies of most real objects + a few false positives, classes mostly right
+        keep = [i for i in range(n) if name[i] != "DontCare" and rng.random() < 0.85]
+        m = len(keep)
+        fp = int(rng.integers(0, 3))
+        d_name = [name[i] if rng.random() < 0.9 else "Car" for i in keep] + ["Car", "Pedestrian", "Cyclist"][:fp]
+        noise = lambda s, k: rng.normal(0, s, k)
+        d_loc = np.concatenate([gt["location"][keep] + np.stack([noise(0.05, m), noise(0.02, m), noise(0.12, m)], 1) * rng.choice([1.0, 1.0, 4.0], (m, 1)),
+                                np.stack([rng.uniform(-10, 10, fp), rng.uniform(1.3, 1.9, fp), rng.uniform(8, 50, fp)], 1)])
+        d_dims = np.concatenate([dims[keep] * (1 + 0.02 * rng.standard_normal((m, 3))), np.tile([[3.8, 1.5, 1.6]], (fp, 1))])
+        d_ry = np.concatenate([ry[keep] + noise(0.04, m), rng.uniform(-np.pi, np.pi, fp)])
+        d_bbox = np.concatenate([bbox[keep] + rng.normal(0, 1.5, (m, 4)),
+                                 np.stack([rng.uniform(100, 900, fp), rng.uniform(120, 200, fp), rng.uniform(100, 900, fp) + 60,
+                                           rng.uniform(120, 200, fp) + 45], 1).reshape(fp, 4)])
+        if fp:
+            d_bbox[m:, 2] = d_bbox[m:, 0] + rng.uniform(30, 90, fp)
+            d_bbox[m:, 3] = d_bbox[m:, 1] + rng.uniform(20, 70, fp)
+        k = m + fp
+        dts.append({"name": np.array(d_name) if k else np.zeros(0, dtype="<U3"), "truncated": np.zeros(k), "occluded": np.zeros(k, dtype=np.int64),
+                    "alpha": d_ry - np.arctan2(d_loc[:, 0], d_loc[:, 2]), "bbox": d_bbox.reshape(k, 4), "dimensions": d_dims.reshape(k, 3),
+                    "location": d_loc.reshape(k, 3), "rotation_y": d_ry, "score": np.round(rng.uniform(0.05, 0.99, k), 4)})
+    return gts, dts
+
+
+def _pack_annos(prefix, annos, out):
+    out[prefix + "_count"] = np.array([len(a["name"]) for a in annos])
+    for key in ("name", "truncated", "occluded", "alpha", "bbox", "dimensions", "location", "rotation_y", "score"):
+        parts = [np.asarray(a[key]) for a in annos if len(a["name"])]
+        out[prefix + "_" + key] = np.concatenate(parts) if parts else np.zeros(0)
+    out[prefix + "_name"] = out[prefix + "_name"].astype("U16")
+
+
+def gen_kitti_eval():
+    """(1) the reference's rotated-IoU device function on random / degenerate box pairs, all four criteria;
+    (2) the whole AP pipeline (clean_data, calculate_iou_partly, compute_statistics_jit, get_thresholds,
+    fused_compute_statistics, eval_class, do_eval, get_official_eval_result; eval.py:10-80, :160-260, :234-760) on a seeded
+    synthetic set of 24 images, with the overlap matrices the reference used."""
+    ev, riou, all_pairs = ref_kitti_eval()
+    rng = np.random.default_rng(20241)
+    n, k = 36, 44
+    boxes = np.stack([rng.uniform(-6, 6, n), rng.uniform(10, 22, n), rng.uniform(1.2, 4.5, n), rng.uniform(1.2, 4.5, n), rng.uniform(-3.2, 3.2, n)], 1)
+    qboxes = np.stack([rng.uniform(-6, 6, k), rng.uniform(10, 22, k), rng.uniform(1.2, 4.5, k), rng.uniform(1.2, 4.5, k), rng.uniform(-3.2, 3.2, k)], 1)
+    qboxes[:8] = boxes[:8]                                     # identical boxes
+    qboxes[8:14, :2] = boxes[8:14, :2] + 0.05                  # nearly coincident centres
+    qboxes[14:18, 4] = boxes[14:18, 4] + np.pi / 2             # same centre-ish, rotated a quarter turn
+    qboxes[14:18, :2] = boxes[14:18, :2]
+    qboxes[18:20] = [[100, 100, 2, 2, 0.3], [-50, 3, 1, 4, 1.0]]        # far away: zero overlap
+    boxes, qboxes = boxes.astype(np.float32), qboxes.astype(np.float32)
+    out = {"boxes": boxes, "qboxes": qboxes}
+    for crit in (-1, 0, 1, 2):
+        out["iou_crit%d" % crit] = all_pairs(boxes, qboxes, crit)
+    _save("kitti_rotate_iou", **out)
+
+    gts, dts = _synthetic_annos(rng, 24)
+    out = {}
+    _pack_annos("gt", gts, out)
+    _pack_annos("dt", dts, out)
+    difficultys = [0, 1, 2]
+    min_overlaps = np.stack([np.array([[0.7, 0.5, 0.5]] * 3), np.array([[0.5, 0.5, 0.5], [0.5, 0.25, 0.25], [0.5, 0.25, 0.25]])], 0)
+    for metric in (0, 1, 2):
+        ret = ev.eval_class(gts, dts, [0, 1, 2], difficultys, metric, min_overlaps, compute_aos=(metric == 0))
+        out["m%d_precision" % metric], out["m%d_recall" % metric] = ret["precision"], ret["recall"]
+        if metric == 0:
+            out["m0_orientation"] = ret["orientation"]
+        overlaps = ev.calculate_iou_partly(dts, gts, metric, 50)[0]           # per image [n_dt, n_gt], the order eval_class uses
+        out["m%d_overlaps" % metric] = np.concatenate([o.reshape(-1) for o in overlaps]) if overlaps else np.zeros(0)
+    out["min_overlaps"] = min_overlaps
+    lines = []
+    for cls in (0, 1, 2):
+        result, ret_dict, car_mod = ev.get_official_eval_result(gts, dts, cls)
+        lines.append(result)
+        for key, val in ret_dict.items():
+            out["official_%d__%s" % (cls, key)] = np.float64(val)
+        out["official_%d_return" % cls] = np.float64(car_mod)
+    out["official_text"] = np.array("\n=====\n".join(lines))
+    # the pieces, on their own
+    sc = np.round(rng.uniform(0, 1, 57), 3)
+    out["thr_scores"], out["thr_num_gt"] = sc, np.int64(71)
+    out["thr_out"] = np.array(ev.get_thresholds(sc.copy(), 71))
+    _save("kitti_ap", **out)
 
 
 def importlib_misc():

@@ -41,7 +41,7 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack="--stack" in sys.argv) as prof:
         step()
         torch.cuda.synchronize()
     ev = prof.events()
@@ -64,6 +64,20 @@ def main():
     print("\n-- the same by input shape")
     for e in rows[:120]:
         print("%-34s %4d x %8.1f us  %s" % (e.key[:34], e.count, e.self_device_time_total, str(e.input_shapes)[:140]))
+    if "--stack" in sys.argv:
+        stacks(prof)
+
+
+
+
+def stacks(prof, names=("aten::copy_", "aten::fill_", "aten::add_", "aten::add", "aten::mul", "aten::sum", "aten::cat", "aten::div", "aten::sub")):
+    """--stack: the innermost frames of this repo behind the small glue ops, by launch count."""
+    rows = [e for e in prof.key_averages(group_by_stack_n=12) if e.key in names and e.self_device_time_total > 0]
+    rows.sort(key=lambda e: -e.count)
+    print("\n-- glue ops by call site")
+    for e in rows[:60]:
+        mine = [f for f in e.stack if "monosowa_amd" in f or "bench" in f or "tools" in f][:2]
+        print("%-14s %4d x %8.1f us  %s" % (e.key, e.count, e.self_device_time_total, " <- ".join(m.strip()[-90:] for m in mine)))
 
 
 if __name__ == "__main__":
