@@ -1,8 +1,10 @@
 """CPU checker for the rotated-box overlap kernels (test infrastructure only; never imported by the product).
 
-The reference's implementation is a numba-CUDA kernel (lib/datasets/kitti/kitti_eval_python/rotate_iou.py:263-330) that
-cannot run here (numba and CUDA are absent), so PARITY IS UNPINNED against reference outputs.  This oracle computes the
-same quantity -- area of the intersection of two rotated rectangles, combined by `criterion` exactly as
+The reference's implementation is a numba-CUDA kernel (lib/datasets/kitti/kitti_eval_python/rotate_iou.py:263-330) whose
+launch code cannot run here (numba and CUDA are absent).  PINNED since round 2: its DEVICE function (rotate_iou.py:17-259)
+runs pair by pair as plain Python on float32 numpy arrays (oracle/gen_golden.py kitti_eval -> tests/golden/
+kitti_rotate_iou.npz), and this oracle agrees with it to 3e-6 on every non-degenerate pair (tests/test_kitti_ap.py).
+This oracle computes the same quantity -- area of the intersection of two rotated rectangles, combined by `criterion` exactly as
 rotate_iou.py:249-260 and eval.py:197-230 do -- with an independent exact method in float64: Sutherland-Hodgman clipping
 of one convex quadrilateral by the other and the shoelace formula.  Box convention as in the reference
 (rotate_iou.py:217-238): (cx, cy, w, h, angle), corners (-w/2,-h/2), (-w/2,h/2), (w/2,h/2), (w/2,-h/2) rotated by
