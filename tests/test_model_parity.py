@@ -99,7 +99,7 @@ def _build_transformer(G):
     return t
 
 
-def _transformer_case(g, device, rel, dtype=torch.float64, check_grad=True):
+def _transformer_case(g, device, rel, dtype=torch.float64, check_grad=True, grad_rel=None):
     """The fixture is a float64 run of the reference (inputs are f32-representable, results stored as
     f32).  Gradients through MSDA contain grad_loc, which jumps at pixel borders, so the gradient check
     is only meaningful in float64 (an f32 run of the reference itself is 2e-3 away from its f64 run)."""
@@ -125,7 +125,7 @@ def _transformer_case(g, device, rel, dtype=torch.float64, check_grad=True):
         s0 = srcs[0].clone().requires_grad_(True)
         hs = t([s0] + srcs[1:], masks, pos, qe, dpe, dpe)[0]
         (hs * torch.linspace(-1, 1, hs.numel(), device=device, dtype=dtype).view_as(hs)).sum().backward()
-        _assert_close(s0.grad, g["grad_src0"], rel, "d loss / d src0")
+        _assert_close(s0.grad, g["grad_src0"], grad_rel or rel, "d loss / d src0")
 
 
 def test_transformer_cpu(golden_dir, cpu_msda):
@@ -136,7 +136,10 @@ def test_transformer_cpu(golden_dir, cpu_msda):
 def test_transformer_gpu(golden_dir):
     g = _load(golden_dir, "transformer_small")
     _transformer_case(g, "cuda", 1e-6, torch.float64)                      # f64 HIP kernels, fwd + grad
-    _transformer_case(g, "cuda", 2e-4, torch.float32, check_grad=False)    # f32 d32 fast path, forward
+    # f32 d32 fast path (fused prologue, window / record kernels, HIP attention): forward to 2e-4; the gradient directly against
+    # the reference's float64 gradient -- 5e-3, because grad_loc jumps at pixel borders and an f32 run of the REFERENCE is
+    # itself 2e-3 away from its f64 run (the tight f32 gradient bounds are the kernel-level oracle tests)
+    _transformer_case(g, "cuda", 2e-4, torch.float32, check_grad=True, grad_rel=5e-3)
 
 
 def test_transformer_rejects_unshipped_variants():
