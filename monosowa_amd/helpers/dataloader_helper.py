@@ -1,6 +1,6 @@
 """``build_dataloader(cfg['dataset']) -> (train_loader, test_loader)``
 (reference: lib/helpers/dataloader_helper.py:12-36: batch_size from the config, 4 workers, shuffle on
-train).  ``dataset.type: synthetic`` serves seeded KITTI-shaped samples; under torch.distributed each
+train).  ``dataset.type: KITTI`` reads a KITTI-format directory (monosowa_amd/kitti_dataset.py), ``synthetic`` serves seeded KITTI-shaped samples; under torch.distributed each
 rank gets a disjoint shard (DistributedSampler), which the reference (single process) never needed."""
 import numpy as np
 import torch
@@ -18,9 +18,10 @@ def my_worker_init_fn(worker_id):
 def build_dataset(cfg, split):
     if cfg["type"] == "synthetic":
         return SyntheticKITTI(split=split, cfg=cfg)
-    raise NotImplementedError(
-        "dataset.type %r: the KITTI file loader (lib/datasets/kitti/*) is outside the MI355X hot path; "
-        "any Dataset yielding the (img, P2, targets, info) contract of monosowa_amd.synthetic works" % cfg["type"])
+    if cfg["type"] == "KITTI":
+        from ..kitti_dataset import KITTI_Dataset
+        return KITTI_Dataset(split=split, cfg=cfg)
+    raise NotImplementedError("%s dataset is not supported" % cfg["type"])
 
 
 def build_dataloader(cfg, workers=4):

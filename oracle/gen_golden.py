@@ -3,7 +3,7 @@
 Run in the build container only (``/root/reference`` does not exist on the GPU box):
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [msda] [module] [transformer] [depth] [misc]
-                                                       [adamw] [decode] [criterion] [heads] [kitti_eval]
+                                                       [adamw] [decode] [criterion] [heads] [kitti_eval] [kitti_dataset]
 
 The reference tree is imported read-only, unmodified.  Third-party symbols that are absent
 from this image are shimmed (never reference code): the unbuilt CUDA extension module
@@ -685,6 +685,116 @@ def gen_kitti_eval():
     out["thr_scores"], out["thr_num_gt"] = sc, np.int64(71)
     out["thr_out"] = np.array(ev.get_thresholds(sc.copy(), 71))
     _save("kitti_ap", **out)
+
+
+# ----------------------------------------------------------------------------- KITTI file dataset (kitti_dataset.py)
+def _dataset_shims():
+    """Third-party modules lib/datasets/kitti/kitti_dataset.py imports at module level and that are absent here: cv2, dill,
+    zstd, point_cloud_utils, open3d, skimage, torchvision.transforms, numba.  Only ONE of their functions is reached on the
+    fixtured path: cv2.getAffineTransform (kitti_utils.py:374-379), shimmed by its definition -- the 2 x 3 matrix mapping
+    three points onto three points, solved in float64."""
+    _more_shims()
+    _numba_shim()
+    for name in ("dill", "zstd", "point_cloud_utils", "skimage"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["skimage"].io = types.ModuleType("skimage.io")
+    sys.modules.setdefault("skimage.io", sys.modules["skimage"].io)
+    tv = sys.modules["torchvision"]
+    if not hasattr(tv, "transforms"):
+        tv.transforms = types.ModuleType("torchvision.transforms")
+        sys.modules["torchvision.transforms"] = tv.transforms
+
+    def get_affine_transform(src, dst):
+        a = np.hstack([np.asarray(src, dtype=np.float64), np.ones((3, 1))])
+        return np.linalg.solve(a, np.asarray(dst, dtype=np.float64)).T
+    sys.modules["cv2"].getAffineTransform = get_affine_transform
+
+
+def _synthetic_kitti_files(rng, ids):
+    """-> {relative path: bytes} of a small KITTI-format directory: smooth synthetic PNGs of the usual odd sizes, calib files
+    with a P2 line, 15-field labels around the dataset's filter thresholds."""
+    import io
+    from PIL import Image
+    files = {"ImageSets/train.txt": "\n".join("%06d" % i for i in ids).encode(), "ImageSets/val.txt": "\n".join("%06d" % i for i in ids).encode()}
+    for k, idx in enumerate(ids):
+        W, H = [(1242, 375), (1224, 370), (1238, 374), (1241, 376)][k % 4]
+        yy, xx = np.mgrid[0:H, 0:W]
+        img = np.stack([(xx * 255 // W), (yy * 255 // H), ((xx // 40 + yy // 40) % 2) * 200 + k * 10], -1).astype(np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, format="PNG")
+        files["training/image_2/%06d.png" % idx] = buf.getvalue()
+        fu = [721.5377, 707.0493, 718.856, 552.554][k % 4]
+        P2 = [fu, 0.0, 609.5593 + k, 44.85728, 0.0, fu, 172.854 - k, 0.2163791, 0.0, 0.0, 1.0, 0.002745884]
+        eye = [0.9999239, 0.00983776, -0.007445048, -0.009869795, 0.9999421, -0.004278459, 0.007402527, 0.004351614, 0.9999631]
+        tr = [0.007533745, -0.9999714, -0.000616602, -0.004069766, 0.01480249, 0.0007280733, -0.9998902, -0.07631618, 0.9998621, 0.00752379, 0.01480755, -0.2717806]
+        fmt = lambda name, v: name + ": " + " ".join("%.12e" % x for x in v)
+        files["training/calib/%06d.txt" % idx] = "\n".join([fmt("P0", P2), fmt("P1", P2), fmt("P2", P2), fmt("P3", P2), fmt("R0_rect", eye),
+                                                            fmt("Tr_velo_to_cam", tr), fmt("Tr_imu_to_velo", tr)]).encode() + b"\n"
+        lines = []
+        for _ in range(int(rng.integers(3, 9))):
+            cls = ["Car", "Car", "Car", "Pedestrian", "Cyclist", "Van", "DontCare"][int(rng.integers(0, 7))]
+            z = float(rng.uniform(1.5, 75))
+            x, y = float(rng.uniform(-0.45, 0.45) * z), float(rng.uniform(1.4, 1.9))
+            h, w, l = float(rng.normal(1.55, 0.1)), float(rng.normal(1.63, 0.1)), float(rng.normal(3.9, 0.4))
+            ry = float(rng.uniform(-np.pi, np.pi))
+            cu, cv = 609.5 + fu * x / z, 172.8 + fu * (y - h / 2) / z
+            hw, hh = fu * l / z * float(rng.uniform(0.3, 0.55)), fu * h / z / 2
+            off = float(rng.uniform(-0.6, 0.6)) * hw                       # some 3D centres fall outside their 2D box
+            box = [max(cu - hw + off, 0.0), max(cv - hh, 0.0), min(cu + hw + off, W - 1.0), min(cv + hh, H - 1.0)]
+            trunc = [0.0, 0.0, 0.2, 0.45, 0.7][int(rng.integers(0, 5))]
+            occ = int(rng.integers(0, 4))
+            if cls == "DontCare":
+                lines.append("DontCare -1 -1 -10 %.2f %.2f %.2f %.2f -1 -1 -1 -1000 -1000 -1000 -10" % tuple(box))
+            else:
+                lines.append("%s %.2f %d %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f" %
+                             (cls, trunc, occ, ry - np.arctan2(x, z), box[0], box[1], box[2], box[3], h, w, l, x, y, z, ry))
+        files["training/label_2/%06d.txt" % idx] = ("\n".join(lines) + "\n").encode()
+    return files
+
+
+def gen_kitti_dataset():
+    """The reference KITTI_Dataset (kitti_dataset.py:27-489, with Object3d / Calibration / affine helpers of kitti_utils.py) on a
+    small synthetic KITTI directory whose FILES are part of the fixture: val split (no augmentation) and train split with
+    flip + crop augmentation under fixed numpy seeds, canonical object space on."""
+    import importlib
+    import tempfile
+    _dataset_shims()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    mod = importlib.import_module("lib.datasets.kitti.kitti_dataset")
+    rng = np.random.default_rng(777)
+    ids = [3, 7, 12, 25, 31, 40]
+    files = _synthetic_kitti_files(rng, ids)
+    out = {"file_names": np.array(sorted(files)), "ids": np.array(ids)}
+    for i, name in enumerate(sorted(files)):
+        out["file_%03d" % i] = np.frombuffer(files[name], dtype=np.uint8)
+    cfg = {"root_dir": None, "writelist": ["Car", "Pedestrian"], "use_canonical_module": True, "canonical_focal_length": 500.0,
+           "aug_crop": True, "random_flip": 0.5, "random_crop": 0.5, "scale": 0.05, "shift": 0.05, "depth_scale": "normal",
+           "meanshape": False, "clip_2d": False}
+    out["cfg_json"] = np.array(__import__("json").dumps({k: v for k, v in cfg.items() if k != "root_dir"}))
+    with tempfile.TemporaryDirectory() as root:
+        for name, blob in files.items():
+            os.makedirs(os.path.dirname(os.path.join(root, name)), exist_ok=True)
+            with open(os.path.join(root, name), "wb") as f:
+                f.write(blob)
+        cfg["root_dir"] = root
+        for split, seeds in (("val", [0]), ("train", [11, 12, 13])):
+            ds = mod.KITTI_Dataset(split, dict(cfg))
+            for seed in seeds:
+                for item in range(len(ds)):
+                    np.random.seed(seed * 100 + item)
+                    img, P2, targets, info = ds[item]
+                    key = "%s_s%d_i%d__" % (split, seed, item)
+                    out[key + "img_sub"] = np.ascontiguousarray(img[:, ::8, ::8])
+                    out[key + "img_sum"] = np.float64(img.astype(np.float64).sum())
+                    out[key + "P2"] = np.asarray(P2)
+                    for k, v in targets.items():
+                        out[key + "t_" + k] = np.asarray(v)
+                    for k in ("img_id", "img_size", "bbox_downsample_ratio", "canonical_scale", "height_crop", "affine", "affine_inv",
+                              "scale_depth", "flip"):
+                        out[key + "info_" + k] = np.asarray(info[k])
+    _save("kitti_dataset", **out)
 
 
 def importlib_misc():
