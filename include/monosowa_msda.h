@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 6
+#define MSDA_ABI_VERSION 7
 
 #define MSDA_E_NULLPTR (-1)   /* a required pointer is NULL                        */
 #define MSDA_E_SHAPE (-2)     /* a dimension is <= 0 or exceeds the indexing range */
@@ -162,6 +162,28 @@ int msda_fused_backward_saved_f32(const float *value, const int64_t *shapes, con
                                   int B, int S, int M, int D, int L, int Lq, int P, int offsets_row_stride,
                                   int logits_row_stride, const int64_t *shapes_host, const int64_t *level_start_host,
                                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* ABI v7: the fused operator on a value VIEW -- the two remaining steps of the module around the operator
+ * (ops/modules/ms_deform_attn.py:138-141) without passes of their own:
+ *   value_token_stride  floats between consecutive tokens of `value` (M*32 when dense; the batch stride is S * value_token_stride).
+ *                       768 when `value` is one 256-column block of a [B, S, 768] projection: the three decoder layers'
+ *                       value_proj(memory) as ONE GEMM, each layer reading its block in place.
+ *   value_mask          optional [B, S] bytes, non-zero = padded token: its value row counts as zero
+ *                       (`value.masked_fill(input_padding_mask[..., None], 0)`, :139-140) and its grad_value row comes out zero.
+ * Everything else as in v5 / v6: loc_save / attn_save both NULL or both given (v6 forward); `saved` != 0: offsets_or_loc /
+ * logits_or_attn are the tensors the v6 forward stored.  grad_value is always dense [B, S, M, D].  Requirements: float,
+ * D = 32, L = P = 4, host pyramid; MSDA_E_SHAPE for a stride < M*32 or not a multiple of 4. */
+int msda_fused_forward_view_f32(const float *value, int value_token_stride, const unsigned char *value_mask,
+                                const int64_t *shapes, const int64_t *level_start, const float *offsets, const float *logits,
+                                const float *ref, int ref_dim, float *out, float *loc_save, float *attn_save, int B, int S, int M,
+                                int D, int L, int Lq, int P, int offsets_row_stride, int logits_row_stride,
+                                const int64_t *shapes_host, const int64_t *level_start_host, void *stream);
+int msda_fused_backward_view_f32(const float *value, int value_token_stride, const unsigned char *value_mask,
+                                 const int64_t *shapes, const int64_t *level_start, const float *offsets_or_loc,
+                                 const float *logits_or_attn, int saved, const float *ref, int ref_dim, const float *grad_out,
+                                 float *grad_value, float *grad_offsets, float *grad_logits, int B, int S, int M, int D, int L,
+                                 int Lq, int P, int offsets_row_stride, int logits_row_stride, const int64_t *shapes_host,
+                                 const int64_t *level_start_host, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -253,41 +253,59 @@ def install():
     return sys.modules[__name__]
 
 
-def ms_deform_attn_fused_forward_merged(value, spatial_shapes, level_start_index, proj, reference_points):
-    """Fused operator on ONE projection output ``proj`` [B, Lq, M*48] = (offsets M*32 | logits M*16) of a merged
-    sampling_offsets / attention_weights GEMM, read in place through row strides (msda_fused_forward_strided_f32)."""
+def _value_view(value, value_mask):
+    """(token stride in floats, mask pointer or None, mask tensor to keep alive) of a [B, S, M, D] value VIEW: dense, or a
+    column block of a wider [B, S, C] projection (the last two dimensions dense, batch stride = S * token stride)."""
+    B, S, M, D = value.shape
+    ts = value.stride(1)
+    _assert(value.dtype == torch.float32 and value.stride(3) == 1 and value.stride(2) == D and ts >= M * D and ts % 4 == 0
+            and (B == 1 or value.stride(0) == S * ts) and value.data_ptr() % 16 == 0,
+            "value must be [B, S, M, D] float32, dense or a 16-byte aligned column block of a [B, S, C] tensor")
+    mask = None
+    if value_mask is not None:
+        _assert(value_mask.shape == (B, S) and value_mask.dtype == torch.bool and value_mask.device == value.device,
+                "value_mask must be a bool [B, S] tensor on the value's device")
+        mask = value_mask.contiguous()
+    return ts, (mask.data_ptr() if mask is not None else None), mask
+
+
+def _fused_forward_view(value, spatial_shapes, level_start_index, proj, reference_points, value_mask, save, name):
     B, S, M, D = value.shape
     Lq = proj.shape[1]
     L = P = 4
     _assert(proj.is_contiguous() and proj.shape[2] == M * 48 and proj.dtype == torch.float32, "proj must be [B, Lq, M*48] float32")
     geom = host_geometry(spatial_shapes, level_start_index)
+    ts, mask_ptr, mask = _value_view(value, value_mask)
     out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    loc = torch.empty((B, M, L, Lq, P, 2), dtype=value.dtype, device=value.device) if save else None
+    attw = torch.empty((B, M, L, Lq, P), dtype=value.dtype, device=value.device) if save else None
     timer = LaunchTimer.active
     with torch.cuda.device(value.device):
         stream = torch.cuda.current_stream()
         if timer is not None:
             e0, e1 = timer.bracket("fwd", (B, S, M, D, L, Lq, P))
             e0.record(stream)
-        code = _lib.load().msda_fused_forward_strided_f32(
-            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
+        code = _lib.load().msda_fused_forward_view_f32(
+            value.data_ptr(), ts, mask_ptr, spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
             proj.data_ptr() + M * 32 * 4, reference_points.data_ptr(), reference_points.size(3), out.data_ptr(),
-            B, S, M, D, L, Lq, P, M * 48, M * 48, geom[0], geom[1], stream.cuda_stream)
+            loc.data_ptr() if save else None, attw.data_ptr() if save else None, B, S, M, D, L, Lq, P, M * 48, M * 48,
+            geom[0], geom[1], stream.cuda_stream)
         if timer is not None:
             e1.record(stream)
-    _lib.check(code, "ms_deform_attn_fused_forward_merged")
-    return out
+    _lib.check(code, name)
+    return out, loc, attw
 
 
-def ms_deform_attn_fused_backward_merged(value, spatial_shapes, level_start_index, proj, reference_points, grad_output):
-    """-> grad_value, grad_proj [B, Lq, M*48] (grad offsets | grad logits in the layout of ``proj``)."""
+def _fused_backward_view(value, spatial_shapes, level_start_index, a, b, saved, reference_points, grad_output, value_mask, name):
     B, S, M, D = value.shape
-    Lq = proj.shape[1]
     L = P = 4
+    Lq = a.shape[3] if saved else a.shape[1]
     _assert(grad_output.is_contiguous() and grad_output.numel() == B * Lq * M * D, "grad_output shape mismatch")
     lib = _lib.load()
     geom = host_geometry(spatial_shapes, level_start_index)
-    grad_value = torch.empty_like(value)
-    grad_proj = torch.empty_like(proj)
+    ts, mask_ptr, mask = _value_view(value, value_mask)
+    grad_value = torch.empty((B, S, M, D), dtype=value.dtype, device=value.device)         # always dense
+    grad_proj = torch.empty((B, Lq, M * 48), dtype=value.dtype, device=value.device)
     ws_bytes = lib.msda_backward_workspace_bytes(B, S, M, D, L, Lq, P, 4)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
     timer = LaunchTimer.active
@@ -296,15 +314,33 @@ def ms_deform_attn_fused_backward_merged(value, spatial_shapes, level_start_inde
         if timer is not None:
             e0, e1 = timer.bracket("bwd", (B, S, M, D, L, Lq, P))
             e0.record(stream)
-        code = lib.msda_fused_backward_strided_f32(
-            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(), proj.data_ptr() + M * 32 * 4,
-            reference_points.data_ptr(), reference_points.size(3), grad_output.data_ptr(), grad_value.data_ptr(),
+        code = lib.msda_fused_backward_view_f32(
+            value.data_ptr(), ts, mask_ptr, spatial_shapes.data_ptr(), level_start_index.data_ptr(), a.data_ptr(), b.data_ptr(),
+            1 if saved else 0, reference_points.data_ptr(), reference_points.size(3), grad_output.data_ptr(), grad_value.data_ptr(),
             grad_proj.data_ptr(), grad_proj.data_ptr() + M * 32 * 4, B, S, M, D, L, Lq, P, M * 48, M * 48, geom[0], geom[1],
             ws.data_ptr(), ws_bytes, stream.cuda_stream)
         if timer is not None:
             e1.record(stream)
-    _lib.check(code, "ms_deform_attn_fused_backward_merged")
+    _lib.check(code, name)
     return grad_value, grad_proj
+
+
+def ms_deform_attn_fused_forward_merged(value, spatial_shapes, level_start_index, proj, reference_points, value_mask=None):
+    """Fused operator on ONE projection output ``proj`` [B, Lq, M*48] = (offsets M*32 | logits M*16) of a merged
+    sampling_offsets / attention_weights GEMM, read in place through row strides.  ``value`` may be a column block of a
+    wider projection (token stride), ``value_mask`` [B, S] bool marks padded tokens whose value rows count as zero
+    (msda_fused_forward_view_f32, ABI v7)."""
+    return _fused_forward_view(value, spatial_shapes, level_start_index, proj, reference_points, value_mask, False,
+                               "ms_deform_attn_fused_forward_merged")[0]
+
+
+def ms_deform_attn_fused_backward_merged(value, spatial_shapes, level_start_index, proj, reference_points, grad_output,
+                                         value_mask=None):
+    """-> grad_value (dense [B, S, M, D]; zero rows for padded tokens), grad_proj [B, Lq, M*48] (grad offsets | grad logits in
+    the layout of ``proj``)."""
+    _assert(proj.is_contiguous() and proj.shape[2] == value.shape[2] * 48, "proj must be [B, Lq, M*48]")
+    return _fused_backward_view(value, spatial_shapes, level_start_index, proj, proj[:, :, value.shape[2] * 32:], False,
+                                reference_points, grad_output, value_mask, "ms_deform_attn_fused_backward_merged")
 
 
 def fused_save_supported(value, spatial_shapes, level_start_index, Lq, ref_dim=2):
@@ -315,58 +351,15 @@ def fused_save_supported(value, spatial_shapes, level_start_index, Lq, ref_dim=2
     return bool(_lib.load().msda_fused_save_supported(S, M, D, 4, Lq, 4, ref_dim, geom[0], geom[1]))
 
 
-def ms_deform_attn_fused_forward_merged_save(value, spatial_shapes, level_start_index, proj, reference_points):
+def ms_deform_attn_fused_forward_merged_save(value, spatial_shapes, level_start_index, proj, reference_points, value_mask=None):
     """As ``ms_deform_attn_fused_forward_merged``; also returns the sampling locations [B, M, 4, Lq, 4, 2] and attention
     weights [B, M, 4, Lq, 4] (level-major) the kernel evaluated, for ``ms_deform_attn_fused_backward_merged_saved``."""
-    B, S, M, D = value.shape
-    Lq = proj.shape[1]
-    L = P = 4
-    _assert(proj.is_contiguous() and proj.shape[2] == M * 48 and proj.dtype == torch.float32, "proj must be [B, Lq, M*48] float32")
-    geom = host_geometry(spatial_shapes, level_start_index)
-    out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
-    loc = torch.empty((B, M, L, Lq, P, 2), dtype=value.dtype, device=value.device)
-    attw = torch.empty((B, M, L, Lq, P), dtype=value.dtype, device=value.device)
-    timer = LaunchTimer.active
-    with torch.cuda.device(value.device):
-        stream = torch.cuda.current_stream()
-        if timer is not None:
-            e0, e1 = timer.bracket("fwd", (B, S, M, D, L, Lq, P))
-            e0.record(stream)
-        code = _lib.load().msda_fused_forward_save_f32(
-            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
-            proj.data_ptr() + M * 32 * 4, reference_points.data_ptr(), reference_points.size(3), out.data_ptr(),
-            loc.data_ptr(), attw.data_ptr(), B, S, M, D, L, Lq, P, M * 48, M * 48, geom[0], geom[1], stream.cuda_stream)
-        if timer is not None:
-            e1.record(stream)
-    _lib.check(code, "ms_deform_attn_fused_forward_merged_save")
-    return out, loc, attw
+    return _fused_forward_view(value, spatial_shapes, level_start_index, proj, reference_points, value_mask, True,
+                               "ms_deform_attn_fused_forward_merged_save")
 
 
 def ms_deform_attn_fused_backward_merged_saved(value, spatial_shapes, level_start_index, loc, attw, reference_points,
-                                               grad_output):
+                                               grad_output, value_mask=None):
     """-> grad_value, grad_proj [B, Lq, M*48] (grad offsets | grad logits), from the saved locations / weights."""
-    B, S, M, D = value.shape
-    Lq = loc.shape[3]
-    L = P = 4
-    _assert(grad_output.is_contiguous() and grad_output.numel() == B * Lq * M * D, "grad_output shape mismatch")
-    lib = _lib.load()
-    geom = host_geometry(spatial_shapes, level_start_index)
-    grad_value = torch.empty_like(value)
-    grad_proj = torch.empty((B, Lq, M * 48), dtype=value.dtype, device=value.device)
-    ws_bytes = lib.msda_backward_workspace_bytes(B, S, M, D, L, Lq, P, 4)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
-    timer = LaunchTimer.active
-    with torch.cuda.device(value.device):
-        stream = torch.cuda.current_stream()
-        if timer is not None:
-            e0, e1 = timer.bracket("bwd", (B, S, M, D, L, Lq, P))
-            e0.record(stream)
-        code = lib.msda_fused_backward_saved_f32(
-            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), loc.data_ptr(), attw.data_ptr(),
-            reference_points.data_ptr(), reference_points.size(3), grad_output.data_ptr(), grad_value.data_ptr(),
-            grad_proj.data_ptr(), grad_proj.data_ptr() + M * 32 * 4, B, S, M, D, L, Lq, P, M * 48, M * 48, geom[0], geom[1],
-            ws.data_ptr(), ws_bytes, stream.cuda_stream)
-        if timer is not None:
-            e1.record(stream)
-    _lib.check(code, "ms_deform_attn_fused_backward_merged_saved")
-    return grad_value, grad_proj
+    return _fused_backward_view(value, spatial_shapes, level_start_index, loc, attw, True, reference_points, grad_output,
+                                value_mask, "ms_deform_attn_fused_backward_merged_saved")

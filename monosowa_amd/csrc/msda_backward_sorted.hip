@@ -27,7 +27,7 @@ constexpr int kMaxCells = 17 * 17;
 __global__ __launch_bounds__(kSortThreads, 2) void bwd_scatter_sorted_kernel(
     const float2 *__restrict__ rec_hw, const float *__restrict__ rec_aw, const ChunkBox *__restrict__ boxes,
     const float *__restrict__ grad_out, float *__restrict__ grad_value, const BwdPlan plan, int B, int S, int M,
-    int Lq, int P, int n_chunks_per_list) {
+    int Lq, int P, int n_chunks_per_list, const unsigned char *__restrict__ vmask = nullptr) {
   __shared__ float tile[kTileRows * kSortRowPad];     // 36 KB
   __shared__ float4 r_wts[kSortCap];                  // corner weights x attn_w
   __shared__ int r_q[kSortCap];                       // query of the point
@@ -213,15 +213,17 @@ __global__ __launch_bounds__(kSortThreads, 2) void bwd_scatter_sorted_kernel(
   if (exclusive) {
     for (int r = gid; r < n_rows; r += kSortThreads / 8) {
       const int ry = r / tw, rx = r - ry * tw;
-      st4(grad_value + ((tok0 + (long long)(y0 + ry) * W + (x0 + rx)) * M + m) * 32 + sub * 4,
-          *reinterpret_cast<const float4 *>(tile + r * kSortRowPad + sub * 4));
+      const long long token = tok0 + (long long)(y0 + ry) * W + (x0 + rx);
+      st4(grad_value + (token * M + m) * 32 + sub * 4,
+          (vmask && vmask[token]) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(tile + r * kSortRowPad + sub * 4));
     }
   } else {
     const int ch = threadIdx.x & 31;
     for (int r = threadIdx.x >> 5; r < n_rows; r += kSortThreads / 32) {
       const float v = tile[r * kSortRowPad + ch];
       const int ry = r / tw, rx = r - ry * tw;
-      if (v != 0.f) atomicAdd(grad_value + ((tok0 + (long long)(y0 + ry) * W + (x0 + rx)) * M + m) * 32 + ch, v);
+      const long long token = tok0 + (long long)(y0 + ry) * W + (x0 + rx);
+      if (v != 0.f && !(vmask && vmask[token])) atomicAdd(grad_value + (token * M + m) * 32 + ch, v);
     }
   }
 }

@@ -202,7 +202,10 @@ template <bool FIXED>
 __global__ __launch_bounds__(kScatterThreads, 4) void bwd_scatter_kernel(
     const float2 *__restrict__ rec_hw, const float *__restrict__ rec_aw, const ChunkBox *__restrict__ boxes,
     const float *__restrict__ bounds, const float *__restrict__ grad_out, float *__restrict__ grad_value,
-    const BwdPlan plan, int B, int S, int M, int Lq, int P, int n_chunks_per_list) {
+    const BwdPlan plan, int B, int S, int M, int Lq, int P, int n_chunks_per_list,
+    const unsigned char *__restrict__ vmask = nullptr) {
+  // vmask [B, S] (optional): padded value tokens (ms_deform_attn.py:139-140 fills their value rows with 0): their grad_value
+  // rows are written as zero / left out of the atomics
   __shared__ unsigned long long acc[kTileRows * 32];     // 64 KB
   // per wave: hit records {w1..w4 premultiplied by attn_w} , {rows(1,2), rows(3,4), query, -}
   __shared__ float4 queue[kScatterWaves][kQueue][2];     // 16 KB
@@ -371,17 +374,20 @@ __global__ __launch_bounds__(kScatterThreads, 4) void bwd_scatter_kernel(
   if (exclusive) {
     for (int r = threadIdx.x >> 3; r < n_rows; r += kScatterThreads / 8) {
       const int ry = r / tw, rx = r - ry * tw;
-      float *dst = grad_value + ((tok0 + (long long)(y0 + ry) * W + (x0 + rx)) * M + m) * 32 + sub * 4;
+      const long long token = tok0 + (long long)(y0 + ry) * W + (x0 + rx);
+      float *dst = grad_value + (token * M + m) * 32 + sub * 4;
       const unsigned long long *a = acc + r * 32 + sub * 4;
-      st4(dst, make_float4(to_float(a[0]), to_float(a[1]), to_float(a[2]), to_float(a[3])));
+      const bool padded = vmask && vmask[token];
+      st4(dst, padded ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(to_float(a[0]), to_float(a[1]), to_float(a[2]), to_float(a[3])));
     }
   } else {
     const int ch = threadIdx.x & 31;
     for (int r = threadIdx.x >> 5; r < n_rows; r += kScatterThreads / 32) {
       const unsigned long long raw = acc[r * 32 + ch];
       const int ry = r / tw, rx = r - ry * tw;
-      if (raw != 0ull || (FIXED && !representable))
-        atomicAdd(grad_value + ((tok0 + (long long)(y0 + ry) * W + (x0 + rx)) * M + m) * 32 + ch, to_float(raw));
+      const long long token = tok0 + (long long)(y0 + ry) * W + (x0 + rx);
+      if ((raw != 0ull || (FIXED && !representable)) && !(vmask && vmask[token]))
+        atomicAdd(grad_value + (token * M + m) * 32 + ch, to_float(raw));
     }
   }
 }

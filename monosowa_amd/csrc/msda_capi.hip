@@ -169,15 +169,24 @@ inline bool window_applies(bool bwd, const int64_t *shapes_host, const int64_t *
 
 // Launch of the record-based gather kernels (forward or the backward's grad_loc / grad_attn_w pass), staged when
 // the tail of the pyramid fits LDS and the option allows it.
+// How the caller's `value` is laid out beyond the reference contract (fused entry points, ABI v7): floats between consecutive
+// tokens (0 = M * 32) and an optional padding mask [B, S] whose tokens read as zero rows.
+struct ValueView {
+  int token_stride = 0;
+  const unsigned char *mask = nullptr;
+};
+
 template <bool BWD, bool FUSED, bool SAVED = false>
 void launch_gather(const float *value, const float *loc, const float *attw, const float *grad_out, float *out,
                    float *grad_loc, float *grad_attw, const float *ref, int ref_dim, const int64_t *shapes_host,
                    const int64_t *lsi_host, int B, int S, int M, int Lq, hipStream_t stream, int loc_rs = 0, int aw_rs = 0,
-                   float *grad_value = nullptr, int far_reach = -1) {
+                   float *grad_value = nullptr, int far_reach = -1, ValueView vv = ValueView()) {
   if (!loc_rs) loc_rs = M * 32;
   if (!aw_rs) aw_rs = M * 16;
+  const int vts = vv.token_stride ? vv.token_stride : M * 32;
   if (Lq == S && (options().window & (BWD ? 2 : 1)) && gather_mode() > 1 && (!FUSED || ref_dim == 2)) {
-    // self-attention shape (the window kernels evaluate the 2-d reference-point formula only): query i sits at token i's pixel -> tile-local value windows (msda_gather_win.hip)
+    // self-attention shape (the window kernels evaluate the 2-d reference-point formula only): query i sits at token i's
+    // pixel -> tile-local value windows (msda_gather_win.hip)
     msda::WinGeom wg;
     if (window_tiling(shapes_host, lsi_host, options().window_halo, BWD, wg)) {
       const int bm_groups = (B * M + 7) / 8;
@@ -186,9 +195,15 @@ void launch_gather(const float *value, const float *loc, const float *attw, cons
       // persistent: one workgroup per CU walks the (batch * head, tile) items (window_persistent = 0: one workgroup per item)
       const int n_virtual = 8 * wg.n_ty * wg.n_tx * bm_groups;
       const int grid = options().window_persistent ? std::min(n_virtual, persistent_grid()) : n_virtual;
-      msda::gather_win_kernel<BWD, FUSED, SAVED><<<grid, BWD ? msda::kWinThreadsBwd : msda::kWinThreads, 0, stream>>>(
-          value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, wt, B, S, M, loc_rs, aw_rs,
-          grad_value, far_reach, n_virtual);
+      const int threads = BWD ? msda::kWinThreadsBwd : msda::kWinThreads;
+      if (vv.mask)
+        msda::gather_win_kernel<BWD, FUSED, SAVED, true><<<grid, threads, 0, stream>>>(
+            value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, wt, B, S, M, loc_rs, aw_rs, grad_value, far_reach,
+            n_virtual, vts, vv.mask);
+      else
+        msda::gather_win_kernel<BWD, FUSED, SAVED, false><<<grid, threads, 0, stream>>>(
+            value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, wt, B, S, M, loc_rs, aw_rs, grad_value, far_reach,
+            n_virtual, vts, nullptr);
       return;
     }
   }
@@ -199,11 +214,12 @@ void launch_gather(const float *value, const float *loc, const float *attw, cons
     const int bm_groups = (B * M + 7) / 8;
     msda::gather_rec_kernel<BWD, true, FUSED>
         <<<8 * geom.n_chunks * bm_groups, BWD ? msda::kStagedThreadsBwd : msda::kStagedThreadsFwd, 0, stream>>>(
-            value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, geom, B, S, M, Lq, n_pairs, loc_rs, aw_rs);
+            value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, geom, B, S, M, Lq, n_pairs, loc_rs, aw_rs, vts,
+            vv.mask);
   } else {
     geom.first_lds_level = 4;
     msda::gather_rec_kernel<BWD, false, FUSED><<<grid_pairs(n_pairs), msda::kPlainThreads, 0, stream>>>(
-        value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, geom, B, S, M, Lq, n_pairs, loc_rs, aw_rs);
+        value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, geom, B, S, M, Lq, n_pairs, loc_rs, aw_rs, vts, vv.mask);
   }
 }
 
@@ -300,7 +316,8 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
                   const T *attw, const T *grad_out, T *grad_value, T *grad_loc, T *grad_attw,
                   int B, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
                   const int64_t *lsi_host, void *workspace, size_t workspace_bytes, void *stream_,
-                  const float *fused_ref = nullptr, int fused_ref_dim = 0, int loc_rs = 0, int aw_rs = 0, bool saved = false) {
+                  const float *fused_ref = nullptr, int fused_ref_dim = 0, int loc_rs = 0, int aw_rs = 0, bool saved = false,
+                  ValueView vv = ValueView()) {
   // saved: `loc` / `attw` are the sampling locations / attention weights the fused forward stored (contiguous); the
   // gradients still go back to raw offsets / logits through `fused_ref` and the row strides (self-attention shape only)
   if (!value || !shapes || !lsi || !loc || !attw || !grad_out || !grad_value || !grad_loc || !grad_attw)
@@ -308,6 +325,8 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
   if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
   hipStream_t stream = (hipStream_t)stream_;
   const long long n_pairs = (long long)B * Lq * M;
+  if ((vv.token_stride || vv.mask) && !(sizeof(T) == 4 && fused_ref && tiled_backward_applies(4, D, L, P) && M * L * 8 <= 1024))
+    return MSDA_E_UNSUPPORTED;          // strided / masked value: fused d32 path only
 
   if constexpr (sizeof(T) == 4) {
     if (tiled_backward_applies(4, D, L, P) && M * L * 8 <= 1024) {
@@ -343,19 +362,19 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
           const int lrs = loc_rs ? loc_rs : M * 32, ars = aw_rs ? aw_rs : M * 16;
           if (fused_ref && !saved)
             msda::scatter_rows_kernel<true><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
-                loc, attw, grad_out, grad_value, fused_ref, fused_ref_dim, table, rp, B, S, M, lrs, ars);
+                loc, attw, grad_out, grad_value, fused_ref, fused_ref_dim, table, rp, B, S, M, lrs, ars, vv.mask);
           else if (saved)
             msda::scatter_rows_kernel<false, true><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
-                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, 0, 0);
+                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, 0, 0, vv.mask);
           else
             msda::scatter_rows_kernel<false><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
                 loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, lrs, ars);
           if (fused_ref && saved)
             launch_gather<true, true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
-                                            shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, rp.reach);
+                                            shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, rp.reach, vv);
           else if (fused_ref)
             launch_gather<true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
-                                      shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, rp.reach);
+                                      shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, rp.reach, vv);
           else
             launch_gather<true, false>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, nullptr, 0, shapes_host,
                                        lsi_host, B, S, M, Lq, stream, 0, 0, grad_value, rp.reach);
@@ -391,17 +410,17 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       // 0.091 at Lq = 50 -- the batches' barriers only pay off on long record lists
       if (options().scatter_sorted == 1 ? Lq * P >= 8192 : options().scatter_sorted == 2)
         msda::bwd_scatter_sorted_kernel<<<8 * plan.n_items * bm_groups, msda::kSortThreads, 0, stream>>>(
-            rec_hw, rec_aw, boxes, grad_out, grad_value, plan, B, S, M, Lq, P, (int)ws.n_chunks_per_list);
+            rec_hw, rec_aw, boxes, grad_out, grad_value, plan, B, S, M, Lq, P, (int)ws.n_chunks_per_list, vv.mask);
       else if (scatter_fixed_point())
         msda::bwd_scatter_kernel<true><<<8 * plan.n_items * bm_groups, msda::kScatterThreads, 0, stream>>>(
-            rec_hw, rec_aw, boxes, bounds, grad_out, grad_value, plan, B, S, M, Lq, P, (int)ws.n_chunks_per_list);
+            rec_hw, rec_aw, boxes, bounds, grad_out, grad_value, plan, B, S, M, Lq, P, (int)ws.n_chunks_per_list, vv.mask);
       else
         msda::bwd_scatter_kernel<false><<<8 * plan.n_items * bm_groups, msda::kScatterThreads, 0, stream>>>(
-            rec_hw, rec_aw, boxes, bounds, grad_out, grad_value, plan, B, S, M, Lq, P, (int)ws.n_chunks_per_list);
+            rec_hw, rec_aw, boxes, bounds, grad_out, grad_value, plan, B, S, M, Lq, P, (int)ws.n_chunks_per_list, vv.mask);
       if (gather_mode() > 0 || fused_ref) {
         if (fused_ref)
           launch_gather<true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
-                                    shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs);
+                                    shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, nullptr, -1, vv);
         else
           launch_gather<true, false>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, nullptr, 0, shapes_host,
                                      lsi_host, B, S, M, Lq, stream);
@@ -463,6 +482,57 @@ int msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *l
                      void *stream) {
   return forward_impl<float>(value, shapes, level_start, loc, attn_w, out, B, S, M, D, L, Lq, P, shapes_host,
                              level_start_host, stream);
+}
+
+// ---- ABI v7: the fused operator on a value VIEW (token stride + padding mask) -------------------------------------------------
+int msda_fused_forward_view_f32(const float *value, int value_token_stride, const unsigned char *value_mask,
+                                const int64_t *shapes, const int64_t *level_start, const float *offsets, const float *logits,
+                                const float *ref, int ref_dim, float *out, float *loc_save, float *attn_save, int B, int S, int M,
+                                int D, int L, int Lq, int P, int offsets_row_stride, int logits_row_stride,
+                                const int64_t *shapes_host, const int64_t *level_start_host, void *stream) {
+  if (!value || !shapes || !level_start || !offsets || !logits || !ref || !out || !shapes_host || !level_start_host)
+    return MSDA_E_NULLPTR;
+  if ((loc_save == nullptr) != (attn_save == nullptr)) return MSDA_E_NULLPTR;
+  if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
+  if (!(D == 32 && L == 4 && P == 4) || (ref_dim != 2 && ref_dim != 6)) return MSDA_E_UNSUPPORTED;
+  if (offsets_row_stride < M * 32 || logits_row_stride < M * 16 || (offsets_row_stride & 3) || (logits_row_stride & 3))
+    return MSDA_E_SHAPE;
+  if (value_token_stride < M * 32 || (value_token_stride & 3) || (long long)S * value_token_stride >= (1LL << 31)) return MSDA_E_SHAPE;
+  if (int e = check_host_geometry(shapes_host, level_start_host, L, S)) return e;
+  ValueView vv;
+  vv.token_stride = value_token_stride;
+  vv.mask = value_mask;
+  if (loc_save) {
+    if (!msda_fused_save_supported(S, M, D, L, Lq, P, ref_dim, shapes_host, level_start_host)) return MSDA_E_UNSUPPORTED;
+    launch_gather<false, true, true>(value, offsets, logits, nullptr, out, loc_save, attn_save, ref, ref_dim, shapes_host,
+                                     level_start_host, B, S, M, Lq, (hipStream_t)stream, offsets_row_stride, logits_row_stride,
+                                     nullptr, -1, vv);
+  } else {
+    launch_gather<false, true>(value, offsets, logits, nullptr, out, nullptr, nullptr, ref, ref_dim, shapes_host,
+                               level_start_host, B, S, M, Lq, (hipStream_t)stream, offsets_row_stride, logits_row_stride, nullptr,
+                               -1, vv);
+  }
+  return (int)hipGetLastError();
+}
+
+int msda_fused_backward_view_f32(const float *value, int value_token_stride, const unsigned char *value_mask,
+                                 const int64_t *shapes, const int64_t *level_start, const float *offsets_or_loc,
+                                 const float *logits_or_attn, int saved, const float *ref, int ref_dim, const float *grad_out,
+                                 float *grad_value, float *grad_offsets, float *grad_logits, int B, int S, int M, int D, int L,
+                                 int Lq, int P, int offsets_row_stride, int logits_row_stride, const int64_t *shapes_host,
+                                 const int64_t *level_start_host, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!ref || !shapes_host || !level_start_host) return MSDA_E_NULLPTR;
+  if (!(D == 32 && L == 4 && P == 4) || (ref_dim != 2 && ref_dim != 6)) return MSDA_E_UNSUPPORTED;
+  if (offsets_row_stride < M * 32 || logits_row_stride < M * 16 || (offsets_row_stride & 3) || (logits_row_stride & 3))
+    return MSDA_E_SHAPE;
+  if (value_token_stride < M * 32 || (value_token_stride & 3) || (long long)S * value_token_stride >= (1LL << 31)) return MSDA_E_SHAPE;
+  if (saved && !msda_fused_save_supported(S, M, D, L, Lq, P, ref_dim, shapes_host, level_start_host)) return MSDA_E_UNSUPPORTED;
+  ValueView vv;
+  vv.token_stride = value_token_stride;
+  vv.mask = value_mask;
+  return backward_impl<float>(value, shapes, level_start, offsets_or_loc, logits_or_attn, grad_out, grad_value, grad_offsets,
+                              grad_logits, B, S, M, D, L, Lq, P, shapes_host, level_start_host, workspace, workspace_bytes,
+                              stream, ref, ref_dim, offsets_row_stride, logits_row_stride, saved != 0, vv);
 }
 
 int msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,

@@ -56,7 +56,10 @@ void gather_rec_kernel(
     const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attw,
     const float *__restrict__ grad_out, float *__restrict__ out, float *__restrict__ grad_loc,
     float *__restrict__ grad_attw, const float *__restrict__ ref, int ref_dim, const GatherGeom g, int B, int S,
-    int M, int Lq, long long n_pairs, int loc_rs, int aw_rs) {
+    int M, int Lq, long long n_pairs, int loc_rs, int aw_rs, int vts = 0, const unsigned char *__restrict__ vmask = nullptr) {
+  // vts: floats between consecutive value tokens (0: M * 32; 768 when `value` is a column block of one projection shared by
+  // three layers).  vmask [B, S] (optional): padded value tokens read as zero rows (ms_deform_attn.py:139-140) -- folded into
+  // the corner weights when the lane builds its records, the row reads stay as they are.
   // loc_rs / aw_rs: floats between consecutive queries in loc / attw (and their gradients): M*32 / M*16 when contiguous;
   // larger when both live in one [B, Lq, 384] buffer (offsets | logits of a merged projection)
   constexpr int kThreads = STAGED ? (BWD ? kStagedThreadsBwd : kStagedThreadsFwd) : kPlainThreads;
@@ -70,7 +73,7 @@ void gather_rec_kernel(
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = threadIdx.x & 7, grp8 = lane >> 3;
-  const int tok = M * 32;
+  const int tok = vts ? vts : M * 32;
   float4 *rec = records[wave] + grp8 * kPairF4;                // this pair's 16 records
 
   long long pair, pair_stride;
@@ -81,7 +84,7 @@ void gather_rec_kernel(
     if (bm >= B * M) return;
     const int chunk = (int)((blockIdx.x / 8) % g.n_chunks);
     const int q_begin = (int)((long long)Lq * chunk / g.n_chunks), q_end = (int)((long long)Lq * (chunk + 1) / g.n_chunks);
-    const float *value_bm = value + ((long long)(bm / M) * S * M + (bm % M)) * 32;
+    const float *value_bm = value + (long long)(bm / M) * S * tok + (bm % M) * 32;
     for (int r = threadIdx.x >> 3; r < g.n_lds_rows; r += kThreads / 8)
       *reinterpret_cast<float4 *>(staged + r * kRowPad + sub * 4) = ld4(value_bm + (long long)(g.lds_token0 + r) * tok + sub * 4);
     __syncthreads();
@@ -99,7 +102,7 @@ void gather_rec_kernel(
   for (int it = 0; it < n_iter; ++it, pair += pair_stride) {
     const int m = (int)(pair % M);
     const int b = (int)(pair / ((long long)M * Lq));
-    const float *vb = value + ((long long)b * S * M + m) * 32 + sub * 4;      // + corner offset
+    const float *vb = value + (long long)b * S * tok + m * 32 + sub * 4;       // + corner offset
     const float *sb = staged + sub * 4;
     const long long q_lin = pair / M;
     const long long loc_at = q_lin * loc_rs + m * 32 + sub * 4, aw_at = q_lin * aw_rs + m * 16 + sub * 2;
@@ -133,15 +136,22 @@ void gather_rec_kernel(
       const int4 off = corner_offsets(tp, W, lvl_base, row_stride);
       float4 *r = rec + (2 * sub + k) * kRecF4;
       r[0] = make_float4(__int_as_float(off.x), __int_as_float(off.y), __int_as_float(off.z), __int_as_float(off.w));
+      float q1 = 1.f, q2 = 1.f, q3 = 1.f, q4 = 1.f;                            // 0 for a corner on a padded token
+      if (vmask) {
+        const unsigned char *mk = vmask + (long long)b * S + lvl_start;         // (corner coordinates are clamped into the level)
+        const int r0 = tp.y0 * W, r1 = tp.y1 * W;
+        q1 = mk[r0 + tp.x0] ? 0.f : 1.f; q2 = mk[r0 + tp.x1] ? 0.f : 1.f;
+        q3 = mk[r1 + tp.x0] ? 0.f : 1.f; q4 = mk[r1 + tp.x1] ? 0.f : 1.f;
+      }
       if (!BWD) {
-        r[1] = make_float4(tp.w1 * wt, tp.w2 * wt, tp.w3 * wt, tp.w4 * wt);
+        r[1] = make_float4(tp.w1 * wt * q1, tp.w2 * wt * q2, tp.w3 * wt * q3, tp.w4 * wt * q4);
       } else {
         // grad_attn_w = sum_i w_i d_i; grad_x = W*wt*(hh(d2-d1) + lh(d4-d3)); grad_y = H*wt*(hw(d3-d1) + lw(d4-d2)),
         // a dropped corner (cuh:114-152) contributing nothing: its coefficients are zeroed
-        const float k1 = (tp.t && tp.l) ? 1.f : 0.f, k2 = (tp.t && tp.r) ? 1.f : 0.f;
-        const float k3 = (tp.b && tp.l) ? 1.f : 0.f, k4 = (tp.b && tp.r) ? 1.f : 0.f;
+        const float k1 = (tp.t && tp.l) ? q1 : 0.f, k2 = (tp.t && tp.r) ? q2 : 0.f;
+        const float k3 = (tp.b && tp.l) ? q3 : 0.f, k4 = (tp.b && tp.r) ? q4 : 0.f;
         const float sx = (float)W * wt, sy = (float)H * wt;
-        r[1] = make_float4(tp.w1, tp.w2, tp.w3, tp.w4);
+        r[1] = make_float4(tp.w1 * q1, tp.w2 * q2, tp.w3 * q3, tp.w4 * q4);
         r[2] = make_float4(-sx * tp.hh * k1, sx * tp.hh * k2, -sx * tp.lh * k3, sx * tp.lh * k4);
         r[3] = make_float4(-sy * tp.hw * k1, -sy * tp.lw * k2, sy * tp.hw * k3, sy * tp.lw * k4);
       }

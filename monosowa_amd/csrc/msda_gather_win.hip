@@ -52,12 +52,16 @@ typedef __attribute__((address_space(1))) const void global_cvoid_t;
 // the only exposed memory phase of an item is the LDS-DMA fill of its windows -- and this lane's tap arithmetic runs under
 // that.  With one workgroup per item (the previous form) launch, input latency, fill and row reads ran back to back, 20
 // times per CU: measured 0.35 ms forward of which ~0.10 ms was that prologue.
-template <bool BWD, bool FUSED, bool SAVED = false>
+// MASKED: `vmask` [B, S] marks padded value tokens; their rows count as zero (ms_deform_attn.py:139-140) -- folded into the
+// corner weights (forward) / the corner dot products (backward) of the lane that owns the point.  `vts`: floats between
+// consecutive value tokens.
+template <bool BWD, bool FUSED, bool SAVED = false, bool MASKED = false>
 __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? kWinThreadsBwd / 256 : 4) void gather_win_kernel(
     const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attw,
     const float *__restrict__ grad_out, float *__restrict__ out, float *__restrict__ grad_loc,
     float *__restrict__ grad_attw, const float *__restrict__ ref, int ref_dim, const WinTable g, int B, int S, int M,
-    int loc_rs, int aw_rs, float *__restrict__ grad_value, int far_reach, int n_virtual) {
+    int loc_rs, int aw_rs, float *__restrict__ grad_value, int far_reach, int n_virtual, int vts,
+    const unsigned char *__restrict__ vmask) {
   // far_reach >= 0 (backward, with msda_scatter_rows.hip): points that are not near_point(.., far_reach) add their
   // grad_value contributions here with global atomics -- the row-tile scatter handles exactly the near ones
   __shared__ float4 win[(kWinMaxRows + 1) * 8];                 // value windows, 8 float4 = one 128-byte row; + the zero row
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? kWinThrea
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = threadIdx.x & 7;
-  const int tok = M * 32;
+  const int tok = vts;
   const int n_tiles = g.n_ty * g.n_tx;
   if (threadIdx.x < 8) win[kWinMaxRows * 8 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? kWinThrea
                  "+v"(in.rf.y) : : "memory");
     if (BWD) asm volatile("" : "+v"(in.go.x), "+v"(in.go.y), "+v"(in.go.z), "+v"(in.go.w) : : "memory");
     const AxisSpec *ay_tab = g.ax[it.ty], *ax_tab = g.ax[g.n_ty + it.tx];
-    const float *value_bm = value + ((long long)it.b * S * M + it.m) * 32;
+    const float *value_bm = value + (long long)it.b * S * tok + it.m * 32;
     int base1, base2, base3;
     {
       int rows = 0;
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? kWinThrea
     int off[2][4];
     float cw[2][4];          // forward: corner weights x attn_w.  backward: lh, lw, W attn_w, H attn_w
     int far_points = 0;      // backward with the row-tile scatter: which of the two points it does not cover
+    int padded = 0;          // MASKED backward: bit 4 k2 + c = corner c of point k2 sits on a padded token
     auto taps = [&]() {
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
@@ -227,6 +232,13 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? kWinThrea
       off[k2][3] = pick(lds00 + ldy + ldx, mem00 + mdy + mdx, tp.b && tp.r);
       if (BWD) { cw[k2][0] = tp.lh; cw[k2][1] = tp.lw; cw[k2][2] = (float)Wm * wt; cw[k2][3] = (float)Hm * wt; }
       else { cw[k2][0] = tp.w1 * wt; cw[k2][1] = tp.w2 * wt; cw[k2][2] = tp.w3 * wt; cw[k2][3] = tp.w4 * wt; }
+      if (MASKED) {                                                       // corners on padded tokens (coordinates are clamped into the level)
+        const unsigned char *mk = vmask + (long long)it.b * S + start_m;
+        const int r0 = tp.y0 * Wm, r1 = tp.y1 * Wm;
+        const bool p0 = mk[r0 + tp.x0] != 0, p1 = mk[r0 + tp.x1] != 0, p2 = mk[r1 + tp.x0] != 0, p3 = mk[r1 + tp.x1] != 0;
+        if (BWD) padded |= ((p0 ? 1 : 0) | (p1 ? 2 : 0) | (p2 ? 4 : 0) | (p3 ? 8 : 0)) << (4 * k2);
+        else { if (p0) cw[k2][0] = 0.f; if (p1) cw[k2][1] = 0.f; if (p2) cw[k2][2] = 0.f; if (p3) cw[k2][3] = 0.f; }
+      }
       if (BWD && far_reach >= 0 && live && tp.valid && !near_point(tp.h_low, tp.w_low, in.cf_y, in.cf_x, far_reach))
         far_points |= 1 << k2;
     }
@@ -391,8 +403,8 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? kWinThrea
           const float lx = k2 ? l4.z : l4.x, ly = k2 ? l4.w : l4.y, wt = k2 ? a2.y : a2.x;
           const Tap<float> tp = make_tap<float>(lx, ly, Hm, Wm);
           auto corner_add = [&](const int y, const int x, const bool keep, const float w) {
-            if (!keep) return;
-            float *row_p = gv + (long long)(start_m + y * Wm + x) * tok;
+            if (!keep || (MASKED && vmask[(long long)it.b * S + start_m + y * Wm + x])) return;
+            float *row_p = gv + (long long)(start_m + y * Wm + x) * (M * 32);      // grad_value is dense, whatever `vts` is
             const float cwt = w * wt;
 #pragma unroll
             for (int s2 = 0; s2 < 8; ++s2) {
@@ -444,6 +456,13 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? kWinThrea
                 asm volatile("" : "+v"(d[k2][c]) : : "memory");
               }
             }
+      }
+      if (MASKED && padded) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (padded & (1 << (4 * k2 + c))) d[k2][c] = 0.f;
       }
       float4 ol = make_float4(0.f, 0.f, 0.f, 0.f);
       float2 oa = make_float2(0.f, 0.f);

@@ -56,7 +56,8 @@ template <bool FUSED, bool LEVEL_MAJOR = false>
 __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_rows_kernel(
     const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out,
     float *__restrict__ grad_value, const float *__restrict__ ref, int ref_dim, const RowCandidate *__restrict__ table,
-    const RowPlan p, int B, int S, int M, int loc_rs, int aw_rs) {
+    const RowPlan p, int B, int S, int M, int loc_rs, int aw_rs, const unsigned char *__restrict__ vmask = nullptr) {
+  // vmask [B, S] (optional): padded value tokens -- their grad_value rows come out as zero (ms_deform_attn.py:139-140)
   __shared__ float4 go_lds[kRowBatchQueries * 8];          // grad_out rows of the batch's candidates (this head), 16 KB
   __shared__ uint2 bucket[kRowBucketEntries];              // per row: {weight bits, candidate slot}, 32 KB
   __shared__ unsigned count[kRowTileRows];
@@ -230,9 +231,11 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
   if (n_chunks == 1) {
     if (r < n_rows) {
       const int ry = r / tw, rx = r - ry * tw;
-      float *dst = grad_value + ((tok0 + (long long)(y0 + ry) * W + (x0 + rx)) * M + m) * 32 + half * 16;
+      const long long token = tok0 + (long long)(y0 + ry) * W + (x0 + rx);
+      float *dst = grad_value + (token * M + m) * 32 + half * 16;
+      const bool padded = vmask && vmask[token];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) st4(dst + 4 * k, acc[k]);
+      for (int k = 0; k < 4; ++k) st4(dst + 4 * k, padded ? make_float4(0.f, 0.f, 0.f, 0.f) : acc[k]);
     }
   } else {
     // several workgroups share the tile: full 128-byte rows of atomics (lane = channel), through LDS
@@ -246,7 +249,8 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
     for (int rr = tid >> 5; rr < n_rows; rr += kRowThreads / 32) {
       const float v = rows_lds[rr * 32 + ch];
       const int ry = rr / tw, rx = rr - ry * tw;
-      if (v != 0.f) atomicAdd(grad_value + ((tok0 + (long long)(y0 + ry) * W + (x0 + rx)) * M + m) * 32 + ch, v);
+      const long long token = tok0 + (long long)(y0 + ry) * W + (x0 + rx);
+      if (v != 0.f && !(vmask && vmask[token])) atomicAdd(grad_value + (token * M + m) * 32 + ch, v);
     }
   }
 }

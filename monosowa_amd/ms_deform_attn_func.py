@@ -63,22 +63,27 @@ class MSDeformAttnFusedFunction(Function):
 
 class MSDeformAttnFusedMergedFunction(Function):
     """The fused operator on one merged projection output ``proj`` [B, Lq, M*48] = (sampling offsets | attention logits),
-    read and differentiated in place through row strides (msda_fused_*_strided_f32)."""
+    read and differentiated in place through row strides.  ``value`` [B, S, M, D] may be a column block of a wider projection
+    (e.g. one of three 256-column blocks of a [B, S, 768] tensor: its gradient comes back dense), ``value_mask`` [B, S] bool
+    marks padded tokens whose value rows count as zero -- ``value.masked_fill(mask[..., None], 0)`` of the reference module
+    (ops/modules/ms_deform_attn.py:139-140) without a pass of its own (msda_fused_*_view_f32, ABI v7)."""
 
     @staticmethod
-    def forward(ctx, value, spatial_shapes, level_start_index, proj, reference_points):
+    def forward(ctx, value, spatial_shapes, level_start_index, proj, reference_points, value_mask=None):
         ctx.host_geom = MSDA.host_geometry(spatial_shapes, level_start_index)
         needs_grad = value.requires_grad or proj.requires_grad
         ctx.saved_prologue = SAVE_PROLOGUE and needs_grad and MSDA.fused_save_supported(
             value, spatial_shapes, level_start_index, proj.shape[1], reference_points.shape[-1])
+        ctx.value_mask = value_mask
         if ctx.saved_prologue:
             # self-attention shape in training: keep the sampling locations / attention weights the kernel evaluated
             # (250 MB per encoder layer at B = 16) so that neither backward kernel re-evaluates softmax + location math
             output, loc, attw = MSDA.ms_deform_attn_fused_forward_merged_save(value, spatial_shapes, level_start_index, proj,
-                                                                              reference_points)
+                                                                              reference_points, value_mask)
             ctx.save_for_backward(value, spatial_shapes, level_start_index, loc, attw, reference_points)
         else:
-            output = MSDA.ms_deform_attn_fused_forward_merged(value, spatial_shapes, level_start_index, proj, reference_points)
+            output = MSDA.ms_deform_attn_fused_forward_merged(value, spatial_shapes, level_start_index, proj, reference_points,
+                                                              value_mask)
             ctx.save_for_backward(value, spatial_shapes, level_start_index, proj, reference_points)
         return output
 
@@ -88,12 +93,13 @@ class MSDeformAttnFusedMergedFunction(Function):
         if ctx.saved_prologue:
             value, shapes, lsi, loc, attw, ref = ctx.saved_tensors
             MSDA.attach_host_geometry(shapes, lsi, *_unpack_geom(ctx.host_geom))
-            gv, gproj = MSDA.ms_deform_attn_fused_backward_merged_saved(value, shapes, lsi, loc, attw, ref, grad_output.contiguous())
-            return gv, None, None, gproj, None
+            gv, gproj = MSDA.ms_deform_attn_fused_backward_merged_saved(value, shapes, lsi, loc, attw, ref, grad_output.contiguous(),
+                                                                        ctx.value_mask)
+            return gv, None, None, gproj, None, None
         value, shapes, lsi, proj, ref = ctx.saved_tensors
         MSDA.attach_host_geometry(shapes, lsi, *_unpack_geom(ctx.host_geom))
-        gv, gproj = MSDA.ms_deform_attn_fused_backward_merged(value, shapes, lsi, proj, ref, grad_output.contiguous())
-        return gv, None, None, gproj, None
+        gv, gproj = MSDA.ms_deform_attn_fused_backward_merged(value, shapes, lsi, proj, ref, grad_output.contiguous(), ctx.value_mask)
+        return gv, None, None, gproj, None, None
 
 
 def _unpack_geom(geom):

@@ -561,6 +561,70 @@ def test_fused_self_attention_shape_odd_planes_and_6d_reference_points(B, M, ref
         assert (a - b).abs().max() <= 2e-5 * b.abs().max(), (name, ((a - b).abs().max() / b.abs().max()).item())
 
 
+@pytest.mark.parametrize("kind", ["self", "cross"])
+@pytest.mark.parametrize("masked,strided", [(True, False), (False, True), (True, True)])
+def test_fused_operator_on_a_value_view_equals_masked_fill_plus_the_unfused_operator(kind, masked, strided):
+    """ABI v7 (msda_fused_*_view_f32): `value` as one 256-column block of a [B, S, 768] projection (token stride) and / or a
+    padding mask, on the self-attention shape (window gather + row-tile scatter, saved prologue) and the cross-attention
+    shape (record gather + tile-owner scatter) -- against value.masked_fill(...) (ms_deform_attn.py:139-140) + the PyTorch
+    prologue + the unfused operator.  grad_value comes back dense with exactly-zero rows for padded tokens."""
+    from monosowa_amd.ms_deform_attn_func import MSDeformAttnFunction, MSDeformAttnFusedMergedFunction
+    MSDA = _msda()
+    torch.manual_seed(31 + masked + 2 * strided)
+    levels = [(24, 40), (12, 20), (6, 10), (3, 5)]
+    B, M, D, L, P = 2, 8, 32, 4, 4
+    shapes = torch.tensor(levels, dtype=torch.long, device="cuda")
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    MSDA.attach_host_geometry(shapes, lsi, levels, lsi.tolist())
+    S = int(shapes.prod(1).sum())
+    if kind == "self":
+        Lq = S
+        ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, device="cuda") + 0.5) / h, (torch.arange(w, device="cuda") + 0.5) / w,
+                                                    indexing="ij")[::-1], -1).reshape(-1, 2) for h, w in levels])
+        ref = ref[None, :, None, :].expand(B, Lq, L, 2).contiguous()
+        off_scale = 3.0                                       # some far / out-of-window points as well
+    else:
+        Lq = 333
+        ref = torch.cat([torch.rand(B, Lq, L, 2, device="cuda"), torch.rand(B, Lq, L, 4, device="cuda") * 0.3], -1)
+        off_scale = 3.0
+    wide = torch.randn(B, S, 3 * M * D, device="cuda")
+    base = (wide[:, :, M * D:2 * M * D] if strided else wide[:, :, M * D:2 * M * D].contiguous()).view(B, S, M, D)
+    value = base.detach().requires_grad_(True) if not strided else None
+    if strided:
+        wide.requires_grad_(True)
+        value_in = wide[:, :, M * D:2 * M * D].view(B, S, M, D)
+        assert not value_in.is_contiguous()
+    else:
+        value_in = value
+    mask = (torch.rand(B, S, device="cuda") < 0.25) if masked else None
+    proj = torch.cat([torch.randn(B, Lq, M * 32, device="cuda") * off_scale, torch.randn(B, Lq, M * 16, device="cuda")], -1).requires_grad_(True)
+    go = torch.randn(B, Lq, M * D, device="cuda")
+    out = MSDeformAttnFusedMergedFunction.apply(value_in, shapes, lsi, proj, ref, mask)
+    out.backward(go)
+    gv = (wide.grad[:, :, M * D:2 * M * D] if strided else value.grad.view(B, S, M * D)).clone()
+    if strided:
+        assert wide.grad[:, :, :M * D].abs().max() == 0 and wide.grad[:, :, 2 * M * D:].abs().max() == 0
+    got = [out.detach().clone(), gv, proj.grad.clone()]
+    proj.grad = None
+
+    v2 = base.detach().clone().contiguous().requires_grad_(True)
+    vm = v2.masked_fill(mask[..., None, None], 0.0) if masked else v2
+    offsets, logits = proj[:, :, :M * 32].view(B, Lq, M, L, P, 2), proj[:, :, M * 32:].reshape(B, Lq, M, L * P)
+    aw = torch.softmax(logits, -1).view(B, Lq, M, L, P)
+    if ref.shape[-1] == 2:
+        norm = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+        loc = ref[:, :, None, :, None, :] + offsets / norm[None, None, None, :, None, :]
+    else:
+        loc = ref[:, :, None, :, None, :2] + offsets / P * (ref[:, :, None, :, None, 2::2] + ref[:, :, None, :, None, 3::2]) * 0.5
+    out_u = MSDeformAttnFunction.apply(vm, shapes, lsi, loc.contiguous(), aw.contiguous(), 64)
+    out_u.backward(go)
+    want = [out_u.detach(), v2.grad.view(B, S, M * D), proj.grad]
+    for name, a, b in zip(("out", "grad_value", "grad_proj"), got, want):
+        assert (a - b).abs().max() <= 2e-5 * b.abs().max(), (kind, name, ((a - b).abs().max() / b.abs().max()).item())
+    if masked:
+        assert got[1][mask].abs().max() == 0                  # padded tokens: exactly zero gradient rows
+
+
 def test_train_val_cli_runs_an_epoch_and_writes_kitti_results(tmp_path):
     """tools/train_val.py (the reference's CLI): one tiny epoch on synthetic data through Trainer -> checkpoint ->
     Tester.inference -> KITTI result files, then `-e` evaluation-only from the saved checkpoint."""
