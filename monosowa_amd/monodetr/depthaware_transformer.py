@@ -162,6 +162,57 @@ class VisualEncoder(nn.Module):
 # ----------------------------------------------------------------------------------------------
 # decoder
 # ----------------------------------------------------------------------------------------------
+MERGE_VALUE_PROJ = True      # the decoder layers' value_proj(memory) as one GEMM
+
+
+class _MergedValueProj(torch.autograd.Function):
+    """memory [B, S, C] x n layers' value_proj -> n views [B, S, C] of ONE [B, S, n*C] projection output (column blocks: token
+    stride n*C).  The backward receives the n dense value gradients the operators produce and turns them into d memory
+    (accumulating GEMMs), the split-K weight gradients and the column-sum bias gradients -- what n token_linear nodes do,
+    minus n - 1 forward launches and the autograd accumulation of d memory."""
+
+    @staticmethod
+    def forward(ctx, memory, *params):
+        n = len(params) // 2
+        weights, biases = params[:n], params[n:]
+        C = memory.shape[-1]
+        merged = F.linear(memory, torch.cat(weights), torch.cat(biases))                 # [B, S, n*C]
+        ctx.save_for_backward(memory, *weights)
+        ctx.n = n
+        return tuple(merged[..., i * C:(i + 1) * C] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from ..token_linear import weight_grad
+        from ..pointwise import colsum
+        memory, *weights = ctx.saved_tensors
+        m2 = memory.reshape(-1, memory.shape[-1])
+        g2 = [None if g is None else g.reshape(-1, g.shape[-1]) for g in grads]
+        gm = None
+        if ctx.needs_input_grad[0]:
+            for g, w in zip(g2, weights):
+                if g is None:
+                    continue
+                gm = g @ w if gm is None else gm.addmm_(g, w)
+            gm = None if gm is None else gm.view_as(memory)
+        gw = [None if g is None else weight_grad(g.contiguous(), m2) for g in g2]
+        gb = [None if g is None else colsum(g.contiguous()) for g in g2]
+        return (gm,) + tuple(gw) + tuple(gb)
+
+
+def merged_value_proj(memory, attns):
+    """-> list of value views (one per MSDeformAttn in ``attns``), or None when the merge does not apply (CPU, other dtypes,
+    a single layer): the layers then project for themselves."""
+    if len(attns) < 2 or not memory.is_cuda or memory.dtype != torch.float32 or not torch.is_grad_enabled() \
+            or any(a.value_proj.bias is None or a.value_proj.weight.shape != attns[0].value_proj.weight.shape for a in attns):
+        if len(attns) >= 2 and memory.is_cuda and memory.dtype == torch.float32 and not torch.is_grad_enabled():
+            C = memory.shape[-1]
+            merged = F.linear(memory, torch.cat([a.value_proj.weight for a in attns]), torch.cat([a.value_proj.bias for a in attns]))
+            return [merged[..., i * C:(i + 1) * C] for i in range(len(attns))]
+        return None
+    return list(_MergedValueProj.apply(memory, *[a.value_proj.weight for a in attns], *[a.value_proj.bias for a in attns]))
+
+
 class DepthAwareDecoderLayer(nn.Module):
     def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8,
                  n_points=4, group_num=1, group_size=50):
@@ -229,7 +280,7 @@ class DepthAwareDecoderLayer(nn.Module):
         return mha(q, k, v, need_weights=False)[0]
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
-                src_padding_mask, depth_pos_embed, mask_depth):
+                src_padding_mask, depth_pos_embed, mask_depth, value=None):
         # depth cross attention over the stride-16 depth-aware tokens
         tq = tgt.transpose(0, 1)
         if mask_depth is None and mha_supported(self.cross_attn_depth, tq, depth_pos_embed, depth_pos_embed):
@@ -242,7 +293,7 @@ class DepthAwareDecoderLayer(nn.Module):
         tgt = dropout_add_layernorm(tgt, self._self_attention(tgt, query_pos), self.norm2, self.dropout2)
         # visual cross attention
         tgt2 = self.cross_attn(_add_pos(tgt, query_pos), reference_points, src, src_spatial_shapes,
-                               level_start_index, src_padding_mask)
+                               level_start_index, src_padding_mask, value=value)
         tgt = dropout_add_layernorm(tgt, tgt2, self.norm1, self.dropout1)
         # ffn
         ff = token_linear(self.dropout3(F.relu(token_linear(tgt, self.linear1))), self.linear2)
@@ -267,6 +318,16 @@ class DepthAwareDecoder(nn.Module):
         output = tgt
         inter, inter_refs, inter_dims = [], [], []
         self.bbox_raw = []          # bbox_embed[lid](output) of every layer: MonoDETR.forward needs exactly these again
+        # every layer's cross-attention projects the SAME memory with its own value_proj (ms_deform_attn.py:138): one GEMM for
+        # all layers, each layer's operator reads its column block in place (value token stride, ABI v7)
+        # -- for the layers whose reference points carry no gradient (the fused operator's condition): with iterative refinement
+        # every layer after the first sees detached points (:602-613); the first one's come from the learned query embedding
+        values = [None] * len(self.layers)
+        if MERGE_VALUE_PROJ:
+            first = 0 if not reference_points.requires_grad else (1 if self.bbox_embed is not None else len(self.layers))
+            merged = merged_value_proj(src, [layer.cross_attn for layer in self.layers[first:]])
+            if merged is not None:
+                values[first:] = merged
         for lid, layer in enumerate(self.layers):
             if reference_points.shape[-1] == 6:
                 ratios = torch.cat([src_valid_ratios, src_valid_ratios, src_valid_ratios], -1)
@@ -275,7 +336,8 @@ class DepthAwareDecoder(nn.Module):
                 assert reference_points.shape[-1] == 2
                 reference_points_input = reference_points[:, :, None] * src_valid_ratios[:, None]
             output = layer(output, query_pos, reference_points_input, src, src_spatial_shapes,
-                           src_level_start_index, src_padding_mask, depth_pos_embed, mask_depth)
+                           src_level_start_index, src_padding_mask, depth_pos_embed, mask_depth,
+                           value=values[lid])
             if self.bbox_embed is not None:   # iterative refinement, detached between layers (:602-613)
                 if MERGE_HEADS and self.dim_embed is not None:
                     tmp, reference_dims = merged_first_layers(output, [self.bbox_embed[lid], self.dim_embed[lid]])

@@ -22,6 +22,7 @@ def _is_power_of_2(n):
     return (n & (n - 1) == 0) and n != 0
 
 
+MASK_IN_KERNEL = True    # fused path: the padding mask is an operator argument instead of a masked_fill pass
 MERGED_PROJ = True     # offsets + logits projections as one GEMM in front of the strided fused operator
 
 
@@ -64,10 +65,12 @@ class MSDeformAttn(nn.Module):
         constant_(self.output_proj.bias.data, 0.)
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
-                input_level_start_index, input_padding_mask=None):
+                input_level_start_index, input_padding_mask=None, value=None):
         """query [N,Lq,C]; reference_points [N,Lq,L,2] or [N,Lq,L,6] (cx,cy,l,r,t,b);
         input_flatten [N,S,C]; input_spatial_shapes [L,2]; input_level_start_index [L];
-        input_padding_mask [N,S] (True = padding) -> [N,Lq,C]."""
+        input_padding_mask [N,S] (True = padding) -> [N,Lq,C].
+        ``value`` (optional, not in the reference): ``self.value_proj(input_flatten)`` computed by the caller, possibly as a
+        column block of one GEMM shared by several layers (``merged_value_proj``)."""
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         # the reference asserts sum(H_l * W_l) == Len_in on the device tensor (ms_deform_attn.py:136), a host
@@ -78,21 +81,32 @@ class MSDeformAttn(nn.Module):
         else:
             assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
 
-        value = token_linear(input_flatten, self.value_proj)
-        if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], float(0))
-        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        if value is None:
+            value = token_linear(input_flatten, self.value_proj)
+        H = self.n_heads
         if self.fuse_prologue and MERGED_PROJ and self.n_levels == 4 and self.n_points == 4 and self.d_model == 32 * self.n_heads \
                 and query.is_cuda and query.dtype == torch.float32 and not reference_points.requires_grad \
                 and reference_points.shape[-1] in (2, 6) and geom is not None \
                 and _func.MSDeformAttnFunction.__module__ == _func.__name__:
-            # sampling_offsets and attention_weights as ONE GEMM; the operator reads (offsets | logits) in place
+            # sampling_offsets and attention_weights as ONE GEMM; the operator reads (offsets | logits) in place.  The padding
+            # mask goes INTO the operator (padded tokens read as zero rows, their gradient rows come out zero: ABI v7) instead of
+            # a masked_fill pass over the value tensor, and `value` may be a column block of a wider projection.
             w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight])
             b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias])
             proj = F.linear(query, w, b)
-            output = _func.MSDeformAttnFusedMergedFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
-                                                                 proj, reference_points.contiguous())
+            v4 = value.unflatten(-1, (H, self.d_model // H))                       # a view, also of a column block
+            if not (v4.stride(3) == 1 and v4.stride(2) == v4.shape[3] and v4.stride(1) % 4 == 0 and v4.data_ptr() % 16 == 0
+                    and (N == 1 or v4.stride(0) == Len_in * v4.stride(1))):
+                v4 = v4.contiguous()
+            mask = input_padding_mask if (input_padding_mask is not None and MASK_IN_KERNEL) else None
+            if input_padding_mask is not None and mask is None:
+                v4 = v4.masked_fill(input_padding_mask[..., None, None], float(0))
+            output = _func.MSDeformAttnFusedMergedFunction.apply(v4, input_spatial_shapes, input_level_start_index,
+                                                                 proj, reference_points.contiguous(), mask)
             return token_linear(output, self.output_proj)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.reshape(N, Len_in, self.n_heads, self.d_model // self.n_heads).contiguous()     # (a caller's column block: copied here)
         sampling_offsets = token_linear(query, self.sampling_offsets).view(
             N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
         attention_weights = token_linear(query, self.attention_weights).view(
