@@ -13,7 +13,7 @@ import torch
 import tqdm
 
 from .decode_helper import PinholeCalib, decode_detections, extract_dets_from_outputs
-from .save_helper import load_checkpoint
+from .save_helper import unwrap, load_checkpoint
 
 
 class GraphedForward:
@@ -45,7 +45,9 @@ class GraphedForward:
 class Tester(object):
     def __init__(self, cfg, model, dataloader, logger, train_cfg=None, model_name="monodetr"):
         self.cfg = cfg
-        self.model = model
+        # the bare module: inference runs on one rank at a time, and a DistributedDataParallel forward would start
+        # collectives (buffer broadcast) that the other ranks never join
+        self.model = unwrap(model)
         self.dataloader = dataloader
         self.max_objs = dataloader.dataset.max_objs
         self.class_name = dataloader.dataset.class_name
