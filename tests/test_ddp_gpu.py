@@ -70,7 +70,11 @@ for it in range(2):                            # second iteration: bucket views 
     gb = {n: p.grad for n, p in wrapped_core.named_parameters() if p.grad is not None}
     assert set(ga) == set(gb), sorted(set(ga) ^ set(gb))[:5]
     noise, worst = deviation(ga, gc), deviation(ga, gb)
-    assert worst <= 2e-4 + 3 * noise, (worst, noise)      # DDP adds nothing beyond the step's own nondeterminism
+    # DDP adds nothing beyond the step's own nondeterminism.  The per-tensor maximum over ~300 tensors is heavy-tailed (a few
+    # tensors with tiny gradients carry all of it), hence the factor; the L2 distance of the whole gradient is the tight check
+    assert worst <= max(5e-2, 10 * noise), (worst, noise)      # (a tensor that missed the reduction would be off by O(1))
+    l2 = lambda a, b: (torch.cat([(a[n] - b[n]).reshape(-1) for n in a]).norm() / torch.cat([a[n].reshape(-1) for n in a]).norm()).item()
+    assert l2(ga, gb) <= 2e-3 + 3 * l2(ga, gc), (l2(ga, gb), l2(ga, gc))
     opt_a.step(); opt_c.step(); opt_b.step()
     wa = dict(plain.named_parameters()); wb = dict(wrapped_core.named_parameters()); wc = dict(twin.named_parameters())
     dw = max((wa[n] - wb[n]).abs().max().item() for n in ga)
@@ -100,3 +104,117 @@ def test_train_step_under_ddp_world_size_1_equals_the_unwrapped_step(tmp_path):
     if r.returncode != 0 or "ddp-ws1 ok" not in r.stdout:
         pytest.fail("DDP worker failed (rc %d)\n--- stdout ---\n%s\n--- stderr ---\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-6000:]),
                     pytrace=False)
+
+
+WORKER2 = r'''
+import os, sys
+sys.path.insert(0, os.environ["MONOSOWA_ROOT"])
+import torch, yaml
+import torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)                      # both ranks share the one GPU of the box: gloo carries the collectives
+dev = torch.device("cuda", 0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from monosowa_amd.helpers.model_helper import build_model, to_mi355x_layout
+from monosowa_amd.helpers.optimizer_helper import build_optimizer
+from monosowa_amd.helpers.trainer_helper import wrap_ddp
+from monosowa_amd.monodetr.criterion import weighted_total
+from monosowa_amd.synthetic import make_batch, prepare_targets
+from monosowa_amd import flash_attn, pointwise
+
+cfg = yaml.safe_load(open(os.path.join(os.environ["MONOSOWA_ROOT"], "configs", "monodetr.yaml")))
+mcfg = dict(cfg["model"], device="cuda", depth_map_size=(20, 6))
+torch.manual_seed(444)
+model, crit = build_model(mcfg)
+model = to_mi355x_layout(model.to(dev)).train()
+crit = crit.to(dev).train()
+opt = build_optimizer(cfg["optimizer"], model)
+ddp = wrap_ddp(model, dev)
+assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel) and dist.get_world_size() == 2
+inputs, calibs, targets, _ = make_batch(2, dev, seed=11 + rank, resolution=(320, 96))      # a different shard per rank
+inputs = inputs.contiguous(memory_format=torch.channels_last)
+tl = prepare_targets(targets, 2)
+frozen = set(model.unused_parameter_names())
+
+def backward_pass(sync):
+    torch.manual_seed(7 + rank)
+    pointwise._seed_counter[0] = flash_attn._seed_counter[0] = 0          # same dropout masks in every pass of this rank
+    ddp.zero_grad(set_to_none=True)
+    if sync:
+        total = weighted_total(crit(ddp(inputs, calibs, tl, targets["img_size"]), tl), crit.weight_dict)
+        total.backward()
+    else:
+        with ddp.no_sync():
+            total = weighted_total(crit(ddp(inputs, calibs, tl, targets["img_size"]), tl), crit.weight_dict)
+            total.backward()
+    return total.detach(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None and n not in frozen}
+
+def deviation(ga, gb):
+    gmax = max(g.abs().max().item() for g in ga.values())
+    return max((ga[n] - gb[n]).abs().max().item() / max(ga[n].abs().max().item(), 1e-5 * gmax) for n in ga)
+
+_, local_a = backward_pass(False)
+_, local_b = backward_pass(False)             # the step's own run-to-run noise (f32 atomics in MIOpen / the coarse-level scatter)
+loss, synced = backward_pass(True)
+names = sorted(local_a)
+flat = torch.cat([local_a[n].reshape(-1) for n in names]).cpu()
+both = [torch.zeros_like(flat) for _ in range(world)]
+dist.all_gather(both, flat)
+mean_flat = ((both[0] + both[1]) / world).to(dev)
+mean, o = {}, 0
+for n in names:
+    k = local_a[n].numel()
+    mean[n] = mean_flat[o:o + k].view_as(local_a[n]); o += k
+noise, worst = deviation(local_a, local_b), deviation(mean, synced)
+# the bucketed all-reduce delivers the mean of the ranks' gradients.  Per tensor: a loose bound (the maximum over ~300 tensors
+# of a relative deviation is heavy-tailed run-to-run noise; a tensor that missed the reduction would be off by O(1)); the
+# tight check is the L2 distance of the whole gradient against the step's own run-to-run noise
+assert worst <= max(5e-2, 10 * noise), (worst, noise)
+l2 = lambda a, b: (torch.cat([(a[n] - b[n]).reshape(-1) for n in a]).norm() / torch.cat([a[n].reshape(-1) for n in a]).norm()).item()
+own = torch.tensor([l2(local_a, local_b)])
+noises = [torch.zeros(1) for _ in range(world)]
+dist.all_gather(noises, own)
+assert l2(mean, synced) <= 2e-3 + 3 * max(n.item() for n in noises), (l2(mean, synced), [n.item() for n in noises])
+other = both[1 - rank].to(dev)
+assert (other - flat.to(dev)).abs().max() > 1e-3 * flat.abs().max()       # the ranks really saw different data
+opt.step()
+w = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+ws = [torch.zeros_like(w) for _ in range(world)]
+dist.all_gather(ws, w)
+assert torch.equal(ws[0], ws[1])                           # replicas identical after the fused AdamW step
+print("rank %d: loss %.5f, |synced - mean| %.2e (noise %.2e)" % (rank, loss.item(), worst, noise))
+torch.cuda.synchronize()
+dist.barrier()
+dist.destroy_process_group()
+if rank == 0:
+    print("ddp-ws2 ok")
+'''
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_allreduce_the_fused_steps_gradients(tmp_path):
+    """World size 2 with the real HIP path (fused encoder blocks, window / row-tile MSDA kernels, HIP attention, fused AdamW):
+    two processes share the box's one GPU, gloo carries the collectives (RCCL refuses two ranks on one device).  Each rank's
+    synchronised gradient must be the mean of the two ranks' local gradients, and the replicas must stay identical after the
+    optimizer step -- the multi-rank semantics of SURVEY 8 row e, on the GPU kernels instead of the CPU oracle port."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "ddp_ws2.py"
+    script.write_text(WORKER2)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MONOSOWA_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2",
+                   LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=900))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("DDP world-size-2 workers timed out", pytrace=False)
+    if any(p.returncode != 0 for p in procs) or "ddp-ws2 ok" not in outs[0][0]:
+        pytest.fail("DDP world-size-2 worker failed\n" + "\n".join("--- rank %d (rc %s) ---\n%s\n%s" % (i, procs[i].returncode, o[-1500:], e[-5000:])
+                                                                     for i, (o, e) in enumerate(outs)), pytrace=False)
