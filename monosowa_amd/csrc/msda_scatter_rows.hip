@@ -187,16 +187,23 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
     // ---- 2./3. buckets and row sums; a row whose bucket overflows (many points on one pixel) takes more rounds -----------
     bool again;
     do {
+      // all slot reservations first (independent LDS atomics with return: in flight together), then the entries -- one atomic,
+      // its wait and its store per corner in turn cost eight LDS round trips per thread and batch
+      unsigned rank[kRowSub][4];
+#pragma unroll
+      for (int u = 0; u < kRowSub; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          rank[u][c] = 0xFFFFFFFFu;
+          if (pend & (1u << (4 * u + c))) rank[u][c] = atomicAdd(&count[rows[u][c]], 1u);
+        }
 #pragma unroll
       for (int u = 0; u < kRowSub; ++u)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          if (pend & (1u << (4 * u + c))) {
-            const unsigned rank = atomicAdd(&count[rows[u][c]], 1u);
-            if (rank < (unsigned)cap) {
-              bucket[rows[u][c] * bstride + rank] = make_uint2(__float_as_uint(coef[u][c]), (unsigned)(slot0 + u * (kRowThreads / 4)));
-              pend &= ~(1u << (4 * u + c));
-            }
+          if (rank[u][c] < (unsigned)cap) {
+            bucket[rows[u][c] * bstride + rank[u][c]] = make_uint2(__float_as_uint(coef[u][c]), (unsigned)(slot0 + u * (kRowThreads / 4)));
+            pend &= ~(1u << (4 * u + c));
           }
       if (pend) overflow = 1;                // rare
       lds_barrier();
