@@ -62,11 +62,14 @@ def parse():
 
 
 def msda_alg_bytes(kind, dims):
-    """Algorithmic bytes of one launch (every input read once, every output written once)."""
+    """Algorithmic bytes of one launch (every input read once, every output written once: SURVEY 8d).  The value term of a
+    FORWARD launch is capped at the rows the launch can touch at all (Lq * L * P points x 4 corners per head): a 50-query
+    inference launch cannot read more than 3,200 of the 10,200 rows per head, and counting all of them would report more
+    than the HBM peak.  (The backward writes every grad_value row whatever Lq is.)"""
     B, S, M, D, L, Lq, P = dims
     if kind == "fwd":
-        return 4 * B * (S * M * D + Lq * M * L * P * 3 + Lq * M * D)
-    return 4 * B * (Lq * M * D + S * M * D + Lq * M * L * P * 3 + S * M * D + Lq * M * L * P * 3)
+        return 4 * B * (min(S, Lq * L * P * 4) * M * D + Lq * M * L * P * 3 + Lq * M * D)
+    return 4 * B * (Lq * M * D + min(S, Lq * L * P * 4) * M * D + Lq * M * L * P * 3 + S * M * D + Lq * M * L * P * 3)
 
 
 def dims_S(timer):
