@@ -147,6 +147,31 @@ def clean_data(gt_anno, dt_anno, current_class, difficulty):
     return int((ignored_gt == 0).sum()), ignored_gt, ignored_dt, dc.reshape(-1, 4)
 
 
+MAX_DISTANCE = (30, 50, 70)          # distance ranges of get_distance_eval_result: [0, 30], (30, 50], (50, 70] metres
+
+
+def clean_data_by_distance(gt_anno, dt_anno, current_class, difficulty):
+    """As clean_data, with the difficulty index selecting a DISTANCE range (norm of the object's location) and the "hard"
+    occlusion / truncation / height limits for every range (eval.py:83-157, DISTANCE_COVER = False)."""
+    cls = CLASS_NAMES[current_class]
+    gname = np.char.lower(np.asarray(gt_anno["name"], dtype=str)) if len(gt_anno["name"]) else np.zeros(0, dtype=str)
+    same = gname == cls
+    neighbour = ((gname == "person_sitting") & (cls == "pedestrian")) | ((gname == "van") & (cls == "car"))
+    bbox = np.asarray(gt_anno["bbox"], dtype=np.float64).reshape(-1, 4)
+    dis = np.linalg.norm(np.asarray(gt_anno["location"], dtype=np.float64).reshape(-1, 3), axis=1)
+    hard = (np.asarray(gt_anno["occluded"]) > MAX_OCCLUSION[2]) | (np.asarray(gt_anno["truncated"]) > MAX_TRUNCATION[2]) \
+        | ((bbox[:, 3] - bbox[:, 1]) <= MIN_HEIGHT[2]) | (dis > MAX_DISTANCE[difficulty])
+    if difficulty > 0:
+        hard = hard | (dis <= MAX_DISTANCE[difficulty - 1])
+    ignored_gt = np.where(same & ~hard, 0, np.where(neighbour | (same & hard), 1, -1)).astype(np.int64)
+    dc = bbox[np.asarray(gt_anno["name"], dtype=str) == "DontCare"] if len(bbox) else np.zeros((0, 4))
+    dname = np.char.lower(np.asarray(dt_anno["name"], dtype=str)) if len(dt_anno["name"]) else np.zeros(0, dtype=str)
+    dbox = np.asarray(dt_anno["bbox"], dtype=np.float64).reshape(-1, 4)
+    small = np.abs(dbox[:, 3] - dbox[:, 1]) < MIN_HEIGHT[2]
+    ignored_dt = np.where(small, 1, np.where(dname == cls, 0, -1)).astype(np.int64)
+    return int((ignored_gt == 0).sum()), ignored_gt, ignored_dt, dc.reshape(-1, 4)
+
+
 def get_thresholds(scores, num_gt, num_sample_pts=N_SAMPLE_PTS):
     """Score thresholds at which recall crosses the 41 sample points (eval.py:10-26)."""
     scores = np.sort(np.asarray(scores, dtype=np.float64))[::-1]
@@ -211,11 +236,11 @@ def calculate_iou_partly(gt_annos, dt_annos, metric, num_parts=50, max_boxes=409
     return overlaps, n1, n2
 
 
-def _prepare_data(gt_annos, dt_annos, current_class, difficulty):
+def _prepare_data(gt_annos, dt_annos, current_class, difficulty, DIForDIS=True):
     """Flat arrays for the native matcher: counts, gt rows (bbox, alpha), dt rows (bbox, alpha, score), ignore flags, DontCare."""
     n_gt, n_dt, n_dc, gt_rows, dt_rows, ign_gt, ign_dt, dcs, valid = [], [], [], [], [], [], [], [], 0
     for g, d in zip(gt_annos, dt_annos):
-        nv, ig, idt, dc = clean_data(g, d, current_class, difficulty)
+        nv, ig, idt, dc = (clean_data if DIForDIS else clean_data_by_distance)(g, d, current_class, difficulty)
         valid += nv
         ign_gt.append(ig); ign_dt.append(idt); dcs.append(dc)
         n_gt.append(len(ig)); n_dt.append(len(idt)); n_dc.append(len(dc))
@@ -233,7 +258,7 @@ def _ptr(a):
 
 
 def eval_class(gt_annos, dt_annos, current_classes, difficultys, metric, min_overlaps, compute_aos=False, num_parts=50,
-               overlaps=None):
+               overlaps=None, DIForDIS=True):
     """Precision / recall / orientation similarity at the 41 recall sample points, [class, difficulty, min_overlap, 41]
     (eval.py:508-633).  `overlaps`: optional per-image [n_dt, n_gt] matrices (default: computed here, on the GPU for the
     rotated metrics)."""
@@ -246,7 +271,7 @@ def eval_class(gt_annos, dt_annos, current_classes, difficultys, metric, min_ove
     precision, recall, aos = np.zeros(shape), np.zeros(shape), np.zeros(shape)
     for m, current_class in enumerate(current_classes):
         for l, difficulty in enumerate(difficultys):
-            d = _prepare_data(gt_annos, dt_annos, current_class, difficulty)
+            d = _prepare_data(gt_annos, dt_annos, current_class, difficulty, DIForDIS)
             assert int((d["n_gt"] * d["n_dt"]).sum()) == flat.size, "overlap matrices do not match the annotations"
             common = (len(gt_annos), _ptr(d["n_gt"]), _ptr(d["n_dt"]), _ptr(d["n_dc"]), _ptr(flat), _ptr(d["gt"]), _ptr(d["dt"]),
                       _ptr(d["ign_gt"]), _ptr(d["ign_dt"]), _ptr(d["dc"]))
@@ -281,12 +306,13 @@ def get_mAP_R40(prec):
     return prec[..., 1:].sum(-1) / 40 * 100
 
 
-def do_eval(gt_annos, dt_annos, current_classes, min_overlaps, compute_aos=False, PR_detail_dict=None):
+def do_eval(gt_annos, dt_annos, current_classes, min_overlaps, compute_aos=False, PR_detail_dict=None, DIForDIS=True):
     """-> mAP_bbox, mAP_bev, mAP_3d, mAP_aos, and the four R40 variants; each [class, difficulty, min_overlap] (eval.py:655-700)."""
     difficultys = [0, 1, 2]
     out, out40 = [], []
     for metric, key in ((0, "bbox"), (1, "bev"), (2, "3d")):
-        ret = eval_class(gt_annos, dt_annos, current_classes, difficultys, metric, min_overlaps, compute_aos and metric == 0)
+        ret = eval_class(gt_annos, dt_annos, current_classes, difficultys, metric, min_overlaps, compute_aos and metric == 0,
+                         DIForDIS=DIForDIS)
         out.append(get_mAP(ret["precision"])); out40.append(get_mAP_R40(ret["precision"]))
         if PR_detail_dict is not None:
             PR_detail_dict[key] = ret["precision"]
@@ -297,23 +323,21 @@ def do_eval(gt_annos, dt_annos, current_classes, min_overlaps, compute_aos=False
     return out[0], out[1], out[2], aos[0], out40[0], out40[1], out40[2], aos[1]
 
 
-def get_official_eval_result(gt_annos, dt_annos, current_classes, PR_detail_dict=None):
-    """The KITTI report: text, dict of headline numbers, Car-moderate 3D AP_R40 (eval.py:863-985; same overlap table, same
-    text layout, same dictionary keys)."""
-    overlap_0_7 = np.array([[0.7, 0.5, 0.5, 0.7, 0.5, 0.7]] * 3)
-    overlap_0_5 = np.array([[0.5, 0.5, 0.5, 0.5, 0.5, 0.5], [0.5, 0.25, 0.25, 0.5, 0.25, 0.5], [0.5, 0.25, 0.25, 0.5, 0.25, 0.5]])
-    overlap_0_3 = np.array([[0.3, 0.5, 0.5, 0.3, 0.5, 0.5], [0.3, 0.25, 0.25, 0.3, 0.25, 0.5], [0.3, 0.25, 0.25, 0.3, 0.25, 0.5]])
+def _report(gt_annos, dt_annos, current_classes, overlap_tables, levels, PR_detail_dict, DIForDIS):
+    """Shared body of the two report functions: per class and overlap setting the AP / AP_R40 lines (same text layout as
+    eval.py:900-985), and the dictionary of headline numbers at the first overlap setting keyed by `levels`."""
     name_to_class = {v: k for k, v in CLASS_TO_NAME.items()}
     if not isinstance(current_classes, (list, tuple)):
         current_classes = [current_classes]
     current_classes = [name_to_class[c] if isinstance(c, str) else c for c in current_classes]
-    min_overlaps = np.stack([overlap_0_7, overlap_0_5, overlap_0_3], 0)[:, :, current_classes]
+    min_overlaps = np.stack(overlap_tables, 0)[:, :, current_classes]
     compute_aos = False
     for anno in dt_annos:                      # the first non-empty detection file decides (alpha == -10: no orientation)
         if np.asarray(anno["alpha"]).shape[0] != 0:
             compute_aos = bool(anno["alpha"][0] != -10)
             break
-    bbox, bev, d3, aos, bbox40, bev40, d340, aos40 = do_eval(gt_annos, dt_annos, current_classes, min_overlaps, compute_aos, PR_detail_dict)
+    bbox, bev, d3, aos, bbox40, bev40, d340, aos40 = do_eval(gt_annos, dt_annos, current_classes, min_overlaps, compute_aos, PR_detail_dict,
+                                                             DIForDIS)
     text, ret = "", {}
     for j, cls in enumerate(current_classes):
         name = CLASS_TO_NAME[cls]
@@ -327,10 +351,28 @@ def get_official_eval_result(gt_annos, dt_annos, current_classes, PR_detail_dict
                     text += "aos  AP:%.2f, %.2f, %.2f\n" % tuple(va[j, :, i])
             if i == 0:
                 for suffix, (vb, ve, v3, va) in (("", (bbox, bev, d3, aos)), ("_R40", (bbox40, bev40, d340, aos40))):
-                    for di, level in enumerate(("easy", "moderate", "hard")):
+                    for di, level in enumerate(levels):
                         if compute_aos:
                             ret["%s_aos_%s%s" % (name, level, suffix)] = va[j, di, 0]
                         ret["%s_3d_%s%s" % (name, level, suffix)] = v3[j, di, 0]
                         ret["%s_bev_%s%s" % (name, level, suffix)] = ve[j, di, 0]
                         ret["%s_image_%s%s" % (name, level, suffix)] = vb[j, di, 0]
     return text, ret, d340[0, 1, 0]
+
+
+def get_official_eval_result(gt_annos, dt_annos, current_classes, PR_detail_dict=None):
+    """The KITTI report: text, dict of headline numbers, Car-moderate 3D AP_R40 (eval.py:863-985; same overlap table, same
+    text layout, same dictionary keys)."""
+    overlap_0_7 = np.array([[0.7, 0.5, 0.5, 0.7, 0.5, 0.7]] * 3)
+    overlap_0_5 = np.array([[0.5, 0.5, 0.5, 0.5, 0.5, 0.5], [0.5, 0.25, 0.25, 0.5, 0.25, 0.5], [0.5, 0.25, 0.25, 0.5, 0.25, 0.5]])
+    overlap_0_3 = np.array([[0.3, 0.5, 0.5, 0.3, 0.5, 0.5], [0.3, 0.25, 0.25, 0.3, 0.25, 0.5], [0.3, 0.25, 0.25, 0.3, 0.25, 0.5]])
+    return _report(gt_annos, dt_annos, current_classes, [overlap_0_7, overlap_0_5, overlap_0_3], ("easy", "moderate", "hard"),
+                   PR_detail_dict, True)
+
+
+def get_distance_eval_result(gt_annos, dt_annos, current_classes, PR_detail_dict=None):
+    """The report by distance range (0-30 m, 30-50 m, 50-70 m) instead of difficulty (eval.py:988-1090): text and dictionary."""
+    overlap_0_7 = np.array([[0.7, 0.5, 0.5, 0.7, 0.5, 0.7]] * 3)
+    overlap_0_5 = np.array([[0.7, 0.5, 0.5, 0.7, 0.5, 0.5], [0.5, 0.25, 0.25, 0.5, 0.25, 0.5], [0.5, 0.25, 0.25, 0.5, 0.25, 0.5]])
+    text, ret, _ = _report(gt_annos, dt_annos, current_classes, [overlap_0_7, overlap_0_5], ("30m", "50m", "70m"), PR_detail_dict, False)
+    return text, ret

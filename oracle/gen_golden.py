@@ -680,6 +680,14 @@ def gen_kitti_eval():
             out["official_%d__%s" % (cls, key)] = np.float64(val)
         out["official_%d_return" % cls] = np.float64(car_mod)
     out["official_text"] = np.array("\n=====\n".join(lines))
+    # the distance-range variant (clean_data_by_distance, get_distance_eval_result: eval.py:83-157, :988-1090)
+    lines = []
+    for cls in (0, 1):
+        result, ret_dict = ev.get_distance_eval_result(gts, dts, cls)
+        lines.append(result)
+        for key, val in ret_dict.items():
+            out["distance_%d__%s" % (cls, key)] = np.float64(val)
+    out["distance_text"] = np.array("\n=====\n".join(lines))
     # the pieces, on their own
     sc = np.round(rng.uniform(0, 1, 57), 3)
     out["thr_scores"], out["thr_num_gt"] = sc, np.int64(71)

@@ -79,6 +79,21 @@ def test_official_report_equals_the_reference_text(ap, monkeypatch):
     _check_official(K, g, gts, dts)
 
 
+def test_distance_range_report_equals_the_reference_text(ap, monkeypatch):
+    """get_distance_eval_result (clean_data_by_distance: ranges 0-30 / 30-50 / 50-70 m) for Car and Pedestrian."""
+    g, gts, dts = ap
+    K = _exact_rotated_overlaps(monkeypatch)
+    texts = []
+    for cls in (0, 1):
+        text, ret = K.get_distance_eval_result(gts, dts, cls)
+        texts.append(text)
+        assert set(ret) == {k.split("__")[1] for k in g.files if k.startswith("distance_%d__" % cls)}
+        for key, val in ret.items():
+            ref = float(g["distance_%d__%s" % (cls, key)])
+            assert abs(val - ref) <= 1e-9 or (np.isnan(val) and np.isnan(ref)), (cls, key, val, ref)
+    assert "\n=====\n".join(texts) == str(g["distance_text"])
+
+
 def _check_official(K, g, gts, dts):
     texts = []
     for cls in (0, 1, 2):
