@@ -120,6 +120,14 @@ int mono_ddn_loss_bwd_f32(const float *logits, const float *boxes, const float *
                           long long sp, float alpha, float gamma, float fg_weight, float bg_weight, float depth_min, float depth_max,
                           void *stream);
 
+/* Expected depth of the bin distribution (depth_predictor/depth_predictor.py:90-91): out [B, H, W] = sum_c softmax(logits)_c *
+ * values[c]; logits [B, C, H, W] with (batch, channel, pixel) strides as above.  backward: grad_logits (same strides) =
+ * grad_out * p_c * (values[c] - out). */
+int mono_depth_expect_fwd_f32(const float *logits, const float *values, float *out, int B, int C, int H, int W, long long sb,
+                              long long sc, long long sp, void *stream);
+int mono_depth_expect_bwd_f32(const float *logits, const float *values, const float *expect, const float *grad_out, float *grad_logits,
+                              int B, int C, int H, int W, long long sb, long long sc, long long sp, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -636,4 +636,25 @@ int mono_ddn_loss_bwd_f32(const float *logits, const float *boxes, const float *
   return (int)hipGetLastError();
 }
 
+
+// ---- expected depth over the bin distribution (ddn_loss.hip) -------------------------------------------------------------
+int mono_depth_expect_fwd_f32(const float *logits, const float *values, float *out, int B, int C, int H, int W, long long sb,
+                              long long sc, long long sp, void *stream) {
+  if (!logits || !values || !out) return -1;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return -2;
+  const int n = B * H * W;
+  mono::depth_expect_fwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(logits, values, out, n, H * W, C, sb, sc, sp);
+  return (int)hipGetLastError();
+}
+
+int mono_depth_expect_bwd_f32(const float *logits, const float *values, const float *expect, const float *grad_out, float *grad_logits,
+                              int B, int C, int H, int W, long long sb, long long sc, long long sp, void *stream) {
+  if (!logits || !values || !expect || !grad_out || !grad_logits) return -1;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return -2;
+  const int n = B * H * W;
+  mono::depth_expect_bwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(logits, values, expect, grad_out, grad_logits, n,
+                                                                               H * W, C, sb, sc, sp);
+  return (int)hipGetLastError();
+}
+
 }  // extern "C"

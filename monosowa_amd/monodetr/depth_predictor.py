@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..flash_attn import mha_forward, mha_supported
-from ..pointwise import conv_group_norm, dropout_add_layernorm, relu_dropout
+from ..pointwise import conv_group_norm, depth_expectation, dropout_add_layernorm, relu_dropout
 from ..token_linear import token_linear
 
 
@@ -62,6 +62,9 @@ def lid_bin_values(num_bins, depth_min, depth_max):
     return torch.cat([values, torch.tensor([depth_max])], dim=0)
 
 
+FUSED_EXPECTATION = True     # weighted depth as one HIP kernel each way (csrc/ddn_loss.hip)
+
+
 class DepthPredictor(nn.Module):
     def __init__(self, model_cfg):
         super().__init__()
@@ -95,8 +98,10 @@ class DepthPredictor(nn.Module):
         src = conv_group_norm(src, self.depth_head[3], self.depth_head[4], relu=True)
         depth_logits = self.depth_classifier(src)
 
-        depth_probs = F.softmax(depth_logits, dim=1)
-        weighted_depth = (depth_probs * self.depth_bin_values.reshape(1, -1, 1, 1)).sum(dim=1)
+        if FUSED_EXPECTATION:
+            weighted_depth = depth_expectation(depth_logits, self.depth_bin_values)      # softmax over the bins x bin centres, summed
+        else:
+            weighted_depth = (F.softmax(depth_logits, dim=1) * self.depth_bin_values.reshape(1, -1, 1, 1)).sum(dim=1)
 
         B, C, H, W = src.shape
         tokens = src.flatten(2).permute(2, 0, 1)

@@ -9,7 +9,7 @@ _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmono
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
-           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32")
+           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32")
 _lib = None
 
 
@@ -67,6 +67,10 @@ def load():
         lib.mono_ddn_loss_fwd_f32.argtypes = [P] * 5 + [I] * 5 + [LL] * 3 + [F] * 6 + [P]
         lib.mono_ddn_loss_bwd_f32.restype = I
         lib.mono_ddn_loss_bwd_f32.argtypes = [P] * 6 + [I] * 5 + [LL] * 3 + [F] * 6 + [P]
+        lib.mono_depth_expect_fwd_f32.restype = I
+        lib.mono_depth_expect_fwd_f32.argtypes = [P] * 3 + [I] * 4 + [LL] * 3 + [P]
+        lib.mono_depth_expect_bwd_f32.restype = I
+        lib.mono_depth_expect_bwd_f32.argtypes = [P] * 5 + [I] * 4 + [LL] * 3 + [P]
         _lib = lib
     return _lib
 
@@ -610,3 +614,40 @@ class _DDNLoss(torch.autograd.Function):
 def ddn_loss(logits, boxes, depth, valid, alpha, gamma, fg_weight, bg_weight, depth_min=1e-3, depth_max=60.0):
     return _DDNLoss.apply(logits, boxes, depth, valid, float(alpha), float(gamma), float(fg_weight), float(bg_weight),
                           float(depth_min), float(depth_max))
+
+
+# ---- expected depth over the bin distribution (csrc/ddn_loss.hip) ------------------------------------------------------------
+class _DepthExpectation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, values):
+        B, C, H, W = logits.shape
+        sb, sc, sp = _ddn_strides(logits)
+        values = values.contiguous()
+        out = torch.empty((B, H, W), dtype=torch.float32, device=logits.device)
+        code = load().mono_depth_expect_fwd_f32(logits.data_ptr(), values.data_ptr(), out.data_ptr(), B, C, H, W, sb, sc, sp,
+                                                torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_depth_expect_fwd_f32 failed with code %d" % code)
+        ctx.save_for_backward(logits, values, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, values, out = ctx.saved_tensors
+        B, C, H, W = logits.shape
+        sb, sc, sp = _ddn_strides(logits)
+        grad = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=logits.device)
+        code = load().mono_depth_expect_bwd_f32(logits.data_ptr(), values.data_ptr(), out.data_ptr(), g.contiguous().data_ptr(),
+                                                grad.data_ptr(), B, C, H, W, sb, sc, sp, torch.cuda.current_stream().cuda_stream)
+        if code:
+            raise RuntimeError("mono_depth_expect_bwd_f32 failed with code %d" % code)
+        return grad, None
+
+
+def depth_expectation(logits, values):
+    """``(softmax(logits, 1) * values.view(1, -1, 1, 1)).sum(1)`` (depth_predictor.py:90-91) -- one HIP kernel each way for
+    float32 CUDA logits [B, C, H, W] (NCHW or channels-last), the PyTorch expression otherwise."""
+    if logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 4 and _ddn_strides(logits) is not None \
+            and values.dtype == torch.float32 and not values.requires_grad:
+        return _DepthExpectation.apply(logits, values)
+    return (torch.softmax(logits, dim=1) * values.reshape(1, -1, 1, 1)).sum(dim=1)

@@ -368,3 +368,28 @@ def test_ddn_loss_kernels_at_the_training_shape_with_extreme_logits():
     assert abs(got.item() - expect.item()) <= 2e-5 * abs(expect.item()), (got.item(), expect.item())
     err = (z.grad.cpu().double() - ref.grad).abs().max().item()
     assert err <= 1e-5 * ref.grad.abs().max().item(), err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_depth_expectation_kernels_equal_the_pytorch_expression(channels_last):
+    """weighted_depth = sum_c softmax(logits)_c * bin_value_c (depth_predictor.py:90-91): the HIP kernels against float64
+    autograd through the PyTorch expression; the depth-predictor fixture test pins the same path to the reference."""
+    from monosowa_amd.pointwise import depth_expectation
+    gen = torch.Generator().manual_seed(9)
+    logits = torch.randn(4, 81, 24, 80, generator=gen) * 6
+    values = torch.cat([torch.linspace(0.01, 59.0, 80), torch.tensor([60.0])])
+    ref = logits.double().requires_grad_(True)
+    expect = (torch.softmax(ref, 1) * values.double().view(1, -1, 1, 1)).sum(1)
+    w = torch.randn(4, 24, 80, generator=gen).double()
+    (expect * w).sum().backward()
+    z = logits.cuda()
+    if channels_last:
+        z = z.contiguous(memory_format=torch.channels_last)
+    z.requires_grad_(True)
+    got = depth_expectation(z, values.cuda())
+    assert "DepthExpectation" in type(got.grad_fn).__name__, "the HIP kernel did not run"
+    (got * w.float().cuda()).sum().backward()
+    assert (got.detach().cpu().double() - expect.detach()).abs().max() <= 2e-6 * expect.abs().max()
+    assert z.grad.stride() == z.stride()
+    assert (z.grad.cpu().double() - ref.grad).abs().max() <= 2e-6 * ref.grad.abs().max()

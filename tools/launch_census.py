@@ -66,6 +66,14 @@ def main():
         print("%-34s %4d x %8.1f us  %s" % (e.key[:34], e.count, e.self_device_time_total, str(e.input_shapes)[:140]))
     if "--stack" in sys.argv:
         stacks(prof)
+    if "--by-time" in sys.argv:
+        print("\n-- glue ops by input shape, by device time")
+        names = ("aten::sum", "aten::copy_", "aten::add", "aten::add_", "aten::mul", "aten::fill_", "aten::cat", "aten::div", "aten::sub", "aten::clamp",
+                 "aten::index", "aten::gather", "aten::where", "aten::sigmoid", "aten::exp", "aten::neg", "aten::mean", "aten::zero_")
+        rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in names and e.self_device_time_total > 0]
+        rows.sort(key=lambda e: -e.self_device_time_total)
+        for e in rows[:70]:
+            print("%-14s %4d x %8.1f us  %s" % (e.key, e.count, e.self_device_time_total, str(e.input_shapes)[:150]))
 
 
 
