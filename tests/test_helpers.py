@@ -435,3 +435,31 @@ def test_folded_weight_cache_is_invalidated_by_optimizer_steps():
         y1 = BB.conv_bn(x, conv, bn, relu=False)
         ref = bn(conv(x))
     assert not torch.allclose(y0, y1) and torch.allclose(y1, ref, atol=1e-6)
+
+
+def test_resnet_body_matches_the_published_architecture():
+    """Row a10: torchvision is absent, so the backbone cannot be pinned to reference OUTPUTS.  What can be pinned are the
+    published facts of torchvision's resnet50 / resnet101 (the models backbone.py:106-108 instantiates): parameter counts
+    without the fc layer (25,557,032 - 2,049,000 and 44,549,160 - 2,049,000), torchvision's state-dict key names (a released
+    checkpoint loads by name), the v1.5 stride placement (stride 2 in the 3x3 convolution of a stage's first block) and the
+    frozen-BN buffers."""
+    from monosowa_amd.monodetr.backbone import ResNetBody
+    for name, want, blocks in (("resnet50", 23508032, (3, 4, 6, 3)), ("resnet101", 42500160, (3, 4, 23, 3))):
+        m = ResNetBody(name)
+        sd = m.state_dict()
+        learnable = sum(v.numel() for k, v in sd.items() if not k.endswith(("running_mean", "running_var")))
+        assert learnable == want, (name, learnable)
+        assert sd["conv1.weight"].shape == (64, 3, 7, 7)
+        for stage, n in zip((1, 2, 3, 4), blocks):
+            layer = getattr(m, "layer%d" % stage)
+            assert len(layer) == n
+            for i, blk in enumerate(layer):
+                prefix = "layer%d.%d." % (stage, i)
+                for k in ("conv1.weight", "bn1.weight", "bn1.bias", "bn1.running_mean", "bn1.running_var", "conv2.weight", "conv3.weight", "bn3.weight"):
+                    assert prefix + k in sd, prefix + k
+                want_stride = 2 if (i == 0 and stage > 1) else 1
+                assert blk.conv1.stride == (1, 1) and blk.conv2.stride == (want_stride, want_stride) and blk.conv2.kernel_size == (3, 3)
+                assert (prefix + "downsample.0.weight" in sd) == (i == 0)
+        width = 64 * 2 ** 3 * 4
+        assert sd["layer4.%d.conv3.weight" % (blocks[3] - 1)].shape[0] == width == 2048
+        assert not any(k.endswith("num_batches_tracked") for k in sd)       # FrozenBatchNorm2d drops it (backbone.py:44-52)
