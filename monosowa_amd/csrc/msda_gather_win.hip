@@ -215,23 +215,25 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? kWinThrea
     for (int k2 = 0; k2 < 2; ++k2) {
       const float lx = k2 ? l4.z : l4.x, ly = k2 ? l4.w : l4.y, wt = k2 ? a2.y : a2.x;
       const Tap<float> tp = make_tap<float>(lx, ly, Hm, Wm);
-      // only corners the reference keeps must be reachable (a dropped corner reads the zero row; a point failing the
-      // cuh:274 test has all four dropped -- tp.l / tp.r do not include that test)
-      const bool inwin = (!tp.t || (tp.y0 >= wy_lo && tp.y0 <= wy_hi)) && (!tp.b || (tp.y1 >= wy_lo && tp.y1 <= wy_hi)) &&
-                         (!tp.l || (tp.x0 >= wx_lo && tp.x0 <= wx_hi)) && (!tp.r || (tp.x1 >= wx_lo && tp.x1 <= wx_hi));
-      // corner -> LDS byte offset (in window), (token << 4) | 1 (outside: global fallback), or the zero row (dropped)
+      // The footprint's clamped corner coordinates against the window: one test for the point (a dropped corner's clamped
+      // coordinate lies next to the kept ones, so this is only stricter at a level border, where the fallback is still right).
+      const bool inwin = tp.y0 >= wy_lo && tp.y1 <= wy_hi && tp.x0 >= wx_lo && tp.x1 <= wx_hi;
+      // corner -> LDS byte offset (in window), kOutside (fetched from global memory in the fix-up pass, which re-derives the
+      // token from the location: rare), or the zero row (a corner the reference drops, a lane without a query)
       const int lds00 = (base_m + (tp.y0 - wy_lo) * ww_m + (tp.x0 - wx_lo)) * 128, ldx = (tp.x1 - tp.x0) * 128,
                 ldy = (tp.y1 - tp.y0) * ww_m * 128;
-      const int mem00 = start_m + tp.y0 * Wm + tp.x0, mdx = tp.x1 - tp.x0, mdy = (tp.y1 - tp.y0) * Wm;
-      auto pick = [&](const int in_lds, const int in_mem, const bool keep) {
-        return (keep && live) ? (inwin ? in_lds : ((in_mem << 4) | 1)) : kZeroOff;
-      };
-      off[k2][0] = pick(lds00, mem00, tp.t && tp.l);
-      off[k2][1] = pick(lds00 + ldx, mem00 + mdx, tp.t && tp.r);
-      off[k2][2] = pick(lds00 + ldy, mem00 + mdy, tp.b && tp.l);
-      off[k2][3] = pick(lds00 + ldy + ldx, mem00 + mdy + mdx, tp.b && tp.r);
+      const int in_or_out = inwin ? 0 : 1;                                  // kOutside = kZeroOff | 1: the row loops read the zero row
+      auto pick = [&](const int in_lds, const bool keep) { return (keep && live) ? (inwin ? in_lds : (kZeroOff | in_or_out)) : kZeroOff; };
+      off[k2][0] = pick(lds00, tp.t && tp.l);
+      off[k2][1] = pick(lds00 + ldx, tp.t && tp.r);
+      off[k2][2] = pick(lds00 + ldy, tp.b && tp.l);
+      off[k2][3] = pick(lds00 + ldy + ldx, tp.b && tp.r);
       if (BWD) { cw[k2][0] = tp.lh; cw[k2][1] = tp.lw; cw[k2][2] = (float)Wm * wt; cw[k2][3] = (float)Hm * wt; }
-      else { cw[k2][0] = tp.w1 * wt; cw[k2][1] = tp.w2 * wt; cw[k2][2] = tp.w3 * wt; cw[k2][3] = tp.w4 * wt; }
+      else {
+        // a dropped corner reads the zero row: its weight need not be zeroed (the products below are finite)
+        const float hw_w = tp.hw * wt, lw_w = tp.lw * wt;
+        cw[k2][0] = tp.hh * hw_w; cw[k2][1] = tp.hh * lw_w; cw[k2][2] = tp.lh * hw_w; cw[k2][3] = tp.lh * lw_w;
+      }
       if (MASKED) {                                                       // corners on padded tokens (coordinates are clamped into the level)
         const unsigned char *mk = vmask + (long long)it.b * S + start_m;
         const int r0 = tp.y0 * Wm, r1 = tp.y1 * Wm;
@@ -312,6 +314,10 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? kWinThrea
       for (int s = 0; s < 4; ++s) vv[s] = *reinterpret_cast<const float4 *>(wbytes + (a ^ ((4 * h + s) * 16)));
     };
     const bool outside = ((off[0][0] | off[0][1] | off[0][2] | off[0][3] | off[1][0] | off[1][1] | off[1][2] | off[1][3]) & 1) != 0;
+    auto outside_token = [&](const int k2, const int c) {                 // value token of corner c of this lane's point k2 (cold path)
+      const Tap<float> tp = make_tap<float>(k2 ? l4.z : l4.x, k2 ? l4.w : l4.y, Hm, Wm);
+      return start_m + ((c & 2) ? tp.y1 : tp.y0) * Wm + ((c & 1) ? tp.x1 : tp.x0);
+    };
 
     if (!BWD) {
       float4 acc[8];
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? kWinThrea
           for (int c = 0; c < 4; ++c)
             if (off[k2][c] & 1) {
               const float w = cw[k2][c];
-              const float *p = value_bm + (long long)(off[k2][c] >> 4) * tok;
+              const float *p = value_bm + (long long)outside_token(k2, c) * tok;
 #pragma unroll
               for (int s = 0; s < 8; ++s) {
                 const float4 x = ld4(p + 4 * (s ^ rot));
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? kWinThrea
 #pragma unroll
           for (int c = 0; c < 4; ++c)
             if (off[k2][c] & 1) {
-              const float *p = value_bm + (long long)(off[k2][c] >> 4) * tok;
+              const float *p = value_bm + (long long)outside_token(k2, c) * tok;
 #pragma unroll
               for (int s = 0; s < 8; ++s) {
                 const float4 x = ld4(p + 4 * (s ^ rot));
