@@ -5,8 +5,8 @@ cd /tmp && export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 mkdir -p $OUT
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/a -- python3 $GRAFT_REPO_ROOT/tools/msda_kernel_bench.py --kinds enc --iters 3 --warmup 1 > $OUT/a.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -- python3 $GRAFT_REPO_ROOT/tools/msda_kernel_bench.py --kinds enc --iters 3 --warmup 1 > $OUT/b.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/a -- python3 $GRAFT_REPO_ROOT/tools/msda_fused_bench.py --kinds enc --iters 3 --warmup 1 > $OUT/a.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -- python3 $GRAFT_REPO_ROOT/tools/msda_fused_bench.py --kinds enc --iters 3 --warmup 1 > $OUT/b.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 for sub in ("a", "b"):
