@@ -35,6 +35,7 @@
 
 namespace msda {
 
+typedef float v2f __attribute__((ext_vector_type(2)));        // packed pair: v_pk_fma_f32 does two FMAs per lane and issue slot
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void global_cvoid_t;
 
@@ -434,14 +435,19 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? kWinThrea
           for (int h = 0; h < 2; ++h) {
             float4 vv[4];
             half_row(off[k2][c], h, vv);
-            float dx = 0.f, dy = 0.f;                                     // two partial sums: independent FMA chains
+            // 16 products as 8 packed FMAs into two pair accumulators (independent chains), then three adds: the backward has
+            // the registers for aligned pairs (8-wave workgroups), and instruction issue is what bounds these loops
+            v2f pa = (v2f){0.f, 0.f}, pb = (v2f){0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 4; s += 2) {
               const float4 ga = gq[4 * h + s], gb = gq[4 * h + s + 1];
-              dx += ga.x * vv[s].x + ga.y * vv[s].y + ga.z * vv[s].z + ga.w * vv[s].w;
-              dy += gb.x * vv[s + 1].x + gb.y * vv[s + 1].y + gb.z * vv[s + 1].z + gb.w * vv[s + 1].w;
+              pa = __builtin_elementwise_fma((v2f){ga.x, ga.y}, (v2f){vv[s].x, vv[s].y}, pa);
+              pa = __builtin_elementwise_fma((v2f){ga.z, ga.w}, (v2f){vv[s].z, vv[s].w}, pa);
+              pb = __builtin_elementwise_fma((v2f){gb.x, gb.y}, (v2f){vv[s + 1].x, vv[s + 1].y}, pb);
+              pb = __builtin_elementwise_fma((v2f){gb.z, gb.w}, (v2f){vv[s + 1].z, vv[s + 1].w}, pb);
             }
-            d[k2][c] += dx + dy;                                          // dropped corner: zero row -> 0 (cuh:114-152)
+            pa += pb;
+            d[k2][c] += pa.x + pa.y;                                      // dropped corner: zero row -> 0 (cuh:114-152)
             // one half row (4 loads) at a time: the dot product has to be finished HERE (the asm consumes it), before the
             // next loads -- otherwise the compiler loads many rows first and packs the products across corners
             asm volatile("" : "+v"(d[k2][c]) : : "memory");
