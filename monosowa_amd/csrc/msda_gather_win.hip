@@ -57,7 +57,7 @@ typedef __attribute__((address_space(1))) const void global_cvoid_t;
 // corner weights (forward) / the corner dot products (backward) of the lane that owns the point.  `vts`: floats between
 // consecutive value tokens.
 template <bool BWD, bool FUSED, bool SAVED = false, bool MASKED = false>
-__global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? kWinThreadsBwd / 256 : 4) void gather_win_kernel(
+__global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThreadsBwd + 255) / 256 : 4) void gather_win_kernel(
     const float *__restrict__ value, const float *__restrict__ loc, const float *__restrict__ attw,
     const float *__restrict__ grad_out, float *__restrict__ out, float *__restrict__ grad_loc,
     float *__restrict__ grad_attw, const float *__restrict__ ref, int ref_dim, const WinTable g, int B, int S, int M,

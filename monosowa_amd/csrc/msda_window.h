@@ -17,9 +17,10 @@ namespace msda {
 constexpr int kWinLevels = 4;
 constexpr int kWinThreads = 1024;                    // forward: 16 waves, one workgroup per CU owns the LDS
 #ifndef MSDA_WIN_THREADS_BWD
-#define MSDA_WIN_THREADS_BWD 512
+#define MSDA_WIN_THREADS_BWD 768
 #endif
-constexpr int kWinThreadsBwd = MSDA_WIN_THREADS_BWD;  // backward: 8 waves = 256 VGPRs per lane (grad_out row + prefetch do not fit 128)
+constexpr int kWinThreadsBwd = MSDA_WIN_THREADS_BWD;  // backward: 12 waves = 170 VGPRs per lane (grad_out row + prefetch need ~157;
+                                                      // measured 1.11 ms per backward with 8 waves, 1.07 with 12; 16 waves would spill)
 constexpr int kWinPairsPerPass = kWinThreads / 8;    // 128 (query, head) pairs in flight
 constexpr int kWinMaxPasses = 2;                     // queries of a tile <= 256
 constexpr int kWinLdsBudget = 160 * 1024 - 128 - 256;    // - the zero row
