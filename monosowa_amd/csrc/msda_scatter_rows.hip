@@ -21,6 +21,8 @@
 
 namespace msda {
 
+typedef float rows_v2f __attribute__((ext_vector_type(2)));      // packed pair: v_pk_fma_f32
+
 // Workgroup barrier for LDS hand-offs that leaves global loads in flight: __syncthreads() carries a workgroup-scope fence
 // that lowers to s_waitcnt vmcnt(0) as well, i.e. every barrier would wait for the next batch's prefetch.
 __device__ __forceinline__ void lds_barrier() {
@@ -92,9 +94,11 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
   const int r = tid >> 1, half = tid & 1;                  // gather role: row of the tile, half of its 32 channels
   if (tid < kRowTileRows) count[tid] = 0;
   if (tid == 0) overflow = 0;
-  float4 acc[4];
+  // this lane's 16 channel sums as 8 packed pairs: a hit costs 8 v_pk_fma_f32 instead of 16 v_fmac_f32 (the bucket walk is
+  // bound by instruction issue and LDS latency, not by arithmetic)
+  rows_v2f ap[8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < 8; ++i) ap[i] = (rows_v2f){0.f, 0.f};
 
   // The scan is a chain of two dependent memory round trips per batch (candidate -> point).  Candidate entries are read two
   // batches ahead; a batch's points are requested as soon as the previous batch's inputs have been turned into taps, so the
@@ -218,7 +222,8 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) {
             const float4 a = g4[kk ^ sw];
-            acc[kk].x += w * a.x; acc[kk].y += w * a.y; acc[kk].z += w * a.z; acc[kk].w += w * a.w;
+            ap[2 * kk] = __builtin_elementwise_fma((rows_v2f){w, w}, (rows_v2f){a.x, a.y}, ap[2 * kk]);
+            ap[2 * kk + 1] = __builtin_elementwise_fma((rows_v2f){w, w}, (rows_v2f){a.z, a.w}, ap[2 * kk + 1]);
           }
         }
         if (half == 0) count[r] = 0;         // the row's two lanes sit in one wave: both have read it
@@ -234,6 +239,9 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
   }
 
   // ---- write the tile -------------------------------------------------------------------------------------------------
+  float4 acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc[k] = make_float4(ap[2 * k].x, ap[2 * k].y, ap[2 * k + 1].x, ap[2 * k + 1].y);
   const long long tok0 = (long long)b * S + p.start[l];
   if (n_chunks == 1) {
     if (r < n_rows) {
