@@ -518,7 +518,7 @@ def test_fused_prologue_matches_the_unfused_operator(ref_dim):
     assert _lib.load().msda_fused_forward_f32(1, 1, 1, 1, 1, 1, 3, 1, 1, 1, 1, 32, 4, 1, 4, 1, 1, None) == -3
 
 
-@pytest.mark.parametrize("B,M,ref_dim", [(3, 5, 2), (1, 3, 2), (2, 8, 6)])
+@pytest.mark.parametrize("B,M,ref_dim", [(3, 5, 2), (1, 3, 2), (2, 8, 6), (2, 8, -2)])
 def test_fused_self_attention_shape_odd_planes_and_6d_reference_points(B, M, ref_dim):
     """Lq == S (the window / row-tile kernels' shape) with (batch x head) counts that are not multiples of 8 -- the persistent
     workgroups walk a padded item list -- and with 6-d reference points, which the window kernels do not evaluate: the
@@ -539,6 +539,11 @@ def test_fused_self_attention_shape_odd_planes_and_6d_reference_points(B, M, ref
     offsets = (torch.randn(B, Lq, M, L, P, 2, device="cuda") * 2.5).requires_grad_(True)
     logits = torch.randn(B, Lq, M, L * P, device="cuda", requires_grad=True)
     ref = centres[None, :, None, :].expand(B, Lq, L, 2)
+    if ref_dim == -2:
+        # Lq == S but the queries are NOT at their tokens' pixels: the windows and the near-point scan are then useless (almost
+        # every tap is fetched from global memory, almost every point is "far" and goes through the atomics) -- never wrong
+        ref_dim = 2
+        ref = torch.rand(B, Lq, L, 2, device="cuda")
     if ref_dim == 6:
         ref = torch.cat([ref, torch.rand(B, Lq, L, 4, device="cuda") * 0.2], -1)
     ref = ref.contiguous()
