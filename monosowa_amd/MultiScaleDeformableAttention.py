@@ -108,13 +108,14 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
         host_geom = getattr(spatial_shapes, "_msda_host_geometry", None) or (None, None)
     timer = LaunchTimer.active
     with torch.cuda.device(value.device):
-        stream = torch.cuda.current_stream()
+        stream = torch.cuda.current_stream() if timer is not None else None      # (a Stream object only for the events)
+        raw = _lib.raw_stream()
         if timer is not None:
             e0, e1 = timer.bracket("fwd", (B, S, M, D, L, Lq, P))
             e0.record(stream)
         code = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                   sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
-                  B, S, M, D, L, Lq, P, host_geom[0], host_geom[1], stream.cuda_stream)
+                  B, S, M, D, L, Lq, P, host_geom[0], host_geom[1], raw)
         if timer is not None:
             e1.record(stream)
     _lib.check(code, "ms_deform_attn_forward")
@@ -162,7 +163,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         host_geom = host_geometry(spatial_shapes, level_start_index) if ws_bytes else (None, None)
     timer = LaunchTimer.active
     with torch.cuda.device(value.device):
-        stream = torch.cuda.current_stream()
+        stream = torch.cuda.current_stream() if timer is not None else None      # (a Stream object only for the events)
+        raw = _lib.raw_stream()
         if timer is not None:
             e0, e1 = timer.bracket("bwd", (B, S, M, D, L, Lq, P))
             e0.record(stream)
@@ -170,7 +172,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                   sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
                   grad_value.data_ptr(), grad_loc.data_ptr(), grad_w.data_ptr(),
                   B, S, M, D, L, Lq, P, host_geom[0], host_geom[1],
-                  ws.data_ptr() if ws is not None else None, ws_bytes, stream.cuda_stream)
+                  ws.data_ptr() if ws is not None else None, ws_bytes, raw)
         if timer is not None:
             e1.record(stream)
     _lib.check(code, "ms_deform_attn_backward")
@@ -204,14 +206,15 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, sampl
     out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
     timer = LaunchTimer.active
     with torch.cuda.device(value.device):
-        stream = torch.cuda.current_stream()
+        stream = torch.cuda.current_stream() if timer is not None else None      # (a Stream object only for the events)
+        raw = _lib.raw_stream()
         if timer is not None:
             e0, e1 = timer.bracket("fwd", (B, S, M, D, L, Lq, P))
             e0.record(stream)
         code = _lib.load().msda_fused_forward_f32(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_offsets.data_ptr(),
             attention_logits.data_ptr(), reference_points.data_ptr(), reference_points.size(3), out.data_ptr(),
-            B, S, M, D, L, Lq, P, geom[0], geom[1], stream.cuda_stream)
+            B, S, M, D, L, Lq, P, geom[0], geom[1], raw)
         if timer is not None:
             e1.record(stream)
     _lib.check(code, "ms_deform_attn_fused_forward")
@@ -232,7 +235,8 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, samp
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
     timer = LaunchTimer.active
     with torch.cuda.device(value.device):
-        stream = torch.cuda.current_stream()
+        stream = torch.cuda.current_stream() if timer is not None else None      # (a Stream object only for the events)
+        raw = _lib.raw_stream()
         if timer is not None:
             e0, e1 = timer.bracket("bwd", (B, S, M, D, L, Lq, P))
             e0.record(stream)
@@ -240,7 +244,7 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, samp
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_offsets.data_ptr(),
             attention_logits.data_ptr(), reference_points.data_ptr(), reference_points.size(3), grad_output.data_ptr(),
             grad_value.data_ptr(), grad_off.data_ptr(), grad_logits.data_ptr(), B, S, M, D, L, Lq, P, geom[0], geom[1],
-            ws.data_ptr(), ws_bytes, stream.cuda_stream)
+            ws.data_ptr(), ws_bytes, raw)
         if timer is not None:
             e1.record(stream)
     _lib.check(code, "ms_deform_attn_fused_backward")
@@ -281,7 +285,8 @@ def _fused_forward_view(value, spatial_shapes, level_start_index, proj, referenc
     attw = torch.empty((B, M, L, Lq, P), dtype=value.dtype, device=value.device) if save else None
     timer = LaunchTimer.active
     with torch.cuda.device(value.device):
-        stream = torch.cuda.current_stream()
+        stream = torch.cuda.current_stream() if timer is not None else None      # (a Stream object only for the events)
+        raw = _lib.raw_stream()
         if timer is not None:
             e0, e1 = timer.bracket("fwd", (B, S, M, D, L, Lq, P))
             e0.record(stream)
@@ -289,7 +294,7 @@ def _fused_forward_view(value, spatial_shapes, level_start_index, proj, referenc
             value.data_ptr(), ts, mask_ptr, spatial_shapes.data_ptr(), level_start_index.data_ptr(), proj.data_ptr(),
             proj.data_ptr() + M * 32 * 4, reference_points.data_ptr(), reference_points.size(3), out.data_ptr(),
             loc.data_ptr() if save else None, attw.data_ptr() if save else None, B, S, M, D, L, Lq, P, M * 48, M * 48,
-            geom[0], geom[1], stream.cuda_stream)
+            geom[0], geom[1], raw)
         if timer is not None:
             e1.record(stream)
     _lib.check(code, name)
@@ -310,7 +315,8 @@ def _fused_backward_view(value, spatial_shapes, level_start_index, a, b, saved, 
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
     timer = LaunchTimer.active
     with torch.cuda.device(value.device):
-        stream = torch.cuda.current_stream()
+        stream = torch.cuda.current_stream() if timer is not None else None      # (a Stream object only for the events)
+        raw = _lib.raw_stream()
         if timer is not None:
             e0, e1 = timer.bracket("bwd", (B, S, M, D, L, Lq, P))
             e0.record(stream)
@@ -318,7 +324,7 @@ def _fused_backward_view(value, spatial_shapes, level_start_index, a, b, saved, 
             value.data_ptr(), ts, mask_ptr, spatial_shapes.data_ptr(), level_start_index.data_ptr(), a.data_ptr(), b.data_ptr(),
             1 if saved else 0, reference_points.data_ptr(), reference_points.size(3), grad_output.data_ptr(), grad_value.data_ptr(),
             grad_proj.data_ptr(), grad_proj.data_ptr() + M * 32 * 4, B, S, M, D, L, Lq, P, M * 48, M * 48, geom[0], geom[1],
-            ws.data_ptr(), ws_bytes, stream.cuda_stream)
+            ws.data_ptr(), ws_bytes, raw)
         if timer is not None:
             e1.record(stream)
     _lib.check(code, name)

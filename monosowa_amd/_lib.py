@@ -79,3 +79,11 @@ def check(code, what):
 
 def set_option(name, value):
     check(load().msda_set_option(name.encode(), int(value)), "msda_set_option(%s, %s)" % (name, value))
+
+
+def raw_stream():
+    """The current HIP stream handle of the current device as an integer (what the C-ABI entry points take): the raw accessor
+    costs 0.1 us where ``torch.cuda.current_stream().cuda_stream`` builds a Stream object for 2.7 us -- on every launch of the
+    host-bound stretch of a train step."""
+    import torch
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())

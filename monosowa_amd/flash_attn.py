@@ -6,6 +6,8 @@ import os
 
 import torch
 
+from ._lib import raw_stream
+
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_attn.so")
 SYMBOLS = ("mono_attn_forward_f32", "mono_attn_backward_f32")
 _lib = None
@@ -59,7 +61,7 @@ def forward(q, k, v, scale, p, seed):
     with torch.cuda.device(q.device):
         code = load().mono_attn_forward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Lq,
                                             k.size(2), 32, _strides(q), _strides(k), _strides(v), _strides(o), float(scale),
-                                            float(p), seed, torch.cuda.current_stream().cuda_stream)
+                                            float(p), seed, raw_stream())
     if code:
         raise RuntimeError("mono_attn_forward_f32 failed with code %d" % code)
     return o, lse
@@ -77,7 +79,7 @@ def backward(q, k, v, o, lse, dout, scale, p, seed):
         code = load().mono_attn_backward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), dout.data_ptr(),
                                              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Lq, Lk, 32,
                                              _strides(q), _strides(k), _strides(v), _strides(o), _strides(dq), _strides(dk),
-                                             _strides(dv), float(scale), float(p), seed, torch.cuda.current_stream().cuda_stream)
+                                             _strides(dv), float(scale), float(p), seed, raw_stream())
     if code:
         raise RuntimeError("mono_attn_backward_f32 failed with code %d" % code)
     return dq, dk, dv
@@ -95,7 +97,7 @@ class _Attention(torch.autograd.Function):
         with torch.cuda.device(q.device):
             code = load().mono_attn_forward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Lq,
                                                 k.size(2), 32, _strides(q), _strides(k), _strides(v), _strides(o), float(scale),
-                                                float(p), seed, torch.cuda.current_stream().cuda_stream)
+                                                float(p), seed, raw_stream())
         if code:
             raise RuntimeError("mono_attn_forward_f32 failed with code %d" % code)
         ctx.save_for_backward(q, k, v, o, lse)

@@ -5,6 +5,8 @@ import os
 
 import torch
 
+from ._lib import raw_stream
+
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
@@ -90,7 +92,7 @@ class _BiasAct(torch.autograd.Function):
         res_ptr = residual.data_ptr() if residual is not None else None
         mask = None
         with torch.cuda.device(y.device):
-            st = torch.cuda.current_stream().cuda_stream
+            st = raw_stream()
             if relu and USE_RELU_MASK and (y.requires_grad or (residual is not None and residual.requires_grad)):
                 mask = torch.empty(y.numel() // 4, dtype=torch.uint8, device=y.device)
                 code = load().mono_bias_relu_mask_f32(y.data_ptr(), bias.data_ptr(), res_ptr, mask.data_ptr(), rows, y.size(1), st)
@@ -116,10 +118,10 @@ class _BiasAct(torch.autograd.Function):
             with torch.cuda.device(y.device):
                 if ctx.masked:
                     code = load().mono_relu_grad_mask_f32(grad.data_ptr(), None, y.data_ptr(), g.data_ptr(), grad.numel(),
-                                                          torch.cuda.current_stream().cuda_stream)
+                                                          raw_stream())
                 else:
                     code = load().mono_relu_grad_f32(grad.data_ptr(), y.data_ptr(), g.data_ptr(), grad.numel(),
-                                                     torch.cuda.current_stream().cuda_stream)
+                                                     raw_stream())
             if code:
                 raise RuntimeError("mono_relu_grad_f32 failed with code %d" % code)
         else:
@@ -137,7 +139,7 @@ class _AffineRelu(torch.autograd.Function):
         mask = torch.empty(y.numel() // 4, dtype=torch.uint8, device=y.device)
         with torch.cuda.device(y.device):
             code = load().mono_affine_relu_mask_f32(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), mask.data_ptr(), rows, C,
-                                                    torch.cuda.current_stream().cuda_stream)
+                                                    raw_stream())
         if code:
             raise RuntimeError("mono_affine_relu_mask_f32 failed with code %d" % code)
         ctx.mark_dirty(y)
@@ -151,7 +153,7 @@ class _AffineRelu(torch.autograd.Function):
         g = torch.empty_like(grad, memory_format=torch.channels_last)
         with torch.cuda.device(grad.device):
             code = load().mono_affine_relu_grad_f32(grad.data_ptr(), mask.data_ptr(), scale.data_ptr(), g.data_ptr(),
-                                                    grad.numel() // grad.size(1), grad.size(1), torch.cuda.current_stream().cuda_stream)
+                                                    grad.numel() // grad.size(1), grad.size(1), raw_stream())
         if code:
             raise RuntimeError("mono_affine_relu_grad_f32 failed with code %d" % code)
         return g, None, None
@@ -175,7 +177,7 @@ class _BiasActFork(torch.autograd.Function):
         rows = y.numel() // y.size(1)
         mask = torch.empty(y.numel() // 4, dtype=torch.uint8, device=y.device) if USE_RELU_MASK else None
         with torch.cuda.device(y.device):
-            st = torch.cuda.current_stream().cuda_stream
+            st = raw_stream()
             if mask is not None:
                 code = load().mono_bias_relu_mask_f32(y.data_ptr(), bias.data_ptr(), residual.data_ptr(), mask.data_ptr(), rows, y.size(1), st)
             else:
@@ -197,7 +199,7 @@ class _BiasActFork(torch.autograd.Function):
         g = torch.empty(ctx.shape, dtype=torch.float32, device=y.device, memory_format=torch.channels_last)
         n = g.numel()
         with torch.cuda.device(y.device):
-            st = torch.cuda.current_stream().cuda_stream
+            st = raw_stream()
             if ga is not None and gb is not None:
                 ga, gb = cl(ga), cl(gb)
                 if ctx.masked:
@@ -262,7 +264,7 @@ def ln_forward(x, z, weight, bias, p, eps):
     with torch.cuda.device(x.device):
         code = load().mono_dropout_add_layernorm_fwd_f32(
             x.data_ptr(), z.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), s.data_ptr(), mean.data_ptr(),
-            rstd.data_ptr(), rows, 256, float(p), seed, float(eps), torch.cuda.current_stream().cuda_stream)
+            rstd.data_ptr(), rows, 256, float(p), seed, float(eps), raw_stream())
     if code:
         raise RuntimeError("mono_dropout_add_layernorm_fwd_f32 failed with code %d" % code)
     return y, s, mean, rstd, seed
@@ -278,7 +280,7 @@ def ln_backward(gy, s, mean, rstd, weight, p, seed):
     with torch.cuda.device(s.device):
         code = load().mono_dropout_add_layernorm_bwd_f32(
             gy.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), weight.data_ptr(), gx.data_ptr(), gz.data_ptr(),
-            gw.data_ptr(), partials.data_ptr(), rows, 256, float(p), seed, torch.cuda.current_stream().cuda_stream)
+            gw.data_ptr(), partials.data_ptr(), rows, 256, float(p), seed, raw_stream())
     if code:
         raise RuntimeError("mono_dropout_add_layernorm_bwd_f32 failed with code %d" % code)
     return gx, gz, gw[0], gw[1]
@@ -324,7 +326,7 @@ class _GroupNormNHWC(torch.autograd.Function):
             code = load().mono_groupnorm_nhwc_fwd_f32(x.data_ptr(), pre_bias.data_ptr() if pre_bias is not None else None,
                                                       weight.data_ptr(), bias.data_ptr(), y.data_ptr(), stats.data_ptr(),
                                                       mean_rstd.data_ptr(), B, H * W, C, 32, float(eps), int(relu),
-                                                      torch.cuda.current_stream().cuda_stream)
+                                                      raw_stream())
         if code:
             raise RuntimeError("mono_groupnorm_nhwc_fwd_f32 failed with code %d" % code)
         ctx.relu = relu
@@ -348,7 +350,7 @@ class _GroupNormNHWC(torch.autograd.Function):
             code = lib.mono_groupnorm_nhwc_bwd_f32(gy.data_ptr(), x.data_ptr(), ptr(pre_bias), ptr(y if ctx.relu else None),
                                                    mean_rstd.data_ptr(), weight.data_ptr(), gx.data_ptr(), part.data_ptr(),
                                                    ptr(gbias), ptr(partials), B, H * W, C, 32, int(ctx.relu),
-                                                   torch.cuda.current_stream().cuda_stream)
+                                                   raw_stream())
         if code:
             raise RuntimeError("mono_groupnorm_nhwc_bwd_f32 failed with code %d" % code)
         gwb = part.sum(0).float()
@@ -386,7 +388,7 @@ def colsum_levels(g3, bounds):
     out = torch.empty((len(bounds), C), dtype=torch.float32, device=g3.device)
     lib = load()
     with torch.cuda.device(g3.device):
-        st = torch.cuda.current_stream().cuda_stream
+        st = raw_stream()
         for i, (a, b) in enumerate(bounds):
             partials = torch.empty(lib.mono_reduce_blocks(B * (b - a)) * C, dtype=torch.float32, device=g3.device)
             code = lib.mono_colsum_strided_f32(g3.data_ptr() + a * C * 4, out[i].data_ptr(), partials.data_ptr(), B, b - a, S * C, C, st)
@@ -407,7 +409,7 @@ def colsum(g2):
         partials = torch.empty(load().mono_reduce_blocks(g2.size(0)) * g2.size(1), dtype=torch.float32, device=g2.device)
         with torch.cuda.device(g2.device):
             code = load().mono_colsum_f32(g2.data_ptr(), out.data_ptr(), partials.data_ptr(), g2.size(0), g2.size(1),
-                                          torch.cuda.current_stream().cuda_stream)
+                                          raw_stream())
         if code:
             raise RuntimeError("mono_colsum_f32 failed with code %d" % code)
         return out
@@ -463,7 +465,7 @@ class FusedAdamWPlan:
         self.copied.record()
         with torch.cuda.device(self.device):
             code = load().mono_adamw_step_f32(self.dev.data_ptr(), self.n_chunks, beta1, beta2, eps, step_size,
-                                              torch.cuda.current_stream().cuda_stream)
+                                              raw_stream())
         if code:
             raise RuntimeError("mono_adamw_step_f32 failed with code %d" % code)
 
@@ -473,7 +475,7 @@ def relu_dropout_forward(h, p):
     h = h.contiguous()
     y = torch.empty_like(h)
     with torch.cuda.device(h.device):
-        code = load().mono_relu_dropout_fwd_f32(h.data_ptr(), y.data_ptr(), h.numel(), float(p), _next_seed(), torch.cuda.current_stream().cuda_stream)
+        code = load().mono_relu_dropout_fwd_f32(h.data_ptr(), y.data_ptr(), h.numel(), float(p), _next_seed(), raw_stream())
     if code:
         raise RuntimeError("mono_relu_dropout_fwd_f32 failed with code %d" % code)
     return y
@@ -483,7 +485,7 @@ def relu_dropout_backward(gy, y, p):
     gy = gy.contiguous()
     gh = torch.empty_like(y)
     with torch.cuda.device(y.device):
-        code = load().mono_relu_dropout_bwd_f32(gy.data_ptr(), y.data_ptr(), gh.data_ptr(), y.numel(), float(p), torch.cuda.current_stream().cuda_stream)
+        code = load().mono_relu_dropout_bwd_f32(gy.data_ptr(), y.data_ptr(), gh.data_ptr(), y.numel(), float(p), raw_stream())
     if code:
         raise RuntimeError("mono_relu_dropout_bwd_f32 failed with code %d" % code)
     return gh
@@ -526,7 +528,7 @@ class _MatchedLosses(torch.autograd.Function):
         tensors = (boxes, depth, dims, angle, idx, t_box, t_depth, t_size, t_bin, t_res)
         with torch.cuda.device(boxes.device):
             code = load().mono_matched_losses_fwd_f32(*[t.data_ptr() for t in tensors], out.data_ptr(), comp.data_ptr(), NL, B, Q, K,
-                                                      torch.cuda.current_stream().cuda_stream)
+                                                      raw_stream())
         if code:
             raise RuntimeError("mono_matched_losses_fwd_f32 failed with code %d" % code)
         ctx.save_for_backward(*tensors, comp)
@@ -547,7 +549,7 @@ class _MatchedLosses(torch.autograd.Function):
         with torch.cuda.device(boxes.device):
             code = load().mono_matched_losses_bwd_f32(*[t.data_ptr() for t in tensors], comp.data_ptr(), go.data_ptr(),
                                                       g_boxes.data_ptr(), g_depth.data_ptr(), g_dims.data_ptr(), g_angle.data_ptr(),
-                                                      NL, B, Q, K, torch.cuda.current_stream().cuda_stream)
+                                                      NL, B, Q, K, raw_stream())
         if code:
             raise RuntimeError("mono_matched_losses_bwd_f32 failed with code %d" % code)
         return (g_boxes, g_depth, g_dims, g_angle) + (None,) * 6
@@ -589,7 +591,7 @@ class _DDNLoss(torch.autograd.Function):
         partial = torch.empty(lib.mono_ddn_loss_blocks(B, H, W), dtype=torch.float32, device=logits.device)
         code = lib.mono_ddn_loss_fwd_f32(logits.data_ptr(), boxes.data_ptr(), depth.data_ptr(), valid.data_ptr(), partial.data_ptr(),
                                          B, C, H, W, N, sb, sc, sp, alpha, gamma, fg_weight, bg_weight, depth_min, depth_max,
-                                         torch.cuda.current_stream().cuda_stream)
+                                         raw_stream())
         if code:
             raise RuntimeError("mono_ddn_loss_fwd_f32 failed with code %d" % code)
         ctx.save_for_backward(logits, boxes, depth, valid)
@@ -605,7 +607,7 @@ class _DDNLoss(torch.autograd.Function):
         g = g.reshape(1).to(torch.float32).contiguous()
         code = load().mono_ddn_loss_bwd_f32(logits.data_ptr(), boxes.data_ptr(), depth.data_ptr(), valid.data_ptr(), g.data_ptr(),
                                             grad.data_ptr(), B, C, H, W, boxes.shape[1], sb, sc, sp, *ctx.consts,
-                                            torch.cuda.current_stream().cuda_stream)
+                                            raw_stream())
         if code:
             raise RuntimeError("mono_ddn_loss_bwd_f32 failed with code %d" % code)
         return (grad,) + (None,) * 9
@@ -625,7 +627,7 @@ class _DepthExpectation(torch.autograd.Function):
         values = values.contiguous()
         out = torch.empty((B, H, W), dtype=torch.float32, device=logits.device)
         code = load().mono_depth_expect_fwd_f32(logits.data_ptr(), values.data_ptr(), out.data_ptr(), B, C, H, W, sb, sc, sp,
-                                                torch.cuda.current_stream().cuda_stream)
+                                                raw_stream())
         if code:
             raise RuntimeError("mono_depth_expect_fwd_f32 failed with code %d" % code)
         ctx.save_for_backward(logits, values, out)
@@ -638,7 +640,7 @@ class _DepthExpectation(torch.autograd.Function):
         sb, sc, sp = _ddn_strides(logits)
         grad = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=logits.device)
         code = load().mono_depth_expect_bwd_f32(logits.data_ptr(), values.data_ptr(), out.data_ptr(), g.contiguous().data_ptr(),
-                                                grad.data_ptr(), B, C, H, W, sb, sc, sp, torch.cuda.current_stream().cuda_stream)
+                                                grad.data_ptr(), B, C, H, W, sb, sc, sp, raw_stream())
         if code:
             raise RuntimeError("mono_depth_expect_bwd_f32 failed with code %d" % code)
         return grad, None
