@@ -128,6 +128,16 @@ int mono_depth_expect_fwd_f32(const float *logits, const float *values, float *o
 int mono_depth_expect_bwd_f32(const float *logits, const float *values, const float *expect, const float *grad_out, float *grad_logits,
                               int B, int C, int H, int W, long long sb, long long sc, long long sp, void *stream);
 
+/* Classification side of SetCriterion for all decoder layers (monodetr.py:396-449; sigmoid focal loss :302-330).
+ * logits [NL, B, Q, C]; idx [3, NL, K] int64 = (image, query, flat target) of the matched pairs; labels [T] int64; sizes [B]
+ * float targets per image.  out [NL, 3] = { focal-loss SUM over (image, query, class), class_error in %, cardinality_error }.
+ * alpha < 0 disables the alpha weighting.  backward: grad_logits [NL, B, Q, C] = grad_out[l] * d focal / d logit.
+ * Limits: C <= 255, B <= 256, B * Q <= 32768. */
+int mono_focal_fwd_f32(const float *logits, const long long *idx, const long long *labels, const float *sizes, float *out, int NL,
+                       int B, int Q, int C, int K, float alpha, float gamma, void *stream);
+int mono_focal_bwd_f32(const float *logits, const long long *idx, const long long *labels, const float *grad_out, float *grad_logits,
+                       int NL, int B, int Q, int C, int K, float alpha, float gamma, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,4 +167,106 @@ __global__ __launch_bounds__(256) void matched_bwd_kernel(const MatchedArgs a, c
   }
 }
 
+// ---- classification side of the criterion for all decoder layers (monodetr.py:396-449, sigmoid_focal_loss :302-330) -------------
+//   out[l] = { sum over (image, query, class) of the sigmoid focal loss against the matched one-hot targets,
+//              class_error = 100 - top-1 accuracy of the matched queries in %,
+//              cardinality_error = mean over images of | #(queries whose arg-max is not the last class) - #targets | }
+// PyTorch: ~25 small kernels forward (one-hot scatter, sigmoid, BCE, p_t, modulation, alpha weighting, reductions, arg-max
+// bookkeeping) and ~30 backward, in the stretch behind the matcher's synchronisation where every launch is exposed.  One
+// workgroup per layer: the layer's matched (image, query) -> class map lives in LDS.
+constexpr int kFocalThreads = 1024;
+constexpr int kFocalMaxCells = 32768;                 // B * Q cells of the class map (bytes of LDS)
+
+struct FocalArgs {
+  const float *logits;                // [NL, B, Q, C]
+  const long long *idx;               // [3, NL, K]: image, query, flat target
+  const long long *labels;            // [T] class of every target
+  const float *sizes;                 // [B] targets per image (cardinality)
+  int NL, B, Q, C, K;
+  float alpha, gamma;
+};
+
+__device__ __forceinline__ void focal_class_map(const FocalArgs &a, int l, unsigned char *cls) {
+  const int cells = a.B * a.Q;
+  for (int i = threadIdx.x; i < cells; i += kFocalThreads) cls[i] = (unsigned char)a.C;          // C = "no object"
+  __syncthreads();
+  const long long *bi = a.idx + (long long)l * a.K, *qi = a.idx + ((long long)a.NL + l) * a.K, *ti = a.idx + ((long long)2 * a.NL + l) * a.K;
+  for (int k = threadIdx.x; k < a.K; k += kFocalThreads) cls[bi[k] * a.Q + qi[k]] = (unsigned char)a.labels[ti[k]];
+  __syncthreads();
+}
+
+// focal term of one logit x against target t in {0, 1} and its derivative (alpha < 0: no alpha weighting)
+__device__ __forceinline__ float focal_term(float x, bool t, float alpha, float gamma, float *dfdx) {
+  // log p = -softplus(-x), log(1 - p) = -softplus(x); softplus(z) = max(z, 0) + log1p(exp(-|z|))
+  const float lse = log1pf(expf(-fabsf(x)));
+  const float log_p = -(fmaxf(-x, 0.f) + lse), log_1p = -(fmaxf(x, 0.f) + lse);
+  const float p = 1.f / (1.f + expf(-x));
+  const float q = t ? 1.f - p : p;                       // 1 - p_t
+  const float ce = t ? -log_p : -log_1p;
+  const float w = alpha >= 0.f ? (t ? alpha : 1.f - alpha) : 1.f;
+  const float mod = gamma == 2.f ? q * q : powf(q, gamma);
+  if (dfdx) {
+    // d q / dx = -+ p (1 - p); d ce / dx = -(1 - p) (t = 1), p (t = 0)
+    const float dq = t ? -p * (1.f - p) : p * (1.f - p);
+    const float dce = t ? -(1.f - p) : p;
+    const float dmod = gamma == 2.f ? 2.f * q : gamma * powf(q, gamma - 1.f);
+    *dfdx = w * (dmod * dq * ce + mod * dce);
+  }
+  return w * mod * ce;
+}
+
+__global__ __launch_bounds__(kFocalThreads) void focal_fwd_kernel(const FocalArgs a, float *__restrict__ out) {
+  __shared__ unsigned char cls[kFocalMaxCells];
+  __shared__ float red[kFocalThreads / 64];
+  __shared__ int card[256], correct;
+  const int l = blockIdx.x, cells = a.B * a.Q;
+  if (threadIdx.x < 256) card[threadIdx.x] = 0;
+  if (threadIdx.x == 0) correct = 0;
+  focal_class_map(a, l, cls);
+  const float *lg = a.logits + (long long)l * cells * a.C;
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < cells; i += kFocalThreads) {
+    const int t = cls[i];
+    int best = 0;
+    float bv = lg[(long long)i * a.C];
+    for (int c = 0; c < a.C; ++c) {
+      const float x = lg[(long long)i * a.C + c];
+      sum += focal_term(x, c == t, a.alpha, a.gamma, nullptr);
+      if (x > bv) { bv = x; best = c; }                 // first maximum, like torch.argmax
+    }
+    if (best != a.C - 1) atomicAdd(&card[i / a.Q], 1);
+    if (t < a.C && best == t) atomicAdd(&correct, 1);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int w = 0; w < kFocalThreads / 64; ++w) tot += red[w];
+    float ce = 0.f;
+    for (int b = 0; b < a.B; ++b) ce += fabsf((float)card[b] - a.sizes[b]);
+    out[l * 3] = tot;
+    out[l * 3 + 1] = a.K > 0 ? 100.f - (float)correct * (100.f / (float)a.K) : 100.f;
+    out[l * 3 + 2] = ce / (float)a.B;
+  }
+}
+
+// grad_logits[l, b, q, c] = grad_out[l] * d focal / d logit     (grad_out: gradient of the per-layer focal SUM)
+__global__ __launch_bounds__(kFocalThreads) void focal_bwd_kernel(const FocalArgs a, const float *__restrict__ grad_out,
+                                                                  float *__restrict__ grad_logits) {
+  __shared__ unsigned char cls[kFocalMaxCells];
+  const int l = blockIdx.x, cells = a.B * a.Q;
+  focal_class_map(a, l, cls);
+  const float *lg = a.logits + (long long)l * cells * a.C;
+  float *gl = grad_logits + (long long)l * cells * a.C;
+  const float g = grad_out[l];
+  for (int i = threadIdx.x; i < cells * a.C; i += kFocalThreads) {
+    const int cell = i / a.C, c = i - cell * a.C;
+    float d;
+    (void)focal_term(lg[i], c == cls[cell], a.alpha, a.gamma, &d);
+    gl[i] = g * d;
+  }
+}
+
 }  // namespace mono

@@ -657,4 +657,24 @@ int mono_depth_expect_bwd_f32(const float *logits, const float *values, const fl
   return (int)hipGetLastError();
 }
 
+
+// ---- classification side of the criterion (matched_losses.hip): focal sums, class error, cardinality error -----------------
+int mono_focal_fwd_f32(const float *logits, const long long *idx, const long long *labels, const float *sizes, float *out, int NL,
+                       int B, int Q, int C, int K, float alpha, float gamma, void *stream) {
+  if (!logits || !out || !sizes || (K > 0 && (!idx || !labels))) return -1;
+  if (NL <= 0 || B <= 0 || Q <= 0 || C <= 0 || C > 255 || K < 0 || B > 256 || (long long)B * Q > mono::kFocalMaxCells) return -2;
+  const mono::FocalArgs a{logits, idx, labels, sizes, NL, B, Q, C, K, alpha, gamma};
+  mono::focal_fwd_kernel<<<NL, mono::kFocalThreads, 0, (hipStream_t)stream>>>(a, out);
+  return (int)hipGetLastError();
+}
+
+int mono_focal_bwd_f32(const float *logits, const long long *idx, const long long *labels, const float *grad_out, float *grad_logits,
+                       int NL, int B, int Q, int C, int K, float alpha, float gamma, void *stream) {
+  if (!logits || !grad_out || !grad_logits || (K > 0 && (!idx || !labels))) return -1;
+  if (NL <= 0 || B <= 0 || Q <= 0 || C <= 0 || C > 255 || K < 0 || (long long)B * Q > mono::kFocalMaxCells) return -2;
+  const mono::FocalArgs a{logits, idx, labels, nullptr, NL, B, Q, C, K, alpha, gamma};
+  mono::focal_bwd_kernel<<<NL, mono::kFocalThreads, 0, (hipStream_t)stream>>>(a, grad_out, grad_logits);
+  return (int)hipGetLastError();
+}
+
 }  // extern "C"

@@ -20,7 +20,7 @@ from torch import nn
 from . import box_ops
 from .losses import DDNLoss, sigmoid_focal_loss
 from .misc import accuracy, get_world_size, is_dist_avail_and_initialized
-from ..pointwise import matched_losses, matched_losses_supported
+from ..pointwise import focal_classification, focal_classification_supported, matched_losses, matched_losses_supported
 
 
 def _paired_giou(a, b):
@@ -42,6 +42,7 @@ def _dev(values, dtype, device):
     return torch.as_tensor(np.asarray(values)).to(dtype).to(device, non_blocking=True)
 
 
+FUSED_FOCAL = True       # classification side (focal sums, class / cardinality errors) as one HIP kernel each way
 FUSED_MATCHED = True     # matched-pair losses through the HIP kernels on the GPU (False: the PyTorch formulation below)
 
 
@@ -282,6 +283,18 @@ class SetCriterion(nn.Module):
         per_layer = {}
 
         # labels (focal), class error, cardinality
+        if FUSED_FOCAL and FUSED_MATCHED and T and focal_classification_supported(logits, idx) and matched_losses_supported(boxes, idx):
+            # the whole criterion behind the matching in four launches: classification side + matched-pair losses, forward
+            # and backward (csrc/matched_losses.hip) -- this stretch of the step is bound by the host's enqueue rate
+            cls3 = focal_classification(logits, idx, flat["labels"], _dev(sizes, torch.float, dev), self.focal_alpha, 2.0)
+            per_layer["loss_ce"] = cls3[:, 0] / num_boxes                  # = focal.mean(2).sum((1, 2)) / num_boxes * Q
+            per_layer["class_error"] = cls3[:, 1].detach()
+            per_layer["cardinality_error"] = cls3[:, 2].detach()
+            sums = matched_losses(boxes, depth, dims, angle, idx, flat["boxes_3d"], flat["depth"], flat["size_3d"],
+                                  flat["heading_bin"], flat["heading_res"]) / num_boxes
+            for j, k in enumerate(("loss_center", "loss_bbox", "loss_giou", "loss_depth", "loss_dim", "loss_angle")):
+                per_layer[k] = sums[:, j]
+            return self._finish(per_layer, NL, dev, loss_depth_map)
         tgt_cls = flat["labels"].long()[t_idx] if T else torch.zeros((NL, 0), dtype=torch.int64, device=dev)
         target_classes = torch.full((NL, B, Q), self.num_classes, dtype=torch.int64, device=dev)
         target_classes[l_idx, b_idx, q_idx] = tgt_cls

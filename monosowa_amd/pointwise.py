@@ -11,7 +11,7 @@ _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmono
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
-           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32")
+           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32")
 _lib = None
 
 
@@ -73,6 +73,10 @@ def load():
         lib.mono_depth_expect_fwd_f32.argtypes = [P] * 3 + [I] * 4 + [LL] * 3 + [P]
         lib.mono_depth_expect_bwd_f32.restype = I
         lib.mono_depth_expect_bwd_f32.argtypes = [P] * 5 + [I] * 4 + [LL] * 3 + [P]
+        lib.mono_focal_fwd_f32.restype = I
+        lib.mono_focal_fwd_f32.argtypes = [P] * 5 + [I] * 5 + [F, F, P]
+        lib.mono_focal_bwd_f32.restype = I
+        lib.mono_focal_bwd_f32.argtypes = [P] * 5 + [I] * 5 + [F, F, P]
         _lib = lib
     return _lib
 
@@ -653,3 +657,45 @@ def depth_expectation(logits, values):
             and values.dtype == torch.float32 and not values.requires_grad:
         return _DepthExpectation.apply(logits, values)
     return (torch.softmax(logits, dim=1) * values.reshape(1, -1, 1, 1)).sum(dim=1)
+
+
+# ---- classification side of the criterion (csrc/matched_losses.hip) ------------------------------------------------------------
+class _FocalClassification(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, idx, labels, sizes, alpha, gamma):
+        NL, B, Q, C = logits.shape
+        K = idx.size(2)
+        out = torch.empty((NL, 3), dtype=torch.float32, device=logits.device)
+        with torch.cuda.device(logits.device):
+            code = load().mono_focal_fwd_f32(logits.data_ptr(), idx.data_ptr(), labels.data_ptr(), sizes.data_ptr(), out.data_ptr(),
+                                             NL, B, Q, C, K, alpha, gamma, raw_stream())
+        if code:
+            raise RuntimeError("mono_focal_fwd_f32 failed with code %d" % code)
+        ctx.save_for_backward(logits, idx, labels)
+        ctx.consts = (alpha, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        logits, idx, labels = ctx.saved_tensors
+        NL, B, Q, C = logits.shape
+        g = go[:, 0].contiguous()                       # class / cardinality errors carry no gradient
+        grad = torch.empty_like(logits)
+        with torch.cuda.device(logits.device):
+            code = load().mono_focal_bwd_f32(logits.data_ptr(), idx.data_ptr(), labels.data_ptr(), g.data_ptr(), grad.data_ptr(),
+                                             NL, B, Q, C, idx.size(2), *ctx.consts, raw_stream())
+        if code:
+            raise RuntimeError("mono_focal_bwd_f32 failed with code %d" % code)
+        return grad, None, None, None, None, None
+
+
+def focal_classification_supported(logits, idx):
+    NL, B, Q, C = logits.shape
+    return logits.is_cuda and logits.dtype == torch.float32 and C <= 255 and B <= 256 and B * Q <= 32768 and idx.size(2) > 0
+
+
+def focal_classification(logits, idx, labels, sizes, alpha, gamma=2.0):
+    """-> [NL, 3]: per decoder layer the sigmoid-focal-loss SUM against the matched one-hot targets (differentiable), the
+    class error in % and the cardinality error (monodetr.py:396-449) -- one HIP launch each way."""
+    return _FocalClassification.apply(logits.contiguous(), idx.contiguous(), labels.to(torch.int64).contiguous(),
+                                      sizes.to(torch.float32).contiguous(), float(alpha), float(gamma))
