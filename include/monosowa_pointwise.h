@@ -138,6 +138,17 @@ int mono_focal_fwd_f32(const float *logits, const long long *idx, const long lon
 int mono_focal_bwd_f32(const float *logits, const long long *idx, const long long *labels, const float *grad_out, float *grad_logits,
                        int NL, int B, int Q, int C, int K, float alpha, float gamma, void *stream);
 
+/* Per-level tail of MonoDETR's detection heads (monodetr.py:238-263), one launch each way: coords [B, Q, 6] = sigmoid(tmp),
+ * depth_ave [B, Q, 2] = ((1 / (sigmoid(depth_reg0) + 1e-6) - 1 + size3d0 / max((coords4 + coords5) img_h, 1) fu
+ *                        + bilinear(wdepth [B, H, W]; coords0, coords1 -- F.grid_sample, align_corners, zero padding)) / 3, depth_reg1).
+ * backward: g_coords / g_depth_ave may be NULL (no gradient); g_wdepth [B, H, W] must be ZERO on entry (atomics); the sampling
+ * location carries no gradient through the depth map (detached in the reference). */
+int mono_head_tail_fwd_f32(const float *tmp, const float *size3d, const float *depth_reg, const float *wdepth, const float *fu,
+                           const float *img_h, float *coords, float *depth_ave, int B, int Q, int H, int W, void *stream);
+int mono_head_tail_bwd_f32(const float *tmp, const float *size3d, const float *depth_reg, const float *wdepth, const float *fu,
+                           const float *img_h, const float *g_coords, const float *g_depth_ave, float *g_tmp, float *g_size3d,
+                           float *g_depth_reg, float *g_wdepth, int B, int Q, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,7 @@
 #include "groupnorm.hip"
 #include "matched_losses.hip"
 #include "ddn_loss.hip"
+#include "head_tail.hip"
 #include <stdint.h>
 
 namespace mono {
@@ -674,6 +675,28 @@ int mono_focal_bwd_f32(const float *logits, const long long *idx, const long lon
   if (NL <= 0 || B <= 0 || Q <= 0 || C <= 0 || C > 255 || K < 0 || (long long)B * Q > mono::kFocalMaxCells) return -2;
   const mono::FocalArgs a{logits, idx, labels, nullptr, NL, B, Q, C, K, alpha, gamma};
   mono::focal_bwd_kernel<<<NL, mono::kFocalThreads, 0, (hipStream_t)stream>>>(a, grad_out, grad_logits);
+  return (int)hipGetLastError();
+}
+
+
+// ---- per-level tail of the detection heads (head_tail.hip) --------------------------------------------------------------------
+int mono_head_tail_fwd_f32(const float *tmp, const float *size3d, const float *depth_reg, const float *wdepth, const float *fu,
+                           const float *img_h, float *coords, float *depth_ave, int B, int Q, int H, int W, void *stream) {
+  if (!tmp || !size3d || !depth_reg || !wdepth || !fu || !img_h || !coords || !depth_ave) return -1;
+  if (B <= 0 || Q <= 0 || H <= 0 || W <= 0) return -2;
+  const mono::HeadTailArgs a{tmp, size3d, depth_reg, wdepth, fu, img_h, B, Q, H, W};
+  mono::head_tail_fwd_kernel<<<(B * Q + 255) / 256, 256, 0, (hipStream_t)stream>>>(a, coords, depth_ave);
+  return (int)hipGetLastError();
+}
+
+int mono_head_tail_bwd_f32(const float *tmp, const float *size3d, const float *depth_reg, const float *wdepth, const float *fu,
+                           const float *img_h, const float *g_coords, const float *g_depth_ave, float *g_tmp, float *g_size3d,
+                           float *g_depth_reg, float *g_wdepth, int B, int Q, int H, int W, void *stream) {
+  if (!tmp || !size3d || !depth_reg || !wdepth || !fu || !img_h || !g_tmp || !g_size3d || !g_depth_reg || !g_wdepth) return -1;
+  if (B <= 0 || Q <= 0 || H <= 0 || W <= 0) return -2;
+  const mono::HeadTailArgs a{tmp, size3d, depth_reg, wdepth, fu, img_h, B, Q, H, W};
+  mono::head_tail_bwd_kernel<<<(B * Q + 255) / 256, 256, 0, (hipStream_t)stream>>>(a, g_coords, g_depth_ave, g_tmp, g_size3d,
+                                                                                   g_depth_reg, g_wdepth);
   return (int)hipGetLastError();
 }
 

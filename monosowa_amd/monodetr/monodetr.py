@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..pointwise import conv_group_norm
+from ..pointwise import conv_group_norm, head_tail, head_tail_supported
 from .depthaware_transformer import MLP, merged_first_layers
 from .misc import NestedTensor, inverse_sigmoid
 
@@ -25,6 +25,7 @@ def _clones(module, n):
 
 
 MERGE_HEADS = True
+FUSED_HEAD_TAIL = True     # box sigmoid + regressed / geometric / depth-map depth average per level as one kernel each way
 REUSE_BBOX_RAW = True
 
 
@@ -163,8 +164,6 @@ class MonoDETR(nn.Module):
             else:
                 assert reference.shape[-1] == 2
                 tmp = torch.cat([tmp[..., :2] + reference, tmp[..., 2:]], -1)
-            outputs_coord = tmp.sigmoid()                                   # 3D-centre projection + l,r,t,b
-            coords.append(outputs_coord)
             if MERGE_HEADS:
                 # class / depth / angle heads read the same hs[lvl]: first layers as one GEMM
                 cls, depth_reg, angle = merged_first_layers(hs[lvl], [self.class_embed[lvl], self.depth_embed[lvl], self.angle_embed[lvl]])
@@ -173,6 +172,15 @@ class MonoDETR(nn.Module):
             classes.append(cls)
             size3d = inter_references_dim[lvl]
             dims3d.append(size3d)
+            if FUSED_HEAD_TAIL and depth_reg is not None and head_tail_supported(tmp, size3d, depth_reg, weighted_depth, fu, img_h):
+                # sigmoid of the box logits + the three-way depth average below: one HIP kernel each way (csrc/head_tail.hip)
+                outputs_coord, depth_ave = head_tail(tmp, size3d, depth_reg, weighted_depth, fu, img_h)
+                coords.append(outputs_coord)
+                depths.append(depth_ave)
+                angles.append(angle)
+                continue
+            outputs_coord = tmp.sigmoid()                                   # 3D-centre projection + l,r,t,b
+            coords.append(outputs_coord)
 
             # geometric depth from the 3D height and the predicted 2D box height (monodetr.py:246-248)
             box2d_height = torch.clamp((outputs_coord[:, :, 4] + outputs_coord[:, :, 5]) * img_h, min=1.0)

@@ -11,7 +11,7 @@ _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmono
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
-           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32")
+           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32")
 _lib = None
 
 
@@ -77,6 +77,10 @@ def load():
         lib.mono_focal_fwd_f32.argtypes = [P] * 5 + [I] * 5 + [F, F, P]
         lib.mono_focal_bwd_f32.restype = I
         lib.mono_focal_bwd_f32.argtypes = [P] * 5 + [I] * 5 + [F, F, P]
+        lib.mono_head_tail_fwd_f32.restype = I
+        lib.mono_head_tail_fwd_f32.argtypes = [P] * 8 + [I] * 4 + [P]
+        lib.mono_head_tail_bwd_f32.restype = I
+        lib.mono_head_tail_bwd_f32.argtypes = [P] * 12 + [I] * 4 + [P]
         _lib = lib
     return _lib
 
@@ -699,3 +703,51 @@ def focal_classification(logits, idx, labels, sizes, alpha, gamma=2.0):
     class error in % and the cardinality error (monodetr.py:396-449) -- one HIP launch each way."""
     return _FocalClassification.apply(logits.contiguous(), idx.contiguous(), labels.to(torch.int64).contiguous(),
                                       sizes.to(torch.float32).contiguous(), float(alpha), float(gamma))
+
+
+# ---- per-level tail of the detection heads (csrc/head_tail.hip) -------------------------------------------------------------------
+class _HeadTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tmp, size3d, depth_reg, wdepth, fu, img_h):
+        B, Q, _ = tmp.shape
+        H, W = wdepth.shape[-2:]
+        coords = torch.empty((B, Q, 6), dtype=torch.float32, device=tmp.device)
+        dave = torch.empty((B, Q, 2), dtype=torch.float32, device=tmp.device)
+        with torch.cuda.device(tmp.device):
+            code = load().mono_head_tail_fwd_f32(tmp.data_ptr(), size3d.data_ptr(), depth_reg.data_ptr(), wdepth.data_ptr(), fu.data_ptr(),
+                                                 img_h.data_ptr(), coords.data_ptr(), dave.data_ptr(), B, Q, H, W, raw_stream())
+        if code:
+            raise RuntimeError("mono_head_tail_fwd_f32 failed with code %d" % code)
+        ctx.save_for_backward(tmp, size3d, depth_reg, wdepth, fu, img_h)
+        return coords, dave
+
+    @staticmethod
+    def backward(ctx, g_coords, g_dave):
+        tmp, size3d, depth_reg, wdepth, fu, img_h = ctx.saved_tensors
+        B, Q, _ = tmp.shape
+        H, W = wdepth.shape[-2:]
+        g_tmp, g_size, g_dreg = torch.empty_like(tmp), torch.empty_like(size3d), torch.empty_like(depth_reg)
+        g_wd = torch.zeros_like(wdepth)
+        gc = g_coords.contiguous() if g_coords is not None else None
+        gd = g_dave.contiguous() if g_dave is not None else None
+        with torch.cuda.device(tmp.device):
+            code = load().mono_head_tail_bwd_f32(tmp.data_ptr(), size3d.data_ptr(), depth_reg.data_ptr(), wdepth.data_ptr(), fu.data_ptr(),
+                                                 img_h.data_ptr(), gc.data_ptr() if gc is not None else None,
+                                                 gd.data_ptr() if gd is not None else None, g_tmp.data_ptr(), g_size.data_ptr(),
+                                                 g_dreg.data_ptr(), g_wd.data_ptr(), B, Q, H, W, raw_stream())
+        if code:
+            raise RuntimeError("mono_head_tail_bwd_f32 failed with code %d" % code)
+        return g_tmp, g_size, g_dreg, g_wd, None, None
+
+
+def head_tail_supported(tmp, size3d, depth_reg, wdepth, fu, img_h):
+    f = torch.float32
+    return tmp.is_cuda and all(t.dtype == f for t in (tmp, size3d, depth_reg, wdepth, fu, img_h)) and tmp.shape[-1] == 6 \
+        and size3d.shape[-1] == 3 and depth_reg.shape[-1] == 2 and wdepth.dim() == 3 and not fu.requires_grad and not img_h.requires_grad
+
+
+def head_tail(tmp, size3d, depth_reg, wdepth, fu, img_h):
+    """-> coords [B, Q, 6] = sigmoid(tmp), depth_ave [B, Q, 2] (regressed + geometric + depth-map depth averaged, log-variance):
+    monodetr.py:238-263 in one launch each way."""
+    c = lambda t: t.contiguous()
+    return _HeadTail.apply(c(tmp), c(size3d), c(depth_reg), c(wdepth), c(fu.reshape(-1)), c(img_h.reshape(-1)))

@@ -393,3 +393,43 @@ def test_depth_expectation_kernels_equal_the_pytorch_expression(channels_last):
     assert (got.detach().cpu().double() - expect.detach()).abs().max() <= 2e-6 * expect.abs().max()
     assert z.grad.stride() == z.stride()
     assert (z.grad.cpu().double() - ref.grad).abs().max() <= 2e-6 * ref.grad.abs().max()
+
+
+@pytest.mark.gpu
+def test_head_tail_kernels_equal_the_pytorch_expressions():
+    """csrc/head_tail.hip (box sigmoid + regressed / geometric / depth-map depth average, monodetr.py:238-263) against float64
+    autograd through the PyTorch expressions of monodetr.py; the MonoDETR-heads fixture pins the same path to the reference."""
+    import torch.nn.functional as F
+    from monosowa_amd.pointwise import head_tail
+    gen = torch.Generator().manual_seed(12)
+    B, Q, H, W = 4, 137, 24, 80
+    tmp = torch.randn(B, Q, 6, generator=gen) * 2
+    tmp[0, :5, 0] = 30.0                                   # sigmoid -> 1: the sample sits on the last column
+    tmp[1, :5, 4:6] = -12.0                                # tiny boxes: the 2D height clamp is active
+    size3d = torch.rand(B, Q, 3, generator=gen) + 1.0
+    dreg = torch.randn(B, Q, 2, generator=gen)
+    wd = torch.rand(B, H, W, generator=gen) * 60
+    fu = torch.rand(B, 1, generator=gen) * 300 + 600
+    img_h = torch.full((B, 1), 375.0)
+    w1, w2 = torch.randn(B, Q, 6, generator=gen).double(), torch.randn(B, Q, 2, generator=gen).double()
+
+    def reference(tmp, size3d, dreg, wd):
+        oc = tmp.sigmoid()
+        bh = torch.clamp((oc[:, :, 4] + oc[:, :, 5]) * img_h.to(tmp.dtype), min=1.0)
+        geo = size3d[:, :, 0] / bh * fu.to(tmp.dtype)
+        centre = ((oc[..., :2] - 0.5) * 2).unsqueeze(2).detach()
+        dm = F.grid_sample(wd.unsqueeze(1), centre, mode="bilinear", align_corners=True).squeeze(1)
+        dave = torch.cat([((1. / (dreg[:, :, 0:1].sigmoid() + 1e-6) - 1.) + geo.unsqueeze(-1) + dm) / 3, dreg[:, :, 1:2]], -1)
+        return oc, dave
+    ref_in = [t.double().requires_grad_(True) for t in (tmp, size3d, dreg, wd)]
+    oc, dave = reference(*ref_in)
+    ((oc * w1).sum() + (dave * w2).sum()).backward()
+    got_in = [t.cuda().requires_grad_(True) for t in (tmp, size3d, dreg, wd)]
+    oc_g, dave_g = head_tail(*got_in, fu.cuda(), img_h.cuda())
+    assert "HeadTail" in type(oc_g.grad_fn).__name__
+    ((oc_g * w1.float().cuda()).sum() + (dave_g * w2.float().cuda()).sum()).backward()
+    for name, a, b in (("coords", oc_g, oc), ("depth_ave", dave_g, dave)):
+        assert (a.detach().cpu().double() - b.detach()).abs().max() <= 2e-6 * b.abs().max(), name
+    for name, a, b in zip(("d tmp", "d size3d", "d depth_reg", "d weighted_depth"), got_in, ref_in):
+        err = (a.grad.cpu().double() - b.grad).abs().max().item()
+        assert err <= 2e-5 * b.grad.abs().max().item(), (name, err)     # (bilinear weights from an f32 pixel coordinate up to 79)
