@@ -149,6 +149,35 @@ bool window_tiling(const int64_t *shapes_host, const int64_t *lsi_host, int halo
   return it->second.first;
 }
 
+// Device copy of a tiling's query table (msda_window.h: WinQuery), made on first use per (device, geometry) and kept for the
+// life of the process (0.3 MB for 40 tiles).  The copy is a blocking hipMemcpy: it is complete before any later launch on any
+// stream.  First use must therefore happen outside a stream capture (like every library's lazy initialisation).
+const msda::WinQuery *query_table(const int64_t *shapes_host, const int64_t *lsi_host, int halo, bool bwd, const msda::WinTable &wt) {
+  static std::mutex mu;
+  static std::map<std::vector<int64_t>, msda::WinQuery *> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::vector<int64_t> key(shapes_host, shapes_host + 8);
+  key.insert(key.end(), lsi_host, lsi_host + 4);
+  key.push_back(halo);
+  key.push_back(bwd);
+  key.push_back(dev);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    std::vector<msda::WinQuery> host((size_t)wt.n_ty * wt.n_tx * msda::kWinMaxQueries * msda::kWinLevels);
+    msda::fill_query_table(wt, host.data());
+    msda::WinQuery *devp = nullptr;
+    if (hipMalloc(&devp, host.size() * sizeof(msda::WinQuery)) != hipSuccess) return nullptr;
+    if (hipMemcpy(devp, host.data(), host.size() * sizeof(msda::WinQuery), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(devp);
+      return nullptr;
+    }
+    it = cache.emplace(key, devp).first;
+  }
+  return it->second;
+}
+
 // One workgroup per CU for the persistent kernels (a multiple of 8: the XCD-aware item order relies on it).
 inline int persistent_grid() {
   static const int n = [] {
@@ -161,10 +190,24 @@ inline int persistent_grid() {
   return n;
 }
 
-inline bool window_applies(bool bwd, const int64_t *shapes_host, const int64_t *lsi_host, int Lq, int S) {
+// The window kernels address a (batch, head) plane with 32-bit lane offsets built from 24-bit products: S and the widest row
+// stride (floats) are bounded so that a plane's span stays below 2^31 bytes.
+constexpr int kWinMaxStride = 4096;
+inline bool window_fits(int S, long long widest_stride) { return S < (1 << 17) && widest_stride <= kWinMaxStride; }
+
+inline bool window_applies(bool bwd, const int64_t *shapes_host, const int64_t *lsi_host, int Lq, int S, long long widest_stride) {
   msda::WinGeom wg;
-  return Lq == S && (options().window & (bwd ? 2 : 1)) && gather_mode() > 1 &&
+  return Lq == S && (options().window & (bwd ? 2 : 1)) && gather_mode() > 1 && window_fits(S, widest_stride) &&
          window_tiling(shapes_host, lsi_host, options().window_halo, bwd, wg);
+}
+
+// A launch helper that could not do what its caller had planned (a device allocation failed) leaves its code here; the entry
+// points return it in place of hipGetLastError().
+thread_local int tl_launch_error = 0;
+inline int launch_status() {
+  const int e = tl_launch_error;
+  tl_launch_error = 0;
+  return e ? e : (int)hipGetLastError();
 }
 
 // Launch of the record-based gather kernels (forward or the backward's grad_loc / grad_attn_w pass), staged when
@@ -188,10 +231,17 @@ void launch_gather(const float *value, const float *loc, const float *attw, cons
     // self-attention shape (the window kernels evaluate the 2-d reference-point formula only): query i sits at token i's
     // pixel -> tile-local value windows (msda_gather_win.hip)
     msda::WinGeom wg;
-    if (window_tiling(shapes_host, lsi_host, options().window_halo, BWD, wg)) {
-      const int bm_groups = (B * M + 7) / 8;
-      msda::WinTable wt;
+    // the kernels address a (batch, head) plane with 32-bit lane offsets built from 24-bit products
+    const long long widest = std::max<long long>(std::max(loc_rs, aw_rs), std::max(M * 32, vts));
+    msda::WinTable wt;
+    const msda::WinQuery *qtab = nullptr;
+    if (window_fits(S, widest) && window_tiling(shapes_host, lsi_host, options().window_halo, BWD, wg)) {
       msda::fill_window_table(wg, wt);
+      qtab = query_table(shapes_host, lsi_host, options().window_halo, BWD, wt);
+      if (!qtab) { tl_launch_error = (int)hipErrorOutOfMemory; return; }
+    }
+    if (qtab) {
+      const int bm_groups = (B * M + 7) / 8;
       // persistent: one workgroup per CU walks the (batch * head, tile) items (window_persistent = 0: one workgroup per item)
       const int n_virtual = 8 * wg.n_ty * wg.n_tx * bm_groups;
       const int grid = options().window_persistent ? std::min(n_virtual, persistent_grid()) : n_virtual;
@@ -199,14 +249,16 @@ void launch_gather(const float *value, const float *loc, const float *attw, cons
       if (vv.mask)
         msda::gather_win_kernel<BWD, FUSED, SAVED, true><<<grid, threads, 0, stream>>>(
             value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, wt, B, S, M, loc_rs, aw_rs, grad_value, far_reach,
-            n_virtual, vts, vv.mask);
+            n_virtual, vts, vv.mask, qtab);
       else
         msda::gather_win_kernel<BWD, FUSED, SAVED, false><<<grid, threads, 0, stream>>>(
             value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, wt, B, S, M, loc_rs, aw_rs, grad_value, far_reach,
-            n_virtual, vts, nullptr);
+            n_virtual, vts, nullptr, qtab);
       return;
     }
   }
+  // callers that planned on the window kernel (saved prologue, far points of the row-tile scatter) cannot fall back
+  if (SAVED || far_reach >= 0) { tl_launch_error = MSDA_E_UNSUPPORTED; return; }
   msda::GatherGeom geom;
   const long long n_pairs = (long long)B * Lq * M;
   const bool staged = make_gather_geom(shapes_host, lsi_host, B, M, Lq, S, geom, BWD) && gather_mode() > 1;
@@ -237,16 +289,16 @@ int forward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, cons
         if (int e = check_host_geometry(shapes_host, lsi_host, L, S)) return e;
         launch_gather<false, false>(value, loc, attw, nullptr, out, nullptr, nullptr, nullptr, 0, shapes_host, lsi_host,
                                     B, S, M, Lq, stream);
-        return (int)hipGetLastError();
+        return launch_status();
       }
       msda::fwd_d32_kernel<4, 4><<<grid_pairs(n_pairs), 256, 0, stream>>>(
           value, shapes, lsi, loc, attw, out, S, M, Lq, n_pairs);
-      return (int)hipGetLastError();
+      return launch_status();
     }
   }
   msda::fwd_generic_kernel<T><<<grid_for(n_pairs, 8), 256, 0, stream>>>(
       value, shapes, lsi, loc, attw, out, S, M, D, L, Lq, P, n_pairs);
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 inline bool tiled_backward_applies(int elem_bytes, int D, int L, int P) {
@@ -344,7 +396,8 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       }
       if (int e = check_host_geometry(shapes_host, lsi_host, L, S)) return e;
       // self-attention shape: row-tile scatter + window gather (no transposed lists, no LDS atomics per channel)
-      if (options().scatter_rows && window_applies(true, shapes_host, lsi_host, Lq, S) && (!fused_ref || fused_ref_dim == 2)) {
+      const long long widest = std::max<long long>(std::max(loc_rs, aw_rs), std::max(M * 32, vv.token_stride));
+      if (options().scatter_rows && window_applies(true, shapes_host, lsi_host, Lq, S, widest) && (!fused_ref || fused_ref_dim == 2)) {
         msda::RowPlan rp;
         if (msda::make_row_plan(shapes_host, lsi_host, options().scatter_reach, rp) &&
             msda::row_plan_table_bytes(rp) <= workspace_bytes) {
@@ -378,7 +431,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
           else
             launch_gather<true, false>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, nullptr, 0, shapes_host,
                                        lsi_host, B, S, M, Lq, stream, 0, 0, grad_value, rp.reach);
-          return (int)hipGetLastError();
+          return launch_status();
         }
       }
       if (saved) return MSDA_E_UNSUPPORTED;          // msda_fused_save_supported() said otherwise
@@ -428,7 +481,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         msda::bwd_gather_kernel<4, 4><<<grid_pairs(n_pairs), 256, 0, stream>>>(
             value, shapes, lsi, loc, attw, grad_out, grad_loc, grad_attw, S, M, Lq, n_pairs);
       }
-      return (int)hipGetLastError();
+      return launch_status();
     }
   }
   hipError_t err = hipMemsetAsync(grad_value, 0, sizeof(T) * (size_t)B * S * M * D, stream);
@@ -436,7 +489,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
   msda::bwd_generic_kernel<T><<<grid_for(n_pairs, 8), 256, 0, stream>>>(
       value, shapes, lsi, loc, attw, grad_out, grad_value, grad_loc, grad_attw, S, M, D, L, Lq, P,
       n_pairs);
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 }  // namespace
@@ -512,7 +565,7 @@ int msda_fused_forward_view_f32(const float *value, int value_token_stride, cons
                                level_start_host, B, S, M, Lq, (hipStream_t)stream, offsets_row_stride, logits_row_stride, nullptr,
                                -1, vv);
   }
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 int msda_fused_backward_view_f32(const float *value, int value_token_stride, const unsigned char *value_mask,
@@ -580,7 +633,7 @@ int msda_fused_forward_strided_f32(const float *value, const int64_t *shapes, co
   if (int e = check_host_geometry(shapes_host, level_start_host, L, S)) return e;
   launch_gather<false, true>(value, offsets, logits, nullptr, out, nullptr, nullptr, ref, ref_dim, shapes_host,
                              level_start_host, B, S, M, Lq, (hipStream_t)stream, offsets_row_stride, logits_row_stride);
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 int msda_fused_backward_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
@@ -615,8 +668,9 @@ int msda_fused_save_supported(int S, int M, int D, int L, int Lq, int P, int ref
   if (!shapes_host || !level_start_host || !(D == 32 && L == 4 && P == 4) || M * L * 8 > 1024 || ref_dim != 2) return 0;
   if (check_host_geometry(shapes_host, level_start_host, L, S)) return 0;
   msda::RowPlan rp;
-  return options().scatter_rows && window_applies(true, shapes_host, level_start_host, Lq, S) &&
-         window_applies(false, shapes_host, level_start_host, Lq, S) &&
+  // (row strides: the entry points refuse strides beyond kWinMaxStride for the saved pair)
+  return options().scatter_rows && window_applies(true, shapes_host, level_start_host, Lq, S, M * 48) &&
+         window_applies(false, shapes_host, level_start_host, Lq, S, M * 48) &&
          msda::make_row_plan(shapes_host, level_start_host, options().scatter_reach, rp) ? 1 : 0;
 }
 
@@ -635,7 +689,7 @@ int msda_fused_forward_save_f32(const float *value, const int64_t *shapes, const
   if (!msda_fused_save_supported(S, M, D, L, Lq, P, ref_dim, shapes_host, level_start_host)) return MSDA_E_UNSUPPORTED;
   launch_gather<false, true, true>(value, offsets, logits, nullptr, out, loc_save, attn_save, ref, ref_dim, shapes_host,
                                    level_start_host, B, S, M, Lq, (hipStream_t)stream, offsets_row_stride, logits_row_stride);
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 int msda_fused_backward_saved_f32(const float *value, const int64_t *shapes, const int64_t *level_start,

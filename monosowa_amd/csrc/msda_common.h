@@ -183,6 +183,18 @@ __device__ __forceinline__ float loc_from_offset(float ref, float off, float s, 
   if (ref_dim == 2) return add_rn(ref, __fdiv_rn(off, s));
   return add_rn(ref, mul_rn(mul_rn(__fdiv_rn(off, (float)P), s), 0.5f));
 }
+// a / b for a divisor whose correctly rounded reciprocal rc = RN(1 / b) is at hand (a level extent: a small integer, constant
+// per lane): two residual corrections, each `r = a - q b` exact in the FMA.  q1 is within one ulp of a / b (its error before
+// rounding is the first estimate's 2^-23 times rc's 2^-24), and a correction of a faithful quotient with a correctly rounded
+// reciprocal rounds correctly unless b's significand is all ones (Markstein 1990) -- never for an integer below 2^24.  Five
+// full-rate instructions where the IEEE division expands to ~11 with a quarter-rate v_rcp_f32.  Finite operands with a
+// normal quotient only (an infinite offset gives NaN instead of inf: either fails the cuh:274 test).
+__device__ __forceinline__ float div_rc(float a, float b, float rc) {
+  float q = mul_rn(a, rc);
+  q = __builtin_fmaf(__builtin_fmaf(-q, b, a), rc, q);
+  q = __builtin_fmaf(__builtin_fmaf(-q, b, a), rc, q);
+  return q;
+}
 template <int P>
 __device__ __forceinline__ float offset_grad(float g, float s, int ref_dim) {       // autograd of the line above
   if (ref_dim == 2) return __fdiv_rn(g, s);

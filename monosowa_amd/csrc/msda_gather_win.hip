@@ -62,7 +62,7 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
     const float *__restrict__ grad_out, float *__restrict__ out, float *__restrict__ grad_loc,
     float *__restrict__ grad_attw, const float *__restrict__ ref, int ref_dim, const WinTable g, int B, int S, int M,
     int loc_rs, int aw_rs, float *__restrict__ grad_value, int far_reach, int n_virtual, int vts,
-    const unsigned char *__restrict__ vmask) {
+    const unsigned char *__restrict__ vmask, const WinQuery *__restrict__ qtab) {
   // far_reach >= 0 (backward, with msda_scatter_rows.hip): points that are not near_point(.., far_reach) add their
   // grad_value contributions here with global atomics -- the row-tile scatter handles exactly the near ones
   __shared__ float4 win[(kWinMaxRows + 1) * 8];                 // value windows, 8 float4 = one 128-byte row; + the zero row
@@ -80,21 +80,18 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
 
   // ---- an item's scalars: virtual index -> (batch * head, tile); the tiles of one (batch, head) share v % 8, which is
   // blockIdx.x % 8 for every item of this workgroup (gridDim.x is a multiple of 8) = one XCD's L2 (speed only)
-  struct Item { int b, m, ty, tx, first1, first2, first3, n_queries; };
+  struct Item { int b, m, ty, tx, tile, n_queries; };
   auto make_item = [&](const int v) {
     Item it;
     const int bm = (v & 7) + 8 * (v / (8 * n_tiles));
-    const int tile = (v >> 3) % n_tiles;
-    it.ty = tile / g.n_tx;
-    it.tx = tile - it.ty * g.n_tx;
+    it.tile = (v >> 3) % n_tiles;
+    it.ty = it.tile / g.n_tx;
+    it.tx = it.tile - it.ty * g.n_tx;
     it.b = bm / M;
     it.m = bm - it.b * M;
     const AxisSpec *ay_tab = g.ax[it.ty], *ax_tab = g.ax[g.n_ty + it.tx];
-    int n = 0;
-    n += (int)ay_tab[0].qn * (int)ax_tab[0].qn; it.first1 = n;
-    n += (int)ay_tab[1].qn * (int)ax_tab[1].qn; it.first2 = n;
-    n += (int)ay_tab[2].qn * (int)ax_tab[2].qn; it.first3 = n;
-    n += (int)ay_tab[3].qn * (int)ax_tab[3].qn; it.n_queries = n;
+    it.n_queries = (int)ay_tab[0].qn * (int)ax_tab[0].qn + (int)ay_tab[1].qn * (int)ax_tab[1].qn +
+                   (int)ay_tab[2].qn * (int)ax_tab[2].qn + (int)ay_tab[3].qn * (int)ax_tab[3].qn;
     return it;
   };
   auto item_valid = [&](const int v) { return v < n_virtual && (v & 7) + 8 * (v / (8 * n_tiles)) < B * M; };
@@ -102,49 +99,45 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
   // ---- a unit's per-lane inputs (lane j of a pair holds points 2j, 2j + 1 after the coalesced load) -----------------------
   const int l_mine = sub >> 1;                                           // level of this lane's two points
   const int Hm = g.H[l_mine], Wm = g.W[l_mine], start_m = g.start[l_mine];
+  const float2 ref_scale = make_float2((float)Wm, (float)Hm);            // FUSED: the offset normaliser of this lane's level (ref_dim == 2)
+  const float2 ref_rc = make_float2(__fdiv_rn(1.f, ref_scale.x), __fdiv_rn(1.f, ref_scale.y));
   struct In {
     float4 lc, go;           // offsets / locations of the two points; this lane's 16 bytes of the pair's grad_out row
     float2 aw;
     float2 rf;               // FUSED forward: the reference point (x, y) of this lane's level (ref_dim == 2 only, see the host)
-    int q_lin, cf_y, cf_x;   // b * S + q (host: B * S < 2^31), -1 for a lane without a query; its centre floor at this lane's level
+    int q, cf_y, cf_x;       // the query's token (-1 for a lane without a query); its centre floor at this lane's level
   };
-  auto load_unit = [&](const Item &it, const int ps) {
+  // A unit's per-lane inputs in two steps, each a unit ahead of its use: the query-table entry (tile, slot, this lane's level),
+  // then -- from the token it names -- the loads.  All per-lane addressing is 32-bit: a scalar base of the unit's (batch, head)
+  // plus a lane offset that is one 24-bit multiply-add (host: S and the row strides < 2^24, a plane's span < 2^31 bytes).
+  auto load_entry = [&](const Item &it, const int ps) {
+    const int i = ps * kPairs + (threadIdx.x >> 3);             // query slot of the tile
+    WinQuery e{-1, 0};
+    if (i < it.n_queries) e = qtab[(unsigned)((it.tile * kWinMaxQueries + i) * kWinLevels + l_mine)];
+    return e;
+  };
+  const unsigned saved_lane = (unsigned)l_mine * (unsigned)S * 4u + (sub & 1) * 2;      // level-major saved tensors: + q * 4
+  auto load_unit = [&](const Item &it, const WinQuery e) {
     In in{};
-    const AxisSpec *ay_tab = g.ax[it.ty], *ax_tab = g.ax[g.n_ty + it.tx];
-    const int i = ps * kPairs + (threadIdx.x >> 3);             // query of the tile
-    in.q_lin = -1;
-    if (i < it.n_queries) {
-      // query i of the tile -> (level, row, column): the level by three compares, then ONE small division
-      // (the per-level table entries are wave-uniform scalars picked by compares: indexing the kernel-argument table with a
-      // per-lane level would be a dependent vector load in front of the input loads)
-      const int ql = (i >= it.first1) + (i >= it.first2) + (i >= it.first3);
-      auto pick = [&](const int a0, const int a1, const int a2, const int a3) { return ql == 0 ? a0 : (ql == 1 ? a1 : (ql == 2 ? a2 : a3)); };
-      auto qpart = [](const AxisSpec a) { return (int)(unsigned short)a.q0 | ((int)(unsigned short)a.qn << 16); };
-      const int yq = pick(qpart(ay_tab[0]), qpart(ay_tab[1]), qpart(ay_tab[2]), qpart(ay_tab[3]));
-      const int xq = pick(qpart(ax_tab[0]), qpart(ax_tab[1]), qpart(ax_tab[2]), qpart(ax_tab[3]));
-      const int qy0 = yq & 0xFFFF, qx0 = xq & 0xFFFF, qxn = xq >> 16;
-      const int Wq = pick(g.W[0], g.W[1], g.W[2], g.W[3]);
-      const int k = i - pick(0, it.first1, it.first2, it.first3);
-      const int dy = (int)(((float)k + 0.5f) / (float)qxn), dx = k - dy * qxn;                // exact: k < 256
-      const int q = pick(g.start[0], g.start[1], g.start[2], g.start[3]) + (qy0 + dy) * Wq + qx0 + dx;       // Lq == S
-      in.q_lin = it.b * S + q;
-      if (BWD && far_reach >= 0) {
-        in.cf_y = centre_floor(qy0 + dy, pick(g.H[0], g.H[1], g.H[2], g.H[3]), Hm);
-        in.cf_x = centre_floor(qx0 + dx, Wq, Wm);
-      }
-      const long long ql64 = in.q_lin;
+    in.q = e.q;
+    in.cf_y = e.cf >> 16;
+    in.cf_x = (int)(short)(e.cf & 0xFFFF);
+    if (e.q >= 0) {
+      const unsigned q = (unsigned)e.q;
+      const long long bS = (long long)it.b * S;
       if (BWD && SAVED) {
         // the forward's saved tensors are LEVEL-MAJOR, [B, M, L, Lq, P(, 2)]: a level's points of neighbouring queries are
         // neighbours in memory, which is what the row-tile scatter's scan wants (whole lines instead of 32-byte quarters)
-        const long long pl = (((long long)(it.b * M + it.m) * 4 + l_mine) * S + q) * 4 + (sub & 1) * 2;
-        in.lc = ld4(loc + pl * 2);
-        in.aw = *reinterpret_cast<const float2 *>(attw + pl);
+        const long long plane = (long long)(it.b * M + it.m) * 4 * S * 4;
+        const unsigned pl = q * 4u + saved_lane;
+        in.lc = ld4(loc + plane * 2 + pl * 2u);
+        in.aw = *reinterpret_cast<const float2 *>(attw + plane + pl);
       } else {
-        in.lc = ld4(loc + ql64 * loc_rs + it.m * 32 + sub * 4);
-        in.aw = *reinterpret_cast<const float2 *>(attw + ql64 * aw_rs + it.m * 16 + sub * 2);
+        in.lc = ld4(loc + (bS * loc_rs + it.m * 32) + (__umul24(q, (unsigned)loc_rs) + sub * 4u));
+        in.aw = *reinterpret_cast<const float2 *>(attw + (bS * aw_rs + it.m * 16) + (__umul24(q, (unsigned)aw_rs) + sub * 2u));
       }
-      if (FUSED && !(BWD && SAVED)) in.rf = *reinterpret_cast<const float2 *>(ref + (ql64 * 4 + l_mine) * 2);
-      if (BWD) in.go = ld4(grad_out + (ql64 * M + it.m) * 32 + sub * 4);
+      if (FUSED && !(BWD && SAVED)) in.rf = *reinterpret_cast<const float2 *>(ref + bS * 8 + (q * 8u + l_mine * 2u));
+      if (BWD) in.go = ld4(grad_out + (bS * M + it.m) * 32 + (__umul24(q, (unsigned)(M * 32)) + sub * 4u));
     }
     return in;
   };
@@ -152,16 +145,37 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
   char *wbytes = reinterpret_cast<char *>(win);
   const int rot = sub ^ (lane >> 3);                                     // see row() below
 
-  int v = blockIdx.x;
-  while (v < n_virtual && !item_valid(v)) v += gridDim.x;
-  if (v >= n_virtual) return;
-  Item it = make_item(v);
-  int ps = 0;
-  In nxt = load_unit(it, 0);
+  // the walk over (item, pass) units; `ok` = false past the last one
+  struct Unit { Item it; int v, ps; bool ok; };
+  auto next_unit = [&](const Unit &u) {
+    Unit n = u;
+    if (!u.ok) return n;
+    n.ps = u.ps + 1;
+    if (n.ps * kPairs >= u.it.n_queries) {
+      n.ps = 0;
+      n.v = u.v + gridDim.x;
+      while (n.v < n_virtual && !item_valid(n.v)) n.v += gridDim.x;
+      n.ok = n.v < n_virtual;
+      if (n.ok) n.it = make_item(n.v);
+    }
+    return n;
+  };
+  Unit cur;
+  cur.v = blockIdx.x;
+  cur.ps = 0;
+  while (cur.v < n_virtual && !item_valid(cur.v)) cur.v += gridDim.x;
+  if (cur.v >= n_virtual) return;
+  cur.ok = true;
+  cur.it = make_item(cur.v);
+  Unit u1 = next_unit(cur);
+  In nxt = load_unit(cur.it, load_entry(cur.it, 0));
+  WinQuery e1 = u1.ok ? load_entry(u1.it, u1.ps) : WinQuery{-1, 0};
   bool first = true;
 
   while (true) {
-    In in = (MSDA_WIN_SKIP & 8) ? load_unit(it, ps) : nxt;
+    const Item it = cur.it;
+    const int ps = cur.ps;
+    In in = (MSDA_WIN_SKIP & 8) ? load_unit(it, load_entry(it, ps)) : nxt;
     // the unit's inputs have arrived long ago; consuming them HERE keeps their wait (which the compiler can only express as
     // vmcnt(0) once the fill below is in flight) in front of the fill
     asm volatile("" : "+v"(in.lc.x), "+v"(in.lc.y), "+v"(in.lc.z), "+v"(in.lc.w), "+v"(in.aw.x), "+v"(in.aw.y), "+v"(in.rf.x),
@@ -180,8 +194,8 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
     // ---- this lane's two taps: pure VALU, evaluated UNDER the fill when the unit starts an item.  Fill, taps and the fill's wait
     // sit in one branch: with the wait in a second `if (ps == 0)` the compiler's wait-count pass sees a path from the fill to the
     // LDS reads that skips it and puts its own vmcnt(0) in front of the first row read -- behind the next unit's input loads.
-    const bool live = in.q_lin >= 0;
-    const long long ql64 = live ? in.q_lin : 0;
+    const bool live = in.q >= 0;
+    const unsigned q_u = live ? (unsigned)in.q : 0u;
     // the tile's window of this lane's level: the four levels' specs are wave-uniform (scalar loads), picked per lane
     int wy_lo, wy_hi, wx_lo, wx_hi, ww_m;
     {
@@ -196,21 +210,24 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
     const int base_m = l_mine == 0 ? 0 : (l_mine == 1 ? base1 : (l_mine == 2 ? base2 : base3));
     float2 a2 = in.aw;
     float4 l4 = in.lc;
-    const float2 ref_scale = make_float2((float)Wm, (float)Hm);          // FUSED backward: d location / d offset (ref_dim == 2)
     if (FUSED && !(BWD && SAVED)) {
       // softmax over the pair's 16 logits (2 per lane), then this lane's two sampling locations (msda_common.h)
+      // (hardware exp2 and reciprocal, ~1 ulp each: the weights are smooth in them; the LOCATIONS below decide floor()s and
+      // are rounded exactly like the reference's `offset / normalizer`, ms_deform_attn.py:149-152)
       const float mx = group_max(fmaxf(a2.x, a2.y));
-      const float e0 = expf(a2.x - mx), e1 = expf(a2.y - mx);
-      const float denom = group_sum(e0 + e1);
-      a2 = make_float2(e0 / denom, e1 / denom);
+      const float e0 = __expf(a2.x - mx), e1 = __expf(a2.y - mx);
+      const float inv = __builtin_amdgcn_rcpf(group_sum(e0 + e1));
+      a2 = make_float2(e0 * inv, e1 * inv);
       if (live)
-        l4 = make_float4(loc_from_offset<4>(in.rf.x, l4.x, (float)Wm, 2), loc_from_offset<4>(in.rf.y, l4.y, (float)Hm, 2),
-                         loc_from_offset<4>(in.rf.x, l4.z, (float)Wm, 2), loc_from_offset<4>(in.rf.y, l4.w, (float)Hm, 2));
+        l4 = make_float4(add_rn(in.rf.x, div_rc(l4.x, ref_scale.x, ref_rc.x)), add_rn(in.rf.y, div_rc(l4.y, ref_scale.y, ref_rc.y)),
+                         add_rn(in.rf.x, div_rc(l4.z, ref_scale.x, ref_rc.x)), add_rn(in.rf.y, div_rc(l4.w, ref_scale.y, ref_rc.y)));
     }
     int off[2][4];
     float cw[2][4];          // forward: corner weights x attn_w.  backward: lh, lw, W attn_w, H attn_w
     int far_points = 0;      // backward with the row-tile scatter: which of the two points it does not cover
     int padded = 0;          // MASKED backward: bit 4 k2 + c = corner c of point k2 sits on a padded token
+    int out_pts = 0;         // bit k2: point k2 lies outside its window (fetched from global memory in the fix-up pass)
+    const int zero_rot = kZeroOff + rot * 16;
     auto taps = [&]() {
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
@@ -221,14 +238,16 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
       const bool inwin = tp.y0 >= wy_lo && tp.y1 <= wy_hi && tp.x0 >= wx_lo && tp.x1 <= wx_hi;
       // corner -> LDS byte offset (in window), kOutside (fetched from global memory in the fix-up pass, which re-derives the
       // token from the location: rare), or the zero row (a corner the reference drops, a lane without a query)
-      const int lds00 = (base_m + (tp.y0 - wy_lo) * ww_m + (tp.x0 - wx_lo)) * 128, ldx = (tp.x1 - tp.x0) * 128,
+      const int lds00 = (base_m + (tp.y0 - wy_lo) * ww_m + (tp.x0 - wx_lo)) * 128 + rot * 16, ldx = (tp.x1 - tp.x0) * 128,
                 ldy = (tp.y1 - tp.y0) * ww_m * 128;
-      const int in_or_out = inwin ? 0 : 1;                                  // kOutside = kZeroOff | 1: the row loops read the zero row
-      auto pick = [&](const int in_lds, const bool keep) { return (keep && live) ? (inwin ? in_lds : (kZeroOff | in_or_out)) : kZeroOff; };
+      // (the offsets carry this lane's slot rotation: the row loops XOR the slot number into them and nothing else)
+      const bool use = inwin && live;
+      auto pick = [&](const int in_lds, const bool keep) { return (keep && use) ? in_lds : zero_rot; };
       off[k2][0] = pick(lds00, tp.t && tp.l);
       off[k2][1] = pick(lds00 + ldx, tp.t && tp.r);
       off[k2][2] = pick(lds00 + ldy, tp.b && tp.l);
       off[k2][3] = pick(lds00 + ldy + ldx, tp.b && tp.r);
+      if (live && !inwin && tp.valid) out_pts |= 1 << k2;                   // its corners read the zero row in the row loops
       if (BWD) { cw[k2][0] = tp.lh; cw[k2][1] = tp.lw; cw[k2][2] = (float)Wm * wt; cw[k2][3] = (float)Hm * wt; }
       else {
         // a dropped corner reads the zero row: its weight need not be zeroed (the products below are finite)
@@ -250,7 +269,7 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
       asm volatile("" : "+v"(off[0][0]), "+v"(off[0][1]), "+v"(off[0][2]), "+v"(off[0][3]), "+v"(off[1][0]), "+v"(off[1][1]),
                    "+v"(off[1][2]), "+v"(off[1][3]) : : "memory");
       asm volatile("" : "+v"(cw[0][0]), "+v"(cw[0][1]), "+v"(cw[0][2]), "+v"(cw[0][3]), "+v"(cw[1][0]), "+v"(cw[1][1]),
-                   "+v"(cw[1][2]), "+v"(cw[1][3]) : : "memory");
+                   "+v"(cw[1][2]), "+v"(cw[1][3]), "+v"(out_pts) : : "memory");
     };
     if (ps == 0) {
       // ---- LDS-DMA fill of the four windows: thread -> (row, 16-byte slot); a wave instruction lands 8 consecutive rows.
@@ -284,22 +303,18 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
       taps();
     }
 
-    // ---- the next unit's inputs: requested now, consumed at the top of the next iteration --------------------------------------
-    int v_next = v, ps_next = ps + 1;
-    Item it_next = it;
-    if (ps_next * kPairs >= it.n_queries) {
-      ps_next = 0;
-      v_next = v + gridDim.x;
-      while (v_next < n_virtual && !item_valid(v_next)) v_next += gridDim.x;
-      if (v_next < n_virtual) it_next = make_item(v_next);
-    }
-    const bool more = v_next < n_virtual;
-    if (more && !(MSDA_WIN_SKIP & 8)) nxt = load_unit(it_next, ps_next);
+    // ---- the next unit's inputs: requested now, consumed at the top of the next iteration; behind them the table entry of
+    // the unit after it --------------------------------------------------------------------------------------------------------
+    const bool more = u1.ok;
+    if (more && !(MSDA_WIN_SKIP & 8)) nxt = load_unit(u1.it, e1);
+    const Unit u2 = next_unit(u1);
+    if (u2.ok) e1 = load_entry(u2.it, u2.ps);
 
     if (!BWD && FUSED && SAVED && live && !(MSDA_WIN_SKIP & 16)) {        // hand the backward what was evaluated here (level-major)
-      const long long pl = (((long long)(it.b * M + it.m) * 4 + l_mine) * S + (in.q_lin - it.b * S)) * 4 + (sub & 1) * 2;
-      st4(grad_loc + pl * 2, l4);
-      *reinterpret_cast<float2 *>(grad_attw + pl) = a2;
+      const long long plane = (long long)(it.b * M + it.m) * 4 * S * 4;
+      const unsigned pl = q_u * 4u + saved_lane;
+      st4(grad_loc + plane * 2 + pl * 2u, l4);
+      *reinterpret_cast<float2 *>(grad_attw + plane + pl) = a2;
     }
 
     // one corner: the whole 128-byte row; register s receives 16-byte slot s ^ rot with rot = sub ^ (pair of the wave): the
@@ -310,20 +325,19 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
     // Half a row (4 x ds_read_b128) at a time: 16 registers of row data in flight instead of 32 -- the prefetched inputs of
     // the next unit need the room (launch bound: 128 VGPRs at 16 waves per CU).
     auto half_row = [&](const int o, const int h, float4 (&vv)[4]) {
-      const int a = ((o & 1) ? kZeroOff : o) + rot * 16;                  // LDS offsets are multiples of 128
 #pragma unroll
-      for (int s = 0; s < 4; ++s) vv[s] = *reinterpret_cast<const float4 *>(wbytes + (a ^ ((4 * h + s) * 16)));
+      for (int s = 0; s < 4; ++s) vv[s] = *reinterpret_cast<const float4 *>(wbytes + (o ^ ((4 * h + s) * 16)));
     };
-    const bool outside = ((off[0][0] | off[0][1] | off[0][2] | off[0][3] | off[1][0] | off[1][1] | off[1][2] | off[1][3]) & 1) != 0;
-    auto outside_token = [&](const int k2, const int c) {                 // value token of corner c of this lane's point k2 (cold path)
+    const bool outside = out_pts != 0;
+    // value token of corner c of this lane's point k2, -1 for a corner the reference drops (cold path: re-derived)
+    auto outside_token = [&](const int k2, const int c) {
       const Tap<float> tp = make_tap<float>(k2 ? l4.z : l4.x, k2 ? l4.w : l4.y, Hm, Wm);
-      return start_m + ((c & 2) ? tp.y1 : tp.y0) * Wm + ((c & 1) ? tp.x1 : tp.x0);
+      const bool keep = ((c & 2) ? tp.b : tp.t) && ((c & 1) ? tp.r : tp.l);
+      return keep ? start_m + ((c & 2) ? tp.y1 : tp.y0) * Wm + ((c & 1) ? tp.x1 : tp.x0) : -1;
     };
 
     if (!BWD) {
       float4 acc[8];
-#pragma unroll
-      for (int s = 0; s < 8; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
@@ -336,7 +350,11 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
             half_row(off[k2][c], h, vv);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-              acc[4 * h + s].x += w * vv[s].x; acc[4 * h + s].y += w * vv[s].y; acc[4 * h + s].z += w * vv[s].z; acc[4 * h + s].w += w * vv[s].w;
+              if (k2 == 0 && c == 0)        // the first corner initialises the accumulators (32 moves fewer)
+                acc[4 * h + s] = make_float4(w * vv[s].x, w * vv[s].y, w * vv[s].z, w * vv[s].w);
+              else {
+                acc[4 * h + s].x += w * vv[s].x; acc[4 * h + s].y += w * vv[s].y; acc[4 * h + s].z += w * vv[s].z; acc[4 * h + s].w += w * vv[s].w;
+              }
             }
             // one half row (4 loads) at a time: the accumulation has to be finished HERE (the asm statement consumes it),
             // before the next loads -- otherwise the compiler loads many rows first and spills
@@ -354,10 +372,11 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (off[k2][c] & 1) {
+          for (int c = 0; c < 4; ++c) {
+            const int token = (out_pts & (1 << k2)) ? outside_token(k2, c) : -1;
+            if (token >= 0) {
               const float w = cw[k2][c];
-              const float *p = value_bm + (long long)outside_token(k2, c) * tok;
+              const float *p = value_bm + (long long)token * tok;
 #pragma unroll
               for (int s = 0; s < 8; ++s) {
                 const float4 x = ld4(p + 4 * (s ^ rot));
@@ -365,19 +384,18 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
                 asm volatile("" : "+v"(acc[s].x), "+v"(acc[s].y), "+v"(acc[s].z), "+v"(acc[s].w) : : "memory");
               }
             }
+          }
       }
-      // reduce-scatter over the pair's 8 lanes.  acc[s] holds slot s ^ rot, so in the butterfly with partner sub ^ 4 every
-      // lane keeps registers 0..3 and hands over 4..7 (the partner's register s ^ 4 is the same slot), then sub ^ 2, sub ^ 1:
+      // reduce-scatter over the pair's 8 lanes.  acc[s] holds slot s ^ rot, so in a butterfly with partners sub ^ 7, sub ^ 2,
+      // sub ^ 1 every lane keeps its low registers and receives the partner's registers of the same slots (no selects):
       // acc[0] ends as slot rot = channels 4 rot .. 4 rot + 3 summed over the pair -- a permutation of the pair's lanes, still
       // one full 128-byte store per pair
-      auto xor4 = [](const float x) {
-        int r = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x104, 0xF, 0x5, false);      // row_shl:4 -> lanes 0..3 of 8
-        r = __builtin_amdgcn_update_dpp(r, __float_as_int(x), 0x114, 0xF, 0xA, false);          // row_shr:4 -> lanes 4..7
-        return __int_as_float(r);
-      };
+      // first step with partner sub ^ 7 (row_half_mirror: one DPP operand, where sub ^ 4 needs two shifted moves): its register
+      // 7 - s = s ^ 7 holds slot s ^ 7 ^ (rot ^ 7) = this lane's slot of register s
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        acc[s].x += xor4(acc[s + 4].x); acc[s].y += xor4(acc[s + 4].y); acc[s].z += xor4(acc[s + 4].z); acc[s].w += xor4(acc[s + 4].w);
+        acc[s].x += dpp_x<0x141>(acc[7 - s].x); acc[s].y += dpp_x<0x141>(acc[7 - s].y);
+        acc[s].z += dpp_x<0x141>(acc[7 - s].z); acc[s].w += dpp_x<0x141>(acc[7 - s].w);
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -386,7 +404,8 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
       }
       const float4 res = make_float4(acc[0].x + dpp_x<0xB1>(acc[1].x), acc[0].y + dpp_x<0xB1>(acc[1].y),
                                      acc[0].z + dpp_x<0xB1>(acc[1].z), acc[0].w + dpp_x<0xB1>(acc[1].w));
-      if (live && (!(MSDA_WIN_SKIP & 4) || res.x == 123.456f)) st4(out + (ql64 * M + it.m) * 32 + rot * 4, res);
+      if (live && (!(MSDA_WIN_SKIP & 4) || res.x == 123.456f))
+        st4(out + ((long long)it.b * S * M + it.m) * 32 + (__umul24(q_u, (unsigned)(M * 32)) + rot * 4u), res);
     } else {
       // grad_out of the pair, all 32 channels in every lane, rotated as row(): each lane fetched 16 bytes of the row a unit
       // ahead; the pair's 8 lanes exchange them through the wave's private 1-KiB LDS block (no workgroup barrier: only this
@@ -458,9 +477,10 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (off[k2][c] & 1) {
-              const float *p = value_bm + (long long)outside_token(k2, c) * tok;
+          for (int c = 0; c < 4; ++c) {
+            const int token = (out_pts & (1 << k2)) ? outside_token(k2, c) : -1;
+            if (token >= 0) {
+              const float *p = value_bm + (long long)token * tok;
 #pragma unroll
               for (int s = 0; s < 8; ++s) {
                 const float4 x = ld4(p + 4 * (s ^ rot));
@@ -468,6 +488,7 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
                 asm volatile("" : "+v"(d[k2][c]) : : "memory");
               }
             }
+          }
       }
       if (MASKED && padded) {
 #pragma unroll
@@ -491,19 +512,19 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
         // chain rule through the prologue for this lane's own two points: softmax backward and the offset scale
         const float dot = group_sum(oa.x * a2.x + oa.y * a2.y);
         oa = make_float2((oa.x - dot) * a2.x, (oa.y - dot) * a2.y);
-        ol = make_float4(offset_grad<4>(ol.x, ref_scale.x, 2), offset_grad<4>(ol.y, ref_scale.y, 2),
-                         offset_grad<4>(ol.z, ref_scale.x, 2), offset_grad<4>(ol.w, ref_scale.y, 2));
+        ol = make_float4(div_rc(ol.x, ref_scale.x, ref_rc.x), div_rc(ol.y, ref_scale.y, ref_rc.y),
+                         div_rc(ol.z, ref_scale.x, ref_rc.x), div_rc(ol.w, ref_scale.y, ref_rc.y));
       }
       if (live) {
-        st4(grad_loc + ql64 * loc_rs + it.m * 32 + sub * 4, ol);
-        *reinterpret_cast<float2 *>(grad_attw + ql64 * aw_rs + it.m * 16 + sub * 2) = oa;
+        const long long bS = (long long)it.b * S;
+        st4(grad_loc + (bS * loc_rs + it.m * 32) + (__umul24(q_u, (unsigned)loc_rs) + sub * 4u), ol);
+        *reinterpret_cast<float2 *>(grad_attw + (bS * aw_rs + it.m * 16) + (__umul24(q_u, (unsigned)aw_rs) + sub * 2u)) = oa;
       }
     }
 
     if (!more) break;
-    v = v_next;
-    ps = ps_next;
-    it = it_next;
+    cur = u1;
+    u1 = u2;
   }
 }
 

@@ -45,6 +45,12 @@ struct WinTable {
   AxisSpec ax[kWinMaxAxisTiles][kWinLevels];         // [0, n_ty): rows of tiles, [n_ty, n_ty + n_tx): columns of tiles
 };
 
+// Per (tile, query slot, sampled level): the query's token and the floor of its centre at that level (centre_floor of
+// msda_common.h, y << 16 | x & 0xFFFF).  Geometry only -- one table serves every (batch, head) plane; the kernels read it
+// instead of re-deriving (level, row, column) from the slot number with compares and divisions in every lane.
+struct WinQuery { int q, cf; };                      // q = -1: empty slot
+constexpr int kWinMaxQueries = kWinPairsPerPass * kWinMaxPasses;
+
 inline int floor_div(int a, int b) {                 // b > 0
   const int q = a / b, r = a - q * b;
   return r < 0 ? q - 1 : q;
@@ -81,6 +87,29 @@ inline void fill_window_table(const WinGeom &g, WinTable &t) {
     for (int l = 0; l < kWinLevels; ++l) t.ax[ty][l] = axis_spec(g.H, g.n_ty, ty, l, g.halo);
   for (int tx = 0; tx < g.n_tx; ++tx)
     for (int l = 0; l < kWinLevels; ++l) t.ax[g.n_ty + tx][l] = axis_spec(g.W, g.n_tx, tx, l, g.halo);
+}
+
+// [n_tiles][kWinMaxQueries][kWinLevels] entries; a tile's queries in level order, row-major within the level.
+inline void fill_query_table(const WinTable &t, WinQuery *out) {
+  for (int ty = 0; ty < t.n_ty; ++ty)
+    for (int tx = 0; tx < t.n_tx; ++tx) {
+      WinQuery *tile = out + (size_t)(ty * t.n_tx + tx) * kWinMaxQueries * kWinLevels;
+      int i = 0;
+      for (int l = 0; l < kWinLevels; ++l) {
+        const AxisSpec ay = t.ax[ty][l], ax = t.ax[t.n_ty + tx][l];
+        for (int dy = 0; dy < ay.qn; ++dy)
+          for (int dx = 0; dx < ax.qn; ++dx, ++i) {
+            const int y = ay.q0 + dy, x = ax.q0 + dx;
+            for (int lv = 0; lv < kWinLevels; ++lv) {
+              const int cy = floor_div((2 * y + 1) * t.H[lv] - t.H[l], 2 * t.H[l]);
+              const int cx = floor_div((2 * x + 1) * t.W[lv] - t.W[l], 2 * t.W[l]);
+              tile[i * kWinLevels + lv] = WinQuery{t.start[l] + y * t.W[l] + x, (int)(((unsigned)cy << 16) | ((unsigned)cx & 0xFFFFu))};
+            }
+          }
+      }
+      for (; i < kWinMaxQueries; ++i)
+        for (int lv = 0; lv < kWinLevels; ++lv) tile[i * kWinLevels + lv] = WinQuery{-1, 0};
+    }
 }
 
 // Host: choose the tiling.  Cost model (LDS cycles per tile, measured orders of magnitude): ~5 per staged row (L2 -> LDS),
