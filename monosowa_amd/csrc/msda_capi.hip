@@ -719,4 +719,21 @@ int msda_backward_f64(const double *value, const int64_t *shapes, const int64_t 
                                workspace_bytes, stream);
 }
 
+#if MSDA_ROWS_STAMP
+int msda_debug_rows_stamps(unsigned long long *out8) {
+  unsigned long long zero[8] = {0};
+  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(msda::g_rows_stamp), sizeof(zero));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(msda::g_rows_stamp), zero, sizeof(zero));
+  return (int)e;
+}
+#endif
+#if MSDA_WIN_STAMP
+// measurement builds: read and reset the window kernels' phase clocks ([forward | backward][12])
+int msda_debug_stamps(unsigned long long *out24) {
+  unsigned long long zero[24] = {0};
+  hipError_t e = hipMemcpyFromSymbol(out24, HIP_SYMBOL(msda::g_win_stamp), sizeof(zero));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(msda::g_win_stamp), zero, sizeof(zero));
+  return (int)e;
+}
+#endif
 }  // extern "C"

@@ -29,11 +29,25 @@
 #include "msda_window.h"
 #include <type_traits>
 
+#ifndef MSDA_WIN_PK_FWD
+#define MSDA_WIN_PK_FWD 0        // forward row FMAs as v_pk_fma_f32
+#endif
 #ifndef MSDA_WIN_SKIP
 #define MSDA_WIN_SKIP 0          // measurement builds only: 1 no fill, 2 no row reads (forward), 4 no output stores (forward), 8 no prefetch, 16 no saves
 #endif
 
+#ifndef MSDA_WIN_STAMP
+#define MSDA_WIN_STAMP 0         // measurement builds only: per-phase shader-clock totals of the window kernels (tools/debug/win_stamps.py)
+#endif
+
 namespace msda {
+
+#if MSDA_WIN_STAMP
+__device__ unsigned long long g_win_stamp[2][12];              // [backward][phase], summed over all waves
+#define MSDA_STAMP(i) do { const long long t_ = clock64(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define MSDA_STAMP(i) do { } while (0)
+#endif
 
 typedef float v2f __attribute__((ext_vector_type(2)));        // packed pair: v_pk_fma_f32 does two FMAs per lane and issue slot
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -172,7 +186,11 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
   WinQuery e1 = u1.ok ? load_entry(u1.it, u1.ps) : WinQuery{-1, 0};
   bool first = true;
 
+#if MSDA_WIN_STAMP
+  long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
+#endif
   while (true) {
+    MSDA_STAMP(0);
     const Item it = cur.it;
     const int ps = cur.ps;
     In in = (MSDA_WIN_SKIP & 8) ? load_unit(it, load_entry(it, ps)) : nxt;
@@ -181,6 +199,10 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
     asm volatile("" : "+v"(in.lc.x), "+v"(in.lc.y), "+v"(in.lc.z), "+v"(in.lc.w), "+v"(in.aw.x), "+v"(in.aw.y), "+v"(in.rf.x),
                  "+v"(in.rf.y) : : "memory");
     if (BWD) asm volatile("" : "+v"(in.go.x), "+v"(in.go.y), "+v"(in.go.z), "+v"(in.go.w) : : "memory");
+#if MSDA_WIN_STAMP
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    MSDA_STAMP(7);
+#endif
     const AxisSpec *ay_tab = g.ax[it.ty], *ax_tab = g.ax[g.n_ty + it.tx];
     const float *value_bm = value + (long long)it.b * S * tok + it.m * 32;
     int base1, base2, base3;
@@ -227,6 +249,7 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
     int far_points = 0;      // backward with the row-tile scatter: which of the two points it does not cover
     int padded = 0;          // MASKED backward: bit 4 k2 + c = corner c of point k2 sits on a padded token
     int out_pts = 0;         // bit k2: point k2 lies outside its window (fetched from global memory in the fix-up pass)
+    int swapped = 0;         // backward: bit 2 k2 / 2 k2 + 1 = the top / bottom corner pair of point k2 is read right corner first
     const int zero_rot = kZeroOff + rot * 16;
     auto taps = [&]() {
 #pragma unroll
@@ -263,18 +286,37 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
       }
       if (BWD && far_reach >= 0 && live && tp.valid && !near_point(tp.h_low, tp.w_low, in.cf_y, in.cf_x, far_reach))
         far_points |= 1 << k2;
+      // Bank parity: a ds_read_b128 is served in groups of 16 lanes over 16 sixteen-byte bank slots; a 128-byte row covers the
+      // 8 slots of its parity, and in every group exactly two lanes share a slot position (rot ^ s) -- lanes 16 apart.  The
+      // left / right corners of a footprint are neighbouring rows (opposite parity): the lane with bit 4 clear reads the
+      // even one first, its partner the odd one, so the two never meet (counters: every group took 2 cycles before).
+      {
+        // (a point outside its window keeps its order: the fix-up pass pairs corners and weights by index)
+        const bool sw_t = use && (((off[k2][0] >> 7) ^ (lane >> 4)) & 1) != 0, sw_b = use && (((off[k2][2] >> 7) ^ (lane >> 4)) & 1) != 0;
+        const int o0 = off[k2][0], o1 = off[k2][1], o2 = off[k2][2], o3 = off[k2][3];
+        off[k2][0] = sw_t ? o1 : o0; off[k2][1] = sw_t ? o0 : o1;
+        off[k2][2] = sw_b ? o3 : o2; off[k2][3] = sw_b ? o2 : o3;
+        if (BWD) swapped |= ((sw_t ? 1 : 0) | (sw_b ? 2 : 0)) << (2 * k2);
+        else {
+          const float w0 = cw[k2][0], w1 = cw[k2][1], w2 = cw[k2][2], w3 = cw[k2][3];
+          cw[k2][0] = sw_t ? w1 : w0; cw[k2][1] = sw_t ? w0 : w1;
+          cw[k2][2] = sw_b ? w3 : w2; cw[k2][3] = sw_b ? w2 : w3;
+        }
+      }
     }
       // the taps are final HERE (the asm statements consume them): otherwise the compiler sinks the tap arithmetic into the
       // row loops below -- behind the fill's wait instead of under it, with all its intermediates alive across the loops
       asm volatile("" : "+v"(off[0][0]), "+v"(off[0][1]), "+v"(off[0][2]), "+v"(off[0][3]), "+v"(off[1][0]), "+v"(off[1][1]),
                    "+v"(off[1][2]), "+v"(off[1][3]) : : "memory");
       asm volatile("" : "+v"(cw[0][0]), "+v"(cw[0][1]), "+v"(cw[0][2]), "+v"(cw[0][3]), "+v"(cw[1][0]), "+v"(cw[1][1]),
-                   "+v"(cw[1][2]), "+v"(cw[1][3]), "+v"(out_pts) : : "memory");
+                   "+v"(cw[1][2]), "+v"(cw[1][3]), "+v"(out_pts), "+v"(swapped) : : "memory");
     };
     if (ps == 0) {
       // ---- LDS-DMA fill of the four windows: thread -> (row, 16-byte slot); a wave instruction lands 8 consecutive rows.
       // Level l's window starts at LDS row base_l (multiple of 8), levels in order.
+      MSDA_STAMP(8);
       if (!first) __syncthreads();                                        // every wave has finished with the previous windows
+      MSDA_STAMP(9);
       int rows = 0;
 #pragma unroll
       for (int l = 0; l < 4; ++l) {
@@ -293,14 +335,19 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
         }
         rows += (n_rows + 7) & ~7;
       }
+      MSDA_STAMP(10);
       taps();
+      MSDA_STAMP(1);
       // this wave's share of the windows has landed.  The builtin, not inline asm: the wait-count pass must KNOW that nothing
       // is outstanding here.   (vmcnt 0, expcnt 7, lgkmcnt 15)
       __builtin_amdgcn_s_waitcnt(0x0F70);
+      MSDA_STAMP(2);
       __syncthreads();                                                    // ... and everyone else's
+      MSDA_STAMP(3);
       first = false;
     } else {
       taps();
+      MSDA_STAMP(1);
     }
 
     // ---- the next unit's inputs: requested now, consumed at the top of the next iteration; behind them the table entry of
@@ -317,6 +364,7 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
       *reinterpret_cast<float2 *>(grad_attw + plane + pl) = a2;
     }
 
+    MSDA_STAMP(4);
     // one corner: the whole 128-byte row; register s receives 16-byte slot s ^ rot with rot = sub ^ (pair of the wave): the
     // 8 lanes of a pair start on 8 different slots and so do the 8 lanes with equal `sub` (whose rows are neighbours when
     // neighbouring queries sample alike: same bank half) -- and the forward's reduce-scatter needs no lane-dependent selects.
@@ -350,11 +398,20 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
             half_row(off[k2][c], h, vv);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
+#if MSDA_WIN_PK_FWD
+              // two channels per issue slot (v_pk_fma_f32 / v_pk_mul_f32; the weight is the same in both halves)
+              const v2f w2 = (v2f){w, w}, lo = (v2f){vv[s].x, vv[s].y}, hi = (v2f){vv[s].z, vv[s].w};
+              v2f a_lo = (v2f){acc[4 * h + s].x, acc[4 * h + s].y}, a_hi = (v2f){acc[4 * h + s].z, acc[4 * h + s].w};
+              if (k2 == 0 && c == 0) { a_lo = w2 * lo; a_hi = w2 * hi; }
+              else { a_lo = __builtin_elementwise_fma(w2, lo, a_lo); a_hi = __builtin_elementwise_fma(w2, hi, a_hi); }
+              acc[4 * h + s] = make_float4(a_lo.x, a_lo.y, a_hi.x, a_hi.y);
+#else
               if (k2 == 0 && c == 0)        // the first corner initialises the accumulators (32 moves fewer)
                 acc[4 * h + s] = make_float4(w * vv[s].x, w * vv[s].y, w * vv[s].z, w * vv[s].w);
               else {
                 acc[4 * h + s].x += w * vv[s].x; acc[4 * h + s].y += w * vv[s].y; acc[4 * h + s].z += w * vv[s].z; acc[4 * h + s].w += w * vv[s].w;
               }
+#endif
             }
             // one half row (4 loads) at a time: the accumulation has to be finished HERE (the asm statement consumes it),
             // before the next loads -- otherwise the compiler loads many rows first and spills
@@ -365,6 +422,7 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+      MSDA_STAMP(5);
       // corners outside their window (they read the zero row above): from global memory, one 16-byte slot at a time.  A pass
       // of its own, so that its addresses and loads do not occupy registers across the row loops; skipped by a wave without
       // such a corner (the usual case)
@@ -473,6 +531,16 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+      MSDA_STAMP(5);
+      if (swapped) {                                                      // back to corner order
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const bool sw_t = (swapped & (1 << (2 * k2))) != 0, sw_b = (swapped & (2 << (2 * k2))) != 0;
+          const float d0 = d[k2][0], d1 = d[k2][1], d2 = d[k2][2], d3 = d[k2][3];
+          d[k2][0] = sw_t ? d1 : d0; d[k2][1] = sw_t ? d0 : d1;
+          d[k2][2] = sw_b ? d3 : d2; d[k2][3] = sw_b ? d2 : d3;
+        }
+      }
       if (outside) {                                                      // see the forward
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
@@ -522,10 +590,15 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
       }
     }
 
+    MSDA_STAMP(6);
     if (!more) break;
     cur = u1;
     u1 = u2;
   }
+#if MSDA_WIN_STAMP
+  if (lane == 0)
+    for (int i = 0; i < 12; ++i) atomicAdd(&g_win_stamp[BWD ? 1 : 0][i], (unsigned long long)st_acc[i]);
+#endif
 }
 
 }  // namespace msda

@@ -19,7 +19,18 @@
 #include "msda_common.h"
 #include "msda_scatter_plan.h"
 
+#ifndef MSDA_ROWS_STAMP
+#define MSDA_ROWS_STAMP 0        // measurement builds only: per-phase shader-clock totals (tools/debug/win_stamps.py)
+#endif
+
 namespace msda {
+
+#if MSDA_ROWS_STAMP
+__device__ unsigned long long g_rows_stamp[8];
+#define ROWS_STAMP(i) do { const long long t_ = clock64(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define ROWS_STAMP(i) do { } while (0)
+#endif
 
 typedef float rows_v2f __attribute__((ext_vector_type(2)));      // packed pair: v_pk_fma_f32
 
@@ -147,8 +158,16 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
     c_next[u] = candidate(cand_index(1, u));
   }
   lds_barrier();
+#if MSDA_ROWS_STAMP
+  long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
+#endif
 
   for (int k = 0; k < n_batches; ++k) {
+    ROWS_STAMP(0);
+#if MSDA_ROWS_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ROWS_STAMP(7);
+#endif
     // ---- 1. this thread's two points -------------------------------------------------------------------------------
     unsigned pend = 0;                                     // bit 4 u + c: corner c of sub-slot u still has to be placed
     int rows[kRowSub][4];
@@ -188,6 +207,7 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
       in[u] = fetch(cand_index(k + 1, u), cur[u]);
       c_next[u] = candidate(cand_index(k + 2, u));
     }
+    ROWS_STAMP(1);
     // ---- 2./3. buckets and row sums; a row whose bucket overflows (many points on one pixel) takes more rounds -----------
     bool again;
     do {
@@ -210,7 +230,9 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
             pend &= ~(1u << (4 * u + c));
           }
       if (pend) overflow = 1;                // rare
+      ROWS_STAMP(2);
       lds_barrier();
+      ROWS_STAMP(3);
       if (r < n_rows) {
         const int n = min((int)count[r], cap);
         const uint2 *bk = bucket + r * bstride;
@@ -228,7 +250,9 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
         }
         if (half == 0) count[r] = 0;         // the row's two lanes sit in one wave: both have read it
       }
+      ROWS_STAMP(4);
       lds_barrier();                         // orders the gather before the next appends / grad_out rows
+      ROWS_STAMP(5);
       again = overflow != 0;                 // written before the first barrier of the round: the same value for everyone
       if (again) {
         lds_barrier();
@@ -238,6 +262,11 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
     } while (again);
   }
 
+#if MSDA_ROWS_STAMP
+  ROWS_STAMP(6);
+  if ((threadIdx.x & 63) == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_rows_stamp[i], (unsigned long long)st_acc[i]);
+#endif
   // ---- write the tile -------------------------------------------------------------------------------------------------
   float4 acc[4];
 #pragma unroll
