@@ -136,16 +136,20 @@ def mha_forward(mha, query, key, value):
     Lq, B, _ = query.shape
     Lk = key.size(0)
     lin = torch.nn.functional.linear
+    # row blocks of the packed projection and column blocks of a merged output come from ONE split each: its backward is a
+    # single concatenation, where every `w[a:b]` slice would zero-fill a full-size gradient, copy its block in and have
+    # autograd add the pieces (5 launches per pair; 15 per call over weights, biases and activations)
     if query is key:                                    # depth encoder: q = k = src + pos, v = src
-        qk = lin(query, w[:2 * E], bias[:2 * E])
-        q, k = qk[..., :E], qk[..., E:]
-        v = lin(value, w[2 * E:], bias[2 * E:])
+        (w_qk, w_v), (b_qk, b_v) = w.split([2 * E, E]), bias.split([2 * E, E])
+        q, k = lin(query, w_qk, b_qk).split(E, -1)
+        v = lin(value, w_v, b_v)
     elif key is value:                                  # decoder: k = v = depth-aware tokens
-        q = lin(query, w[:E], bias[:E])
-        kv = lin(key, w[E:], bias[E:])
-        k, v = kv[..., :E], kv[..., E:]
+        (w_q, w_kv), (b_q, b_kv) = w.split([E, 2 * E]), bias.split([E, 2 * E])
+        q = lin(query, w_q, b_q)
+        k, v = lin(key, w_kv, b_kv).split(E, -1)
     else:
-        q, k, v = lin(query, w[:E], bias[:E]), lin(key, w[E:2 * E], bias[E:2 * E]), lin(value, w[2 * E:], bias[2 * E:])
+        (w_q, w_k, w_v), (b_q, b_k, b_v) = w.split(E), bias.split(E)
+        q, k, v = lin(query, w_q, b_q), lin(key, w_k, b_k), lin(value, w_v, b_v)
     heads = lambda t, L: t.unflatten(-1, (H, 32)).permute(1, 2, 0, 3)           # [L,B,E] -> [B,H,L,32] view
     o = attention(heads(q, Lq), heads(k, Lk), heads(v, Lk), mha.dropout if mha.training else 0.0)
     return mha.out_proj(o.permute(2, 0, 1, 3).reshape(Lq, B, E))

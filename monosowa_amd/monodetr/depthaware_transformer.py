@@ -348,7 +348,7 @@ class DepthAwareDecoder(nn.Module):
                     new_ref = tmp + inverse_sigmoid(reference_points)
                 else:
                     new_ref = torch.cat([tmp[..., :2] + inverse_sigmoid(reference_points), tmp[..., 2:]], -1)
-                reference_points = new_ref.sigmoid().detach()
+                reference_points = new_ref.detach().sigmoid()
             else:
                 reference_dims = None
             if reference_dims is None:
@@ -358,6 +358,9 @@ class DepthAwareDecoder(nn.Module):
                 inter_refs.append(reference_points)
                 inter_dims.append(reference_dims)
         if self.return_intermediate:
+            # the per-layer tensors themselves, for callers that index the stacks layer by layer (MonoDETR.forward): a
+            # `stack[l]` select would zero-fill and copy a full [n_layers, B, Q, C] gradient per layer in the backward
+            self.inter_outputs, self.inter_dims = inter, inter_dims
             return torch.stack(inter), torch.stack(inter_refs), torch.stack(inter_dims)
         return output, reference_points
 

@@ -27,6 +27,7 @@ def _clones(module, n):
 MERGE_HEADS = True
 FUSED_HEAD_TAIL = True     # box sigmoid + regressed / geometric / depth-map depth average per level as one kernel each way
 REUSE_BBOX_RAW = True
+USE_LAYER_TENSORS = True   # heads read the decoder's per-layer tensors instead of selects of its stacked outputs
 
 
 class MonoDETR(nn.Module):
@@ -152,29 +153,37 @@ class MonoDETR(nn.Module):
         coords, classes, dims3d, depths, angles = [], [], [], [], []
         fu = calibs[:, 0, 0].unsqueeze(1)
         img_h = img_sizes[:, 1:2]
+        img_h_f = img_h.to(torch.float32) if FUSED_HEAD_TAIL else img_h     # loaders hand int32 sizes; the products below promote them
+        # the decoder's per-layer tensors, not selects of its stacks (same values; see DepthAwareDecoder.forward)
+        dec = self.depthaware_transformer.decoder
+        hs_l = getattr(dec, "inter_outputs", None)
+        hs_l = hs_l if hs_l is not None and len(hs_l) == hs.shape[0] and USE_LAYER_TENSORS else hs.unbind(0)
+        dims_l = getattr(dec, "inter_dims", None)
+        dims_l = dims_l if dims_l is not None and len(dims_l) == hs.shape[0] and USE_LAYER_TENSORS else inter_references_dim.unbind(0)
         for lvl in range(hs.shape[0]):
             reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
             # the decoder evaluated bbox_embed[lvl] on the same hs[lvl] for its reference refinement (whose result it
             # detaches); the reference evaluates it a second time here (monodetr.py:222) -- same values, so reuse the
             # tensor (its graph carries the gradient the recomputation would have produced)
             raw = getattr(self.depthaware_transformer.decoder, "bbox_raw", None)
-            tmp = raw[lvl] if raw and len(raw) == hs.shape[0] and REUSE_BBOX_RAW else self.bbox_embed[lvl](hs[lvl])
+            tmp = raw[lvl] if raw and len(raw) == hs.shape[0] and REUSE_BBOX_RAW else self.bbox_embed[lvl](hs_l[lvl])
             if reference.shape[-1] == 6:
                 tmp = tmp + reference
             else:
                 assert reference.shape[-1] == 2
-                tmp = torch.cat([tmp[..., :2] + reference, tmp[..., 2:]], -1)
+                t_xy, t_rest = tmp.split([2, tmp.shape[-1] - 2], -1)
+                tmp = torch.cat([t_xy + reference, t_rest], -1)
             if MERGE_HEADS:
                 # class / depth / angle heads read the same hs[lvl]: first layers as one GEMM
-                cls, depth_reg, angle = merged_first_layers(hs[lvl], [self.class_embed[lvl], self.depth_embed[lvl], self.angle_embed[lvl]])
+                cls, depth_reg, angle = merged_first_layers(hs_l[lvl], [self.class_embed[lvl], self.depth_embed[lvl], self.angle_embed[lvl]])
             else:
-                cls, depth_reg, angle = self.class_embed[lvl](hs[lvl]), None, None
+                cls, depth_reg, angle = self.class_embed[lvl](hs_l[lvl]), None, None
             classes.append(cls)
-            size3d = inter_references_dim[lvl]
+            size3d = dims_l[lvl]
             dims3d.append(size3d)
-            if FUSED_HEAD_TAIL and depth_reg is not None and head_tail_supported(tmp, size3d, depth_reg, weighted_depth, fu, img_h):
+            if FUSED_HEAD_TAIL and depth_reg is not None and head_tail_supported(tmp, size3d, depth_reg, weighted_depth, fu, img_h_f):
                 # sigmoid of the box logits + the three-way depth average below: one HIP kernel each way (csrc/head_tail.hip)
-                outputs_coord, depth_ave = head_tail(tmp, size3d, depth_reg, weighted_depth, fu, img_h)
+                outputs_coord, depth_ave = head_tail(tmp, size3d, depth_reg, weighted_depth, fu, img_h_f)
                 coords.append(outputs_coord)
                 depths.append(depth_ave)
                 angles.append(angle)
@@ -186,7 +195,7 @@ class MonoDETR(nn.Module):
             box2d_height = torch.clamp((outputs_coord[:, :, 4] + outputs_coord[:, :, 5]) * img_h, min=1.0)
             depth_geo = size3d[:, :, 0] / box2d_height * fu
             if depth_reg is None:
-                depth_reg = self.depth_embed[lvl](hs[lvl])
+                depth_reg = self.depth_embed[lvl](hs_l[lvl])
             # depth read from the predicted depth map at the projected 3D centre (:254-259)
             centre = ((outputs_coord[..., :2] - 0.5) * 2).unsqueeze(2).detach()
             depth_map = F.grid_sample(weighted_depth.unsqueeze(1), centre, mode="bilinear",
@@ -195,7 +204,7 @@ class MonoDETR(nn.Module):
                                     + depth_geo.unsqueeze(-1) + depth_map) / 3,
                                    depth_reg[:, :, 1:2]], -1)
             depths.append(depth_ave)
-            angles.append(angle if angle is not None else self.angle_embed[lvl](hs[lvl]))
+            angles.append(angle if angle is not None else self.angle_embed[lvl](hs_l[lvl]))
 
         out = {"pred_logits": classes[-1], "pred_boxes": coords[-1], "pred_3d_dim": dims3d[-1],
                "pred_depth": depths[-1], "pred_angle": angles[-1],

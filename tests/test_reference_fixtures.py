@@ -293,6 +293,16 @@ def test_monodetr_heads_equal_reference_class_gpu(golden_dir):
     g = _npz(golden_dir, "monodetr_heads")
     _heads_case(g, "cuda", torch.float64, 2e-6)
     _heads_case(g, "cuda", torch.float32, 3e-4)
+    # the loaders hand image sizes as int32 (kitti_dataset / synthetic): same values, and the fused head-tail kernel must be
+    # the path that runs
+    model = _build_monodetr(g, "cuda", torch.float32).train()
+    calibs = torch.from_numpy(g["calibs"]).to(device="cuda", dtype=torch.float32)
+    sizes = torch.from_numpy(g["img_sizes"])
+    assert (sizes == sizes.round()).all()
+    out = model(torch.zeros(2, 3, 96, 128, device="cuda"), calibs, None, sizes.to(device="cuda", dtype=torch.int32))
+    assert "HeadTail" in type(out["pred_depth"].grad_fn).__name__, type(out["pred_depth"].grad_fn).__name__
+    for k in ("pred_boxes", "pred_depth"):
+        assert _rel(out[k], g["train_" + k]) <= 3e-4, k
 
 
 # ---- DDN depth-map loss kernels (csrc/ddn_loss.hip) vs the reference DDNLoss fixture --------------------------------------
