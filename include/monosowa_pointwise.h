@@ -138,6 +138,15 @@ int mono_focal_fwd_f32(const float *logits, const long long *idx, const long lon
 int mono_focal_bwd_f32(const float *logits, const long long *idx, const long long *labels, const float *grad_out, float *grad_logits,
                        int NL, int B, int Q, int C, int K, float alpha, float gamma, void *stream);
 
+/* The Hungarian matcher's cost, restricted to each image's own targets (reference matcher.py:53-88: focal-style class cost, L1
+ * of the projected 3-D centre and of (l, r, t, b), generalised IoU, weighted): logits [NL, B, Q, C], boxes [NL, B, Q, 6] (cx, cy, l,
+ * r, t, b); labels [T] int64 and tboxes [T, 6] of the batch's concatenated targets; cols [B, N] int64 = flat target of slot j of
+ * image b (padding slots repeat a valid target).  out [NL, B, Q, N].  Every operation is rounded like the PyTorch expression's
+ * (no contraction), so the assignments are the reference's. */
+int mono_match_cost_f32(const float *logits, const float *boxes, const long long *labels, const float *tboxes, const long long *cols,
+                        float *out, int NL, int B, int Q, int C, int N, float w_class, float w_3d, float w_bbox, float w_giou,
+                        void *stream);
+
 /* Per-level tail of MonoDETR's detection heads (monodetr.py:238-263), one launch each way: coords [B, Q, 6] = sigmoid(tmp),
  * depth_ave [B, Q, 2] = ((1 / (sigmoid(depth_reg0) + 1e-6) - 1 + size3d0 / max((coords4 + coords5) img_h, 1) fu
  *                        + bilinear(wdepth [B, H, W]; coords0, coords1 -- F.grid_sample, align_corners, zero padding)) / 3, depth_reg1).

@@ -269,4 +269,82 @@ __global__ __launch_bounds__(kFocalThreads) void focal_bwd_kernel(const FocalArg
   }
 }
 
+
+// ---- the matcher's cost blocks (matcher.py:60-99 of this repo = the reference's matcher.py:53-88 restricted to each image's own
+// targets) as one launch.  One thread per (layer, image, query, target slot).  Every operation is the PyTorch expression's own,
+// rounded individually and in its order (no contraction: rn()), with the same elementary functions (expf / logf of the device
+// library): the floats -- and with them the assignments -- are those of the ~70 elementwise launches it replaces.
+// exp / log exactly as PyTorch's elementwise kernels evaluate them: the device library's functions by name.  (hipcc 7.2 expands a
+// plain `logf` through the backend's own lowering, which differs from __ocml_log_f32 in the last bit for a third of the arguments
+// in (0, 1): tools/ubench/log_variants.hip.)
+extern "C" __device__ float __ocml_exp_f32(float);
+extern "C" __device__ float __ocml_log_f32(float);
+
+struct CostArgs {
+  const float *logits, *boxes;         // [NL, B, Q, C], [NL, B, Q, 6]
+  const long long *labels;             // [T]
+  const float *tboxes;                 // [T, 6]
+  const long long *cols;               // [B, N]: flat target of slot j of image b (padding slots repeat a valid target)
+  int NL, B, Q, C, N;
+  float w_class, w_3d, w_bbox, w_giou;
+};
+
+__device__ __forceinline__ float rn_mul(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float rn_add(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float rn_sub(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
+__global__ __launch_bounds__(256) void match_cost_kernel(const CostArgs a, float *__restrict__ out) {
+  const long long n = (long long)a.NL * a.B * a.Q * a.N;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int j = (int)(i % a.N);
+  const long long cell = i / a.N;                          // (l, b, q)
+  const int b = (int)((cell / a.Q) % a.B);
+  const long long t = a.cols[(long long)b * a.N + j];
+  const long long id = a.labels[t];
+  // focal-style classification cost of the target's class
+  const float x = a.logits[cell * a.C + id];
+  const float p = 1.0f / rn_add(1.0f, __ocml_exp_f32(-x));                                           // sigmoid
+  const float neg = rn_mul(rn_mul(0.75f, rn_mul(p, p)), -__ocml_log_f32(rn_add(rn_sub(1.0f, p), 1e-8f)));
+  const float omp = rn_sub(1.0f, p);
+  const float pos = rn_mul(rn_mul(0.25f, rn_mul(omp, omp)), -__ocml_log_f32(rn_add(p, 1e-8f)));
+  const float cost_class = rn_sub(pos, neg);
+  const float *pb = a.boxes + cell * 6, *tb = a.tboxes + t * 6;
+  float pa[6], ta[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { pa[k] = pb[k]; ta[k] = tb[k]; }
+  const float c3d = rn_add(fabsf(rn_sub(pa[0], ta[0])), fabsf(rn_sub(pa[1], ta[1])));
+  float cbb = rn_add(fabsf(rn_sub(pa[2], ta[2])), fabsf(rn_sub(pa[3], ta[3])));
+  cbb = rn_add(cbb, fabsf(rn_sub(pa[4], ta[4])));
+  cbb = rn_add(cbb, fabsf(rn_sub(pa[5], ta[5])));
+  // (cx, cy, l, r, t, b) -> (cx - l, cy - t, cx + r, cy + b)
+  const float ax0 = rn_sub(pa[0], pa[2]), ay0 = rn_sub(pa[1], pa[4]), ax1 = rn_add(pa[0], pa[3]), ay1 = rn_add(pa[1], pa[5]);
+  const float bx0 = rn_sub(ta[0], ta[2]), by0 = rn_sub(ta[1], ta[4]), bx1 = rn_add(ta[0], ta[3]), by1 = rn_add(ta[1], ta[5]);
+  const float area1 = rn_mul(rn_sub(ax1, ax0), rn_sub(ay1, ay0)), area2 = rn_mul(rn_sub(bx1, bx0), rn_sub(by1, by0));
+  // torch.min / torch.max / clamp(min=0) hand NaNs on (fminf / fmaxf would drop them)
+  auto tmin = [](const float u, const float v) { return (u != u || u < v) ? u : v; };
+  auto tmax = [](const float u, const float v) { return (u != u || u > v) ? u : v; };
+  auto relu = [](const float u) { return u < 0.f ? 0.f : u; };
+  const float w = relu(rn_sub(tmin(ax1, bx1), tmax(ax0, bx0))), h = relu(rn_sub(tmin(ay1, by1), tmax(ay0, by0)));
+  const float inter = rn_mul(w, h);
+  const float uni = rn_sub(rn_add(area1, area2), inter);
+  const float iou = inter / uni;
+  const float wc = relu(rn_sub(tmax(ax1, bx1), tmin(ax0, bx0))), hc = relu(rn_sub(tmax(ay1, by1), tmin(ay0, by0)));
+  const float area = rn_mul(wc, hc);
+  const float cost_giou = -rn_sub(iou, rn_sub(area, uni) / area);
+  float c = rn_add(rn_mul(a.w_bbox, cbb), rn_mul(a.w_3d, c3d));
+  c = rn_add(c, rn_mul(a.w_class, cost_class));
+  c = rn_add(c, rn_mul(a.w_giou, cost_giou));
+  out[i] = c;
+}
+
 }  // namespace mono

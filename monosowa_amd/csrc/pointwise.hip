@@ -679,6 +679,20 @@ int mono_focal_bwd_f32(const float *logits, const long long *idx, const long lon
 }
 
 
+// ---- the matcher's per-image cost blocks (matched_losses.hip) ------------------------------------------------------------------
+int mono_match_cost_f32(const float *logits, const float *boxes, const long long *labels, const float *tboxes, const long long *cols,
+                        float *out, int NL, int B, int Q, int C, int N, float w_class, float w_3d, float w_bbox, float w_giou,
+                        void *stream) {
+  if (!logits || !boxes || !labels || !tboxes || !cols || !out) return -1;
+  if (NL <= 0 || B <= 0 || Q <= 0 || C <= 0 || N <= 0) return -2;
+  const long long n = (long long)NL * B * Q * N;
+  if (n > (1ll << 31)) return -2;
+  const mono::CostArgs a{logits, boxes, labels, tboxes, cols, NL, B, Q, C, N, w_class, w_3d, w_bbox, w_giou};
+  mono::match_cost_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(a, out);
+  return (int)hipGetLastError();
+}
+
+
 // ---- per-level tail of the detection heads (head_tail.hip) --------------------------------------------------------------------
 int mono_head_tail_fwd_f32(const float *tmp, const float *size3d, const float *depth_reg, const float *wdepth, const float *fu,
                            const float *img_h, float *coords, float *depth_ave, int B, int Q, int H, int W, void *stream) {

@@ -293,8 +293,10 @@ class SetCriterion(nn.Module):
         dev = logits.device
         sizes = [len(t["labels"]) for t in targets]
         T = sum(sizes)
-        flat = {k: torch.cat([t[k] for t in targets], dim=0)
-                for k in ("labels", "boxes_3d", "boxes", "depth", "size_3d", "heading_bin", "heading_res")}
+        flat_keys = ("labels", "boxes_3d", "boxes", "depth", "size_3d", "heading_bin", "heading_res")
+        flat = getattr(targets, "flat", None)              # prepare_targets hands the batch-flat tensors along (7 launches fewer)
+        if flat is None or any(k not in flat for k in flat_keys) or flat["labels"].shape[0] != T:
+            flat = {k: torch.cat([t[k] for t in targets], dim=0) for k in flat_keys}
         num_boxes = self._num_boxes(targets, group_num, dev)
 
         pending = self.matcher.match_layers_begin(logits, boxes, flat, sizes, group_num)      # cost pass + async D2H

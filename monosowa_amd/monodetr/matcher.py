@@ -12,6 +12,7 @@ from scipy.optimize import linear_sum_assignment
 from torch import nn
 
 from .box_ops import box_cxcylrtb_to_xyxy, generalized_box_iou
+from ..pointwise import match_cost_blocks, match_cost_supported
 
 
 def _pairwise_l1(a, b):
@@ -22,6 +23,7 @@ def _pairwise_l1(a, b):
     return out
 
 
+FUSED_COST = True      # ... from one HIP launch (pointwise.match_cost_blocks) instead of ~70 elementwise ones; same floats
 BLOCK_COST = True      # match_layers: per-image cost blocks only (False: full cross matrix + gather, as the reference)
 
 
@@ -131,7 +133,11 @@ class HungarianMatcher(nn.Module):
         offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
         cols = np.minimum(offs[:, None] + np.arange(maxn)[None, :], T - 1)            # [B, maxn], clamped padding
         cols = torch.as_tensor(cols, dtype=torch.int64).to(pred_logits.device, non_blocking=True)
-        if BLOCK_COST:
+        if BLOCK_COST and FUSED_COST and match_cost_supported(pred_logits, pred_boxes):
+            # the same floats from one HIP launch (csrc/matched_losses.hip: match_cost_kernel)
+            blocks = match_cost_blocks(pred_logits, pred_boxes, flat_targets["labels"], flat_targets["boxes_3d"], cols, self.cost_class,
+                                       self.cost_3dcenter, self.cost_bbox, self.cost_giou)
+        elif BLOCK_COST:
             blocks = self.cost_blocks(pred_logits, pred_boxes, flat_targets["labels"][cols], flat_targets["boxes_3d"][cols])
         else:
             C = self.cost_matrix({"pred_logits": pred_logits.flatten(0, 1), "pred_boxes": pred_boxes.flatten(0, 1)},

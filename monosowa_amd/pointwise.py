@@ -11,7 +11,7 @@ _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmono
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
-           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32")
+           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32")
 _lib = None
 
 
@@ -73,6 +73,8 @@ def load():
         lib.mono_depth_expect_fwd_f32.argtypes = [P] * 3 + [I] * 4 + [LL] * 3 + [P]
         lib.mono_depth_expect_bwd_f32.restype = I
         lib.mono_depth_expect_bwd_f32.argtypes = [P] * 5 + [I] * 4 + [LL] * 3 + [P]
+        lib.mono_match_cost_f32.restype = I
+        lib.mono_match_cost_f32.argtypes = [P] * 6 + [I] * 5 + [F] * 4 + [P]
         lib.mono_focal_fwd_f32.restype = I
         lib.mono_focal_fwd_f32.argtypes = [P] * 5 + [I] * 5 + [F, F, P]
         lib.mono_focal_bwd_f32.restype = I
@@ -703,6 +705,30 @@ def focal_classification(logits, idx, labels, sizes, alpha, gamma=2.0):
     class error in % and the cardinality error (monodetr.py:396-449) -- one HIP launch each way."""
     return _FocalClassification.apply(logits.contiguous(), idx.contiguous(), labels.to(torch.int64).contiguous(),
                                       sizes.to(torch.float32).contiguous(), float(alpha), float(gamma))
+
+
+# ---- the matcher's cost blocks (csrc/matched_losses.hip) ---------------------------------------------------------------------------
+def match_cost_supported(logits, boxes):
+    return logits.is_cuda and logits.dtype == torch.float32 and boxes.dtype == torch.float32 and boxes.shape[-1] == 6 and logits.dim() == 4
+
+
+@torch.no_grad()
+def match_cost_blocks(logits, boxes, labels, tboxes, cols, w_class, w_3d, w_bbox, w_giou):
+    """[NL, B, Q, N] cost of every query against its image's own targets (matcher.py:53-88 per image block): one launch, the
+    floats of the PyTorch expressions."""
+    NL, B, Q, C = logits.shape
+    N = cols.size(1)
+    logits, boxes = logits.contiguous(), boxes.contiguous()
+    labels, tboxes = labels.to(torch.int64).contiguous(), tboxes.to(torch.float32).contiguous()
+    cols = cols.to(torch.int64).contiguous()
+    out = torch.empty((NL, B, Q, N), dtype=torch.float32, device=logits.device)
+    with torch.cuda.device(logits.device):
+        code = load().mono_match_cost_f32(logits.data_ptr(), boxes.data_ptr(), labels.data_ptr(), tboxes.data_ptr(), cols.data_ptr(),
+                                          out.data_ptr(), NL, B, Q, C, N, float(w_class), float(w_3d), float(w_bbox), float(w_giou),
+                                          raw_stream())
+    if code:
+        raise RuntimeError("mono_match_cost_f32 failed with code %d" % code)
+    return out
 
 
 # ---- per-level tail of the detection heads (csrc/head_tail.hip) -------------------------------------------------------------------

@@ -122,5 +122,13 @@ def prepare_targets(targets, batch_size):
         mask = targets["mask_2d"][:batch_size]
         b_idx, s_idx = mask.nonzero(as_tuple=True)                 # one sync
         counts = torch.bincount(b_idx, minlength=batch_size).tolist() if b_idx.numel() else [0] * batch_size
-    per_key = {k: v[b_idx, s_idx].split(counts) for k, v in targets.items() if k in keys}
-    return [{k: per_key[k][b] for k in per_key} for b in range(batch_size)]
+    flat = {k: v[b_idx, s_idx] for k, v in targets.items() if k in keys}
+    per_key = {k: v.split(counts) for k, v in flat.items()}
+    out = TargetList({k: per_key[k][b] for k in per_key} for b in range(batch_size))
+    out.flat = flat                 # the per-image entries are views of these: the criterion need not concatenate them again
+    return out
+
+
+class TargetList(list):
+    """The reference's list of per-image target dicts, remembering the batch-flat tensors its entries are views of."""
+    flat = None

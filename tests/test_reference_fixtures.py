@@ -443,3 +443,26 @@ def test_head_tail_kernels_equal_the_pytorch_expressions():
     for name, a, b in zip(("d tmp", "d size3d", "d depth_reg", "d weighted_depth"), got_in, ref_in):
         err = (a.grad.cpu().double() - b.grad).abs().max().item()
         assert err <= 2e-5 * b.grad.abs().max().item(), (name, err)     # (bilinear weights from an f32 pixel coordinate up to 79)
+
+
+@pytest.mark.gpu
+def test_match_cost_kernel_reproduces_the_pytorch_floats():
+    """csrc/matched_losses.hip::match_cost_kernel against HungarianMatcher.cost_blocks (the operation sequence of the reference's
+    matcher.py:53-88): BIT-identical costs -- the assignments depend on them -- over random predictions incl. degenerate boxes;
+    the criterion fixture (reference indices) runs through the same kernel."""
+    from monosowa_amd.monodetr.matcher import HungarianMatcher
+    from monosowa_amd.pointwise import match_cost_blocks
+    gen = torch.Generator().manual_seed(77)
+    NL, B, Q, C, T, N = 3, 5, 137, 3, 23, 9
+    logits = (torch.randn(NL, B, Q, C, generator=gen) * 4).cuda()
+    boxes = torch.rand(NL, B, Q, 6, generator=gen).cuda()
+    boxes[0, 0, :7, 2:] = 0.0                                  # zero-area predictions: 0 / 0 in the IoU
+    labels = torch.randint(0, C, (T,), generator=gen).cuda()
+    tboxes = torch.rand(T, 6, generator=gen).cuda()
+    cols = torch.randint(0, T, (B, N), generator=gen).cuda()
+    m = HungarianMatcher(cost_class=2.0, cost_3dcenter=10.0, cost_bbox=5.0, cost_giou=2.0)
+    want = m.cost_blocks(logits, boxes, labels[cols], tboxes[cols])
+    got = match_cost_blocks(logits, boxes, labels, tboxes, cols, 2.0, 10.0, 5.0, 2.0)
+    assert got.shape == want.shape
+    same = (got == want) | (got.isnan() & want.isnan())
+    assert bool(same.all()), (int((~same).sum()), float((got - want)[~same].abs().max()))
