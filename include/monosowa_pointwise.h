@@ -153,10 +153,17 @@ int mono_match_cost_f32(const float *logits, const float *boxes, const long long
  * backward: g_coords / g_depth_ave may be NULL (no gradient); g_wdepth [B, H, W] must be ZERO on entry (atomics); the sampling
  * location carries no gradient through the depth map (detached in the reference). */
 int mono_head_tail_fwd_f32(const float *tmp, const float *size3d, const float *depth_reg, const float *wdepth, const float *fu,
-                           const float *img_h, float *coords, float *depth_ave, int B, int Q, int H, int W, void *stream);
+                           const float *img_h, float *coords, float *depth_ave, int B, int Q, int H, int W, const float *ref,
+                           int ref_dim, void *stream);
 int mono_head_tail_bwd_f32(const float *tmp, const float *size3d, const float *depth_reg, const float *wdepth, const float *fu,
                            const float *img_h, const float *g_coords, const float *g_depth_ave, float *g_tmp, float *g_size3d,
-                           float *g_depth_reg, float *g_wdepth, int B, int Q, int H, int W, void *stream);
+                           float *g_depth_reg, float *g_wdepth, int B, int Q, int H, int W, const float *ref, int ref_dim,
+                           void *stream);
+/* ref (optional, NULL = none): detached reference boxes [B, Q, ref_dim]; the box logits are then tmp + inverse_sigmoid(ref) on the
+ * first ref_dim coordinates (monodetr.py:224-232).
+ * The decoder's detached reference refinement (depthaware_transformer.py:602-613): out [n, 6] = sigmoid(tmp [n, 6] +
+ * inverse_sigmoid(ref [n, ref_dim]) on the first ref_dim coordinates). */
+int mono_refine_reference_f32(const float *tmp, const float *ref, float *out, int n, int ref_dim, void *stream);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,19 @@ struct HeadTailArgs {
   const float *wdepth;      // [B, H, W] weighted depth map
   const float *fu, *img_h;  // [B]
   int B, Q, H, W;
+  const float *ref;         // optional [B, Q, ref_dim] (no gradient): the box logits are tmp + inverse_sigmoid(ref) on the first ref_dim
+  int ref_dim;              // coordinates (monodetr.py:224-232; util/misc.py inverse_sigmoid, eps 1e-5)
 };
+
+__device__ __forceinline__ float inverse_sigmoidf_(float x) {
+  x = fminf(fmaxf(x, 0.f), 1.f);
+  return logf(fmaxf(x, 1e-5f) / fmaxf(1.f - x, 1e-5f));
+}
+// box logit k of cell i
+__device__ __forceinline__ float head_logit(const HeadTailArgs &a, int i, int k) {
+  const float t = a.tmp[i * 6 + k];
+  return (a.ref && k < a.ref_dim) ? t + inverse_sigmoidf_(a.ref[i * a.ref_dim + k]) : t;
+}
 
 struct HeadTap { int x0, y0; float wnw, wne, wsw, wse; bool nw, ne, sw, se; };
 
@@ -48,7 +60,7 @@ __global__ __launch_bounds__(256) void head_tail_fwd_kernel(const HeadTailArgs a
   const int b = i / a.Q;
   float oc[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) { oc[k] = sigmoidf_(a.tmp[i * 6 + k]); coords[i * 6 + k] = oc[k]; }
+  for (int k = 0; k < 6; ++k) { oc[k] = sigmoidf_(head_logit(a, i, k)); coords[i * 6 + k] = oc[k]; }
   const float bh = fmaxf((oc[4] + oc[5]) * a.img_h[b], 1.0f);
   const float geo = a.size3d[i * 3] / bh * a.fu[b];
   const float s = sigmoidf_(a.depth_reg[i * 2]);
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const HeadTailArgs a
   const int b = i / a.Q;
   float oc[6], goc[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) { oc[k] = sigmoidf_(a.tmp[i * 6 + k]); goc[k] = g_coords ? g_coords[i * 6 + k] : 0.f; }
+  for (int k = 0; k < 6; ++k) { oc[k] = sigmoidf_(head_logit(a, i, k)); goc[k] = g_coords ? g_coords[i * 6 + k] : 0.f; }
   const float g0 = g_dave ? g_dave[i * 2] / 3.f : 0.f, g1 = g_dave ? g_dave[i * 2 + 1] : 0.f;
   const float h = (oc[4] + oc[5]) * a.img_h[b], bh = fmaxf(h, 1.0f), fu = a.fu[b], s3 = a.size3d[i * 3];
   g_size3d[i * 3] = g0 * fu / bh;
@@ -96,6 +108,17 @@ __global__ __launch_bounds__(256) void head_tail_bwd_kernel(const HeadTailArgs a
   }
 #pragma unroll
   for (int k = 0; k < 6; ++k) g_tmp[i * 6 + k] = goc[k] * (oc[k] * (1.f - oc[k]));
+}
+
+// The decoder's iterative reference refinement (depthaware_transformer.py:602-613), detached in the reference:
+// out [n, 6] = sigmoid(tmp + inverse_sigmoid(ref) on the first ref_dim coordinates).
+__global__ __launch_bounds__(256) void refine_reference_kernel(const float *__restrict__ tmp, const float *__restrict__ ref,
+                                                               float *__restrict__ out, int n, int ref_dim) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * 6) return;
+  const int cell = i / 6, k = i - cell * 6;
+  const float t = tmp[i];
+  out[i] = sigmoidf_(k < ref_dim ? t + inverse_sigmoidf_(ref[cell * ref_dim + k]) : t);
 }
 
 }  // namespace mono

@@ -695,22 +695,31 @@ int mono_match_cost_f32(const float *logits, const float *boxes, const long long
 
 // ---- per-level tail of the detection heads (head_tail.hip) --------------------------------------------------------------------
 int mono_head_tail_fwd_f32(const float *tmp, const float *size3d, const float *depth_reg, const float *wdepth, const float *fu,
-                           const float *img_h, float *coords, float *depth_ave, int B, int Q, int H, int W, void *stream) {
+                           const float *img_h, float *coords, float *depth_ave, int B, int Q, int H, int W, const float *ref,
+                           int ref_dim, void *stream) {
   if (!tmp || !size3d || !depth_reg || !wdepth || !fu || !img_h || !coords || !depth_ave) return -1;
-  if (B <= 0 || Q <= 0 || H <= 0 || W <= 0) return -2;
-  const mono::HeadTailArgs a{tmp, size3d, depth_reg, wdepth, fu, img_h, B, Q, H, W};
+  if (B <= 0 || Q <= 0 || H <= 0 || W <= 0 || (ref && (ref_dim < 1 || ref_dim > 6))) return -2;
+  const mono::HeadTailArgs a{tmp, size3d, depth_reg, wdepth, fu, img_h, B, Q, H, W, ref, ref_dim};
   mono::head_tail_fwd_kernel<<<(B * Q + 255) / 256, 256, 0, (hipStream_t)stream>>>(a, coords, depth_ave);
   return (int)hipGetLastError();
 }
 
 int mono_head_tail_bwd_f32(const float *tmp, const float *size3d, const float *depth_reg, const float *wdepth, const float *fu,
                            const float *img_h, const float *g_coords, const float *g_depth_ave, float *g_tmp, float *g_size3d,
-                           float *g_depth_reg, float *g_wdepth, int B, int Q, int H, int W, void *stream) {
+                           float *g_depth_reg, float *g_wdepth, int B, int Q, int H, int W, const float *ref, int ref_dim,
+                           void *stream) {
   if (!tmp || !size3d || !depth_reg || !wdepth || !fu || !img_h || !g_tmp || !g_size3d || !g_depth_reg || !g_wdepth) return -1;
-  if (B <= 0 || Q <= 0 || H <= 0 || W <= 0) return -2;
-  const mono::HeadTailArgs a{tmp, size3d, depth_reg, wdepth, fu, img_h, B, Q, H, W};
+  if (B <= 0 || Q <= 0 || H <= 0 || W <= 0 || (ref && (ref_dim < 1 || ref_dim > 6))) return -2;
+  const mono::HeadTailArgs a{tmp, size3d, depth_reg, wdepth, fu, img_h, B, Q, H, W, ref, ref_dim};
   mono::head_tail_bwd_kernel<<<(B * Q + 255) / 256, 256, 0, (hipStream_t)stream>>>(a, g_coords, g_depth_ave, g_tmp, g_size3d,
                                                                                    g_depth_reg, g_wdepth);
+  return (int)hipGetLastError();
+}
+
+int mono_refine_reference_f32(const float *tmp, const float *ref, float *out, int n, int ref_dim, void *stream) {
+  if (!tmp || !ref || !out) return -1;
+  if (n <= 0 || ref_dim < 1 || ref_dim > 6 || (long long)n * 6 > (1ll << 30)) return -2;
+  mono::refine_reference_kernel<<<(n * 6 + 255) / 256, 256, 0, (hipStream_t)stream>>>(tmp, ref, out, n, ref_dim);
   return (int)hipGetLastError();
 }
 

@@ -21,7 +21,7 @@ from .. import MultiScaleDeformableAttention as _MSDA
 from ..ms_deform_attn import MSDeformAttn
 from .. import encoder_block
 from ..flash_attn import mha_forward, mha_supported
-from ..pointwise import dropout_add_layernorm, relu_dropout
+from ..pointwise import dropout_add_layernorm, refine_reference, refine_reference_supported, relu_dropout
 from ..token_linear import token_linear
 
 
@@ -162,6 +162,7 @@ class VisualEncoder(nn.Module):
 # ----------------------------------------------------------------------------------------------
 # decoder
 # ----------------------------------------------------------------------------------------------
+FUSED_REFINE = True          # the decoder's detached reference refinement as one launch (csrc/head_tail.hip)
 MERGE_VALUE_PROJ = True      # the decoder layers' value_proj(memory) as one GEMM
 
 
@@ -344,11 +345,13 @@ class DepthAwareDecoder(nn.Module):
                 else:
                     tmp, reference_dims = self.bbox_embed[lid](output), None
                 self.bbox_raw.append(tmp)
-                if reference_points.shape[-1] == 6:
-                    new_ref = tmp + inverse_sigmoid(reference_points)
+                if FUSED_REFINE and refine_reference_supported(tmp, reference_points):
+                    reference_points = refine_reference(tmp, reference_points)          # one launch, no graph (detached below anyway)
+                elif reference_points.shape[-1] == 6:
+                    reference_points = (tmp + inverse_sigmoid(reference_points)).detach().sigmoid()
                 else:
                     new_ref = torch.cat([tmp[..., :2] + inverse_sigmoid(reference_points), tmp[..., 2:]], -1)
-                reference_points = new_ref.detach().sigmoid()
+                    reference_points = new_ref.detach().sigmoid()
             else:
                 reference_dims = None
             if reference_dims is None:

@@ -30,6 +30,11 @@ REUSE_BBOX_RAW = True
 USE_LAYER_TENSORS = True   # heads read the decoder's per-layer tensors instead of selects of its stacked outputs
 
 
+def tmp_supported(ref):
+    """reference boxes the fused head tail can take itself: detached float32 CUDA [B, Q, 2 | 6]"""
+    return ref.is_cuda and ref.dtype == torch.float32 and not ref.requires_grad and ref.dim() == 3 and ref.shape[-1] in (2, 6)
+
+
 class MonoDETR(nn.Module):
     def __init__(self, backbone, depthaware_transformer, depth_predictor, num_classes, num_queries,
                  num_feature_levels, aux_loss=True, with_box_refine=False, two_stage=False, init_box=False,
@@ -161,13 +166,19 @@ class MonoDETR(nn.Module):
         dims_l = getattr(dec, "inter_dims", None)
         dims_l = dims_l if dims_l is not None and len(dims_l) == hs.shape[0] and USE_LAYER_TENSORS else inter_references_dim.unbind(0)
         for lvl in range(hs.shape[0]):
-            reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
+            ref_raw = init_reference if lvl == 0 else inter_references[lvl - 1]
+            # detached reference boxes (every level but the first, whose points come from the query embedding): the fused head
+            # tail adds inverse_sigmoid(reference) to the box logits itself
+            ref_in_kernel = FUSED_HEAD_TAIL and MERGE_HEADS and tmp_supported(ref_raw)
+            reference = None if ref_in_kernel else inverse_sigmoid(ref_raw)
             # the decoder evaluated bbox_embed[lvl] on the same hs[lvl] for its reference refinement (whose result it
             # detaches); the reference evaluates it a second time here (monodetr.py:222) -- same values, so reuse the
             # tensor (its graph carries the gradient the recomputation would have produced)
             raw = getattr(self.depthaware_transformer.decoder, "bbox_raw", None)
             tmp = raw[lvl] if raw and len(raw) == hs.shape[0] and REUSE_BBOX_RAW else self.bbox_embed[lvl](hs_l[lvl])
-            if reference.shape[-1] == 6:
+            if reference is None:
+                pass
+            elif reference.shape[-1] == 6:
                 tmp = tmp + reference
             else:
                 assert reference.shape[-1] == 2
@@ -183,11 +194,15 @@ class MonoDETR(nn.Module):
             dims3d.append(size3d)
             if FUSED_HEAD_TAIL and depth_reg is not None and head_tail_supported(tmp, size3d, depth_reg, weighted_depth, fu, img_h_f):
                 # sigmoid of the box logits + the three-way depth average below: one HIP kernel each way (csrc/head_tail.hip)
-                outputs_coord, depth_ave = head_tail(tmp, size3d, depth_reg, weighted_depth, fu, img_h_f)
+                outputs_coord, depth_ave = head_tail(tmp, size3d, depth_reg, weighted_depth, fu, img_h_f,
+                                                     ref=ref_raw if reference is None else None)
                 coords.append(outputs_coord)
                 depths.append(depth_ave)
                 angles.append(angle)
                 continue
+            if reference is None:                                           # (the fused path was planned but does not apply)
+                inv = inverse_sigmoid(ref_raw)
+                tmp = tmp + inv if inv.shape[-1] == 6 else torch.cat([tmp[..., :2] + inv, tmp[..., 2:]], -1)
             outputs_coord = tmp.sigmoid()                                   # 3D-centre projection + l,r,t,b
             coords.append(outputs_coord)
 

@@ -11,7 +11,7 @@ _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmono
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
-           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32")
+           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32")
 _lib = None
 
 
@@ -80,9 +80,11 @@ def load():
         lib.mono_focal_bwd_f32.restype = I
         lib.mono_focal_bwd_f32.argtypes = [P] * 5 + [I] * 5 + [F, F, P]
         lib.mono_head_tail_fwd_f32.restype = I
-        lib.mono_head_tail_fwd_f32.argtypes = [P] * 8 + [I] * 4 + [P]
+        lib.mono_head_tail_fwd_f32.argtypes = [P] * 8 + [I] * 4 + [P, I, P]
         lib.mono_head_tail_bwd_f32.restype = I
-        lib.mono_head_tail_bwd_f32.argtypes = [P] * 12 + [I] * 4 + [P]
+        lib.mono_head_tail_bwd_f32.argtypes = [P] * 12 + [I] * 4 + [P, I, P]
+        lib.mono_refine_reference_f32.restype = I
+        lib.mono_refine_reference_f32.argtypes = [P, P, P, I, I, P]
         _lib = lib
     return _lib
 
@@ -734,36 +736,38 @@ def match_cost_blocks(logits, boxes, labels, tboxes, cols, w_class, w_3d, w_bbox
 # ---- per-level tail of the detection heads (csrc/head_tail.hip) -------------------------------------------------------------------
 class _HeadTail(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tmp, size3d, depth_reg, wdepth, fu, img_h):
+    def forward(ctx, tmp, size3d, depth_reg, wdepth, fu, img_h, ref):
         B, Q, _ = tmp.shape
         H, W = wdepth.shape[-2:]
         coords = torch.empty((B, Q, 6), dtype=torch.float32, device=tmp.device)
         dave = torch.empty((B, Q, 2), dtype=torch.float32, device=tmp.device)
+        rp, rd = (ref.data_ptr(), ref.shape[-1]) if ref is not None else (None, 0)
         with torch.cuda.device(tmp.device):
             code = load().mono_head_tail_fwd_f32(tmp.data_ptr(), size3d.data_ptr(), depth_reg.data_ptr(), wdepth.data_ptr(), fu.data_ptr(),
-                                                 img_h.data_ptr(), coords.data_ptr(), dave.data_ptr(), B, Q, H, W, raw_stream())
+                                                 img_h.data_ptr(), coords.data_ptr(), dave.data_ptr(), B, Q, H, W, rp, rd, raw_stream())
         if code:
             raise RuntimeError("mono_head_tail_fwd_f32 failed with code %d" % code)
-        ctx.save_for_backward(tmp, size3d, depth_reg, wdepth, fu, img_h)
+        ctx.save_for_backward(tmp, size3d, depth_reg, wdepth, fu, img_h, ref)
         return coords, dave
 
     @staticmethod
     def backward(ctx, g_coords, g_dave):
-        tmp, size3d, depth_reg, wdepth, fu, img_h = ctx.saved_tensors
+        tmp, size3d, depth_reg, wdepth, fu, img_h, ref = ctx.saved_tensors
         B, Q, _ = tmp.shape
         H, W = wdepth.shape[-2:]
         g_tmp, g_size, g_dreg = torch.empty_like(tmp), torch.empty_like(size3d), torch.empty_like(depth_reg)
         g_wd = torch.zeros_like(wdepth)
         gc = g_coords.contiguous() if g_coords is not None else None
         gd = g_dave.contiguous() if g_dave is not None else None
+        rp, rd = (ref.data_ptr(), ref.shape[-1]) if ref is not None else (None, 0)
         with torch.cuda.device(tmp.device):
             code = load().mono_head_tail_bwd_f32(tmp.data_ptr(), size3d.data_ptr(), depth_reg.data_ptr(), wdepth.data_ptr(), fu.data_ptr(),
                                                  img_h.data_ptr(), gc.data_ptr() if gc is not None else None,
                                                  gd.data_ptr() if gd is not None else None, g_tmp.data_ptr(), g_size.data_ptr(),
-                                                 g_dreg.data_ptr(), g_wd.data_ptr(), B, Q, H, W, raw_stream())
+                                                 g_dreg.data_ptr(), g_wd.data_ptr(), B, Q, H, W, rp, rd, raw_stream())
         if code:
             raise RuntimeError("mono_head_tail_bwd_f32 failed with code %d" % code)
-        return g_tmp, g_size, g_dreg, g_wd, None, None
+        return g_tmp, g_size, g_dreg, g_wd, None, None, None
 
 
 def head_tail_supported(tmp, size3d, depth_reg, wdepth, fu, img_h):
@@ -772,8 +776,31 @@ def head_tail_supported(tmp, size3d, depth_reg, wdepth, fu, img_h):
         and size3d.shape[-1] == 3 and depth_reg.shape[-1] == 2 and wdepth.dim() == 3 and not fu.requires_grad and not img_h.requires_grad
 
 
-def head_tail(tmp, size3d, depth_reg, wdepth, fu, img_h):
+def head_tail(tmp, size3d, depth_reg, wdepth, fu, img_h, ref=None):
     """-> coords [B, Q, 6] = sigmoid(tmp), depth_ave [B, Q, 2] (regressed + geometric + depth-map depth averaged, log-variance):
-    monodetr.py:238-263 in one launch each way."""
+    monodetr.py:238-263 in one launch each way.  ``ref`` [B, Q, 2 | 6] (detached reference boxes): the logits are
+    ``tmp + inverse_sigmoid(ref)`` on ref's coordinates (monodetr.py:224-232) -- the 7 launches of that expression folded in."""
     c = lambda t: t.contiguous()
-    return _HeadTail.apply(c(tmp), c(size3d), c(depth_reg), c(wdepth), c(fu.reshape(-1)), c(img_h.reshape(-1)))
+    if ref is not None:
+        assert not ref.requires_grad and ref.dtype == torch.float32 and ref.shape[:2] == tmp.shape[:2]
+        ref = c(ref)
+    return _HeadTail.apply(c(tmp), c(size3d), c(depth_reg), c(wdepth), c(fu.reshape(-1)), c(img_h.reshape(-1)), ref)
+
+
+@torch.no_grad()
+def refine_reference(tmp, ref):
+    """sigmoid(tmp + inverse_sigmoid(ref) on ref's coordinates) -> [..., 6], no autograd: the decoder's reference refinement, which
+    the reference detaches (depthaware_transformer.py:602-613); ~9 launches as one."""
+    tmp, ref = tmp.detach().contiguous(), ref.detach().contiguous()
+    out = torch.empty_like(tmp)
+    n = tmp.numel() // 6
+    with torch.cuda.device(tmp.device):
+        code = load().mono_refine_reference_f32(tmp.data_ptr(), ref.data_ptr(), out.data_ptr(), n, ref.shape[-1], raw_stream())
+    if code:
+        raise RuntimeError("mono_refine_reference_f32 failed with code %d" % code)
+    return out
+
+
+def refine_reference_supported(tmp, ref):
+    return tmp.is_cuda and tmp.dtype == torch.float32 and ref.dtype == torch.float32 and tmp.shape[-1] == 6 and ref.shape[-1] in (2, 6) \
+        and tmp.shape[:-1] == ref.shape[:-1]

@@ -444,6 +444,30 @@ def test_head_tail_kernels_equal_the_pytorch_expressions():
         err = (a.grad.cpu().double() - b.grad).abs().max().item()
         assert err <= 2e-5 * b.grad.abs().max().item(), (name, err)     # (bilinear weights from an f32 pixel coordinate up to 79)
 
+    # with detached reference boxes folded in (monodetr.py:224-232) and the decoder's refinement kernel
+    from monosowa_amd.monodetr.misc import inverse_sigmoid
+    from monosowa_amd.pointwise import refine_reference
+    for rd in (2, 6):
+        refb = torch.rand(B, Q, rd, generator=gen)
+        refb[0, :3] = 0.0
+        refb[1, :3] = 1.0                                    # the clamps of inverse_sigmoid
+        inv = inverse_sigmoid(refb.double())
+        ref_in = [t.double().requires_grad_(True) for t in (tmp, size3d, dreg, wd)]
+        t_full = ref_in[0] + inv if rd == 6 else torch.cat([ref_in[0][..., :2] + inv, ref_in[0][..., 2:]], -1)
+        oc, dave = reference(t_full, *ref_in[1:])
+        ((oc * w1).sum() + (dave * w2).sum()).backward()
+        got_in = [t.cuda().requires_grad_(True) for t in (tmp, size3d, dreg, wd)]
+        oc_g, dave_g = head_tail(*got_in, fu.cuda(), img_h.cuda(), ref=refb.cuda())
+        ((oc_g * w1.float().cuda()).sum() + (dave_g * w2.float().cuda()).sum()).backward()
+        assert (oc_g.detach().cpu().double() - oc.detach()).abs().max() <= 2e-6, rd
+        assert (dave_g.detach().cpu().double() - dave.detach()).abs().max() <= 2e-6 * dave.abs().max(), rd
+        for name, a, b in zip(("d tmp", "d size3d", "d depth_reg", "d weighted_depth"), got_in, ref_in):
+            err = (a.grad.cpu().double() - b.grad).abs().max().item()
+            assert err <= 2e-5 * b.grad.abs().max().item(), (rd, name, err)
+        want = t_full.detach().sigmoid()
+        got = refine_reference(tmp.cuda(), refb.cuda())
+        assert (got.cpu().double() - want).abs().max() <= 2e-6, rd
+
 
 @pytest.mark.gpu
 def test_match_cost_kernel_reproduces_the_pytorch_floats():
