@@ -67,12 +67,25 @@ def forward(q, k, v, scale, p, seed):
     return o, lse
 
 
+def _batch_major(t):
+    """[B, H, L, 32] view whose batch stride is the outermost: a [B, L, H*32] buffer (else [L, B, H*32])"""
+    return t.stride(0) >= t.stride(2)
+
+
+def _like_heads(t):
+    """A fresh dense [B, H, L, 32] view in the memory order of ``t`` -- [L, B, H*32] or [B, L, H*32] -- so that the gradient of
+    a projection output lies like the output itself and flows back into its GEMMs without a layout copy."""
+    B, H, L, _ = t.shape
+    if _batch_major(t):
+        return torch.empty((B, L, H * 32), dtype=torch.float32, device=t.device).view(B, L, H, 32).permute(0, 2, 1, 3)
+    return torch.empty((L, B, H * 32), dtype=torch.float32, device=t.device).view(L, B, H, 32).permute(1, 2, 0, 3)
+
+
 def backward(q, k, v, o, lse, dout, scale, p, seed):
-    """dq, dk, dv as [B, H, L, 32] views of fresh [L, B, H*32] buffers (the layout of the MHA projections)."""
+    """dq, dk, dv as [B, H, L, 32] views of fresh buffers laid out like q, k, v (the layout of the MHA projections)."""
     B, H, Lq, _ = q.shape
     Lk = k.size(2)
-    mk = lambda L: torch.empty((L, B, H * 32), dtype=torch.float32, device=q.device).view(L, B, H, 32).permute(1, 2, 0, 3)
-    dq, dk, dv = mk(Lq), mk(Lk), mk(Lk)
+    dq, dk, dv = _like_heads(q), _like_heads(k), _like_heads(v)
     delta = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
     assert dout.stride() == o.stride()
     with torch.cuda.device(q.device):
@@ -91,8 +104,7 @@ class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, scale, p, seed):
         B, H, Lq, _ = q.shape
-        obuf = torch.empty((Lq, B, H * 32), dtype=torch.float32, device=q.device)
-        o = obuf.view(Lq, B, H, 32).permute(1, 2, 0, 3)
+        o = _like_heads(q)                           # [Lq, B, H*32] or, for a batch-major q, [B, Lq, H*32]
         lse = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
         with torch.cuda.device(q.device):
             code = load().mono_attn_forward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Lq,
@@ -108,8 +120,7 @@ class _Attention(torch.autograd.Function):
     def backward(ctx, dout):
         q, k, v, o, lse = ctx.saved_tensors
         if dout.stride() != o.stride():
-            buf = torch.empty((o.size(2), o.size(0), o.size(1) * 32), dtype=torch.float32, device=o.device)
-            d2 = buf.view(o.size(2), o.size(0), o.size(1), 32).permute(1, 2, 0, 3)
+            d2 = _like_heads(o)
             d2.copy_(dout)
             dout = d2
         dq, dk, dv = backward(q, k, v, o, lse, dout, ctx.scale, ctx.p, ctx.seed)
@@ -135,7 +146,12 @@ def mha_forward(mha, query, key, value):
     w, bias = mha.in_proj_weight, mha.in_proj_bias
     Lq, B, _ = query.shape
     Lk = key.size(0)
-    lin = torch.nn.functional.linear
+    def lin(x, w_, b_):
+        # the [L, B, E] view of a batch-major buffer (the decoder's queries, tokens cut out of an NHWC map): project the buffer as
+        # it lies -- a non-contiguous input costs F.linear a copy and an unfused bias add -- and hand back the same kind of view
+        if not x.is_contiguous() and x.transpose(0, 1).is_contiguous():
+            return torch.nn.functional.linear(x.transpose(0, 1), w_, b_).transpose(0, 1)
+        return torch.nn.functional.linear(x, w_, b_)
     # row blocks of the packed projection and column blocks of a merged output come from ONE split each: its backward is a
     # single concatenation, where every `w[a:b]` slice would zero-fill a full-size gradient, copy its block in and have
     # autograd add the pieces (5 launches per pair; 15 per call over weights, biases and activations)
@@ -152,6 +168,8 @@ def mha_forward(mha, query, key, value):
         q, k, v = lin(query, w_q, b_q), lin(key, w_k, b_k), lin(value, w_v, b_v)
     heads = lambda t, L: t.unflatten(-1, (H, 32)).permute(1, 2, 0, 3)           # [L,B,E] -> [B,H,L,32] view
     o = attention(heads(q, Lq), heads(k, Lk), heads(v, Lk), mha.dropout if mha.training else 0.0)
+    if _batch_major(o):                                 # o lies like q: out_proj on [B, Lq, E], returned as its [Lq, B, E] view
+        return mha.out_proj(o.permute(0, 2, 1, 3).reshape(B, Lq, E)).transpose(0, 1)
     return mha.out_proj(o.permute(2, 0, 1, 3).reshape(Lq, B, E))
 
 

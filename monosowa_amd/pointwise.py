@@ -265,9 +265,32 @@ def _next_seed():
 LN_MIN_ROWS = int(os.environ.get('MONOSOWA_LN_MIN_ROWS', '1'))
 
 
+def row_dense(t):
+    """A tensor whose elements fill its storage without gaps or overlap, with the last dimension contiguous, in SOME order of the
+    leading dimensions (e.g. the [L, B, C] view of a [B, L, C] buffer): per-row and elementwise kernels can walk it in memory
+    order, and ``torch.empty_like`` reproduces its strides."""
+    if t.is_contiguous():
+        return True
+    if t.dim() < 2 or t.stride(-1) != 1:
+        return False
+    order = sorted(range(t.dim() - 1), key=lambda d: -t.stride(d))
+    return t.permute(*order, t.dim() - 1).is_contiguous()
+
+
+def same_layout(ref, t):
+    """``t`` in the memory layout of the row-dense tensor ``ref`` (a copy only if it is not already)."""
+    if t.stride() == ref.stride():
+        return t
+    return torch.empty_like(ref).copy_(t)
+
+
 def ln_forward(x, z, weight, bias, p, eps):
     """y = LayerNorm_256(x + dropout_p(z)); returns (y, s, mean, rstd, seed) -- the last four feed ``ln_backward``."""
-    x, z = x.contiguous(), z.contiguous()
+    # rows are independent: any row-dense layout is walked in memory order (the result keeps it), e.g. the [L, B, C] view of a
+    # batch-major buffer -- no copy into [L, B, C] order and back
+    if not row_dense(x):
+        x = x.contiguous()
+    z = same_layout(x, z)
     rows = x.numel() // 256
     y, s = torch.empty_like(x), torch.empty_like(x)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
@@ -284,7 +307,7 @@ def ln_forward(x, z, weight, bias, p, eps):
 
 def ln_backward(gy, s, mean, rstd, weight, p, seed):
     """-> (gx, gz, gweight, gbias) of ``ln_forward``."""
-    gy = gy.contiguous()
+    gy = same_layout(s, gy)
     gx, gz = torch.empty_like(s), torch.empty_like(s)
     rows = s.numel() // 256
     gw = torch.empty(2, 256, dtype=torch.float32, device=s.device)
@@ -484,8 +507,9 @@ class FusedAdamWPlan:
 
 # ---------------------------------------------------------------------------------------------------------
 def relu_dropout_forward(h, p):
-    h = h.contiguous()
-    y = torch.empty_like(h)
+    if not row_dense(h):
+        h = h.contiguous()
+    y = torch.empty_like(h)                      # elementwise: memory order, strides kept
     with torch.cuda.device(h.device):
         code = load().mono_relu_dropout_fwd_f32(h.data_ptr(), y.data_ptr(), h.numel(), float(p), _next_seed(), raw_stream())
     if code:
@@ -494,7 +518,7 @@ def relu_dropout_forward(h, p):
 
 
 def relu_dropout_backward(gy, y, p):
-    gy = gy.contiguous()
+    gy = same_layout(y, gy)
     gh = torch.empty_like(y)
     with torch.cuda.device(y.device):
         code = load().mono_relu_dropout_bwd_f32(gy.data_ptr(), y.data_ptr(), gh.data_ptr(), y.numel(), float(p), raw_stream())

@@ -55,6 +55,10 @@ class _TokenLinear(torch.autograd.Function):
 def token_linear(x, linear):
     """``linear(x)`` for an ``nn.Linear``.  On the GPU under autograd the backward is ours: split-K weight gradient
     when there are enough tokens, bias gradient through the column-sum kernel."""
+    if x.dim() == 3 and not x.is_contiguous() and x.transpose(0, 1).is_contiguous():
+        # the [L, B, C] view of a batch-major buffer: the GEMM runs on the buffer as it lies (a non-contiguous input costs
+        # F.linear a copy and an unfused bias add), the result is handed back as the same kind of view
+        return token_linear(x.transpose(0, 1), linear).transpose(0, 1)
     if x.is_cuda and torch.is_grad_enabled() and linear.weight.requires_grad and x.numel() // x.shape[-1] >= MIN_ROWS:
         return _TokenLinear.apply(x, linear.weight, linear.bias)
     return linear(x)
