@@ -297,7 +297,7 @@ class DepthAwareDecoderLayer(nn.Module):
                                level_start_index, src_padding_mask, value=value)
         tgt = dropout_add_layernorm(tgt, tgt2, self.norm1, self.dropout1)
         # ffn
-        ff = token_linear(self.dropout3(F.relu(token_linear(tgt, self.linear1))), self.linear2)
+        ff = token_linear(relu_dropout(token_linear(tgt, self.linear1), self.dropout3), self.linear2)
         return dropout_add_layernorm(tgt, ff, self.norm3, self.dropout4)
 
 
@@ -457,9 +457,12 @@ class DepthAwareTransformer(nn.Module):
 
         bs, _, c = memory.shape
         query_pos, tgt = torch.split(query_embed, c, dim=1)
+        # the learned queries are the same for every image: the reference-point head runs on the [Q, C] embedding once (the
+        # reference evaluates it on the expanded [B, Q, C] tensor: same values), and the decoder's first residual stream is a real
+        # [B, Q, C] tensor (an expanded view costs every consumer its own copy)
+        reference_points = self.reference_points(query_pos).sigmoid().unsqueeze(0).expand(bs, -1, -1)
         query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
-        tgt = tgt.unsqueeze(0).expand(bs, -1, -1)
-        reference_points = self.reference_points(query_pos).sigmoid()
+        tgt = tgt.unsqueeze(0).expand(bs, -1, -1).contiguous()
         init_reference_out = reference_points
 
         depth_tokens = depth_pos_embed.flatten(2).permute(2, 0, 1)
