@@ -321,11 +321,13 @@ class DepthAwareDecoder(nn.Module):
         self.bbox_raw = []          # bbox_embed[lid](output) of every layer: MonoDETR.forward needs exactly these again
         # every layer's cross-attention projects the SAME memory with its own value_proj (ms_deform_attn.py:138): one GEMM for
         # all layers, each layer's operator reads its column block in place (value token stride, ABI v7)
-        # -- for the layers whose reference points carry no gradient (the fused operator's condition): with iterative refinement
-        # every layer after the first sees detached points (:602-613); the first one's come from the learned query embedding
+        # -- for the layers the fused operator takes: detached reference points (with iterative refinement every layer after the
+        # first, :602-613) or 2-d points with a gradient (the first layer's, from the learned query embedding: the operator's
+        # autograd node derives d ref from d offsets)
         values = [None] * len(self.layers)
         if MERGE_VALUE_PROJ:
-            first = 0 if not reference_points.requires_grad else (1 if self.bbox_embed is not None else len(self.layers))
+            first = 0 if (not reference_points.requires_grad or reference_points.shape[-1] == 2) \
+                else (1 if self.bbox_embed is not None else len(self.layers))
             merged = merged_value_proj(src, [layer.cross_attn for layer in self.layers[first:]])
             if merged is not None:
                 values[first:] = merged

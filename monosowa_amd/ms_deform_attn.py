@@ -85,7 +85,8 @@ class MSDeformAttn(nn.Module):
             value = token_linear(input_flatten, self.value_proj)
         H = self.n_heads
         if self.fuse_prologue and MERGED_PROJ and self.n_levels == 4 and self.n_points == 4 and self.d_model == 32 * self.n_heads \
-                and query.is_cuda and query.dtype == torch.float32 and not reference_points.requires_grad \
+                and query.is_cuda and query.dtype == torch.float32 \
+                and (not reference_points.requires_grad or reference_points.shape[-1] == 2) \
                 and reference_points.shape[-1] in (2, 6) and geom is not None \
                 and _func.MSDeformAttnFunction.__module__ == _func.__name__:
             # sampling_offsets and attention_weights as ONE GEMM; the operator reads (offsets | logits) in place.  The padding

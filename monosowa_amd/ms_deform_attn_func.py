@@ -5,6 +5,7 @@ tensors, returns ``(grad_value, None, None, grad_sampling_loc, grad_attn_weight,
 There is deliberately no pure-PyTorch twin here: the reference's ``ms_deform_attn_core_pytorch``
 ("for debug and test only", :41-61) lives in ``oracle/`` as the checker.
 """
+import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
@@ -72,7 +73,7 @@ class MSDeformAttnFusedMergedFunction(Function):
     def forward(ctx, value, spatial_shapes, level_start_index, proj, reference_points, value_mask=None):
         ctx.host_geom = MSDA.host_geometry(spatial_shapes, level_start_index)
         needs_grad = value.requires_grad or proj.requires_grad
-        ctx.saved_prologue = SAVE_PROLOGUE and needs_grad and MSDA.fused_save_supported(
+        ctx.saved_prologue = SAVE_PROLOGUE and needs_grad and not reference_points.requires_grad and MSDA.fused_save_supported(
             value, spatial_shapes, level_start_index, proj.shape[1], reference_points.shape[-1])
         ctx.value_mask = value_mask
         if ctx.saved_prologue:
@@ -99,7 +100,17 @@ class MSDeformAttnFusedMergedFunction(Function):
         value, shapes, lsi, proj, ref = ctx.saved_tensors
         MSDA.attach_host_geometry(shapes, lsi, *_unpack_geom(ctx.host_geom))
         gv, gproj = MSDA.ms_deform_attn_fused_backward_merged(value, shapes, lsi, proj, ref, grad_output.contiguous(), ctx.value_mask)
-        return gv, None, None, gproj, None, None
+        g_ref = None
+        if ctx.needs_input_grad[4]:
+            # 2-d reference points with a gradient (the decoder's first layer: points from the learned query embedding):
+            # location = ref + offset / (W_l, H_l), so d ref[b, q, l] = sum over heads and points of d location
+            #          = sum of d offset * (W_l, H_l)     (ms_deform_attn.py:149-152)
+            assert ref.shape[-1] == 2
+            B, Lq, M = gproj.shape[0], gproj.shape[1], value.shape[2]
+            g_off = gproj[..., :M * 32].reshape(B, Lq, M, 4, 4, 2)
+            normalizer = torch.stack([shapes[:, 1], shapes[:, 0]], -1).to(g_off.dtype)
+            g_ref = g_off.sum((2, 4)) * normalizer
+        return gv, None, None, gproj, g_ref, None
 
 
 def _unpack_geom(geom):

@@ -630,6 +630,41 @@ def test_fused_operator_on_a_value_view_equals_masked_fill_plus_the_unfused_oper
         assert got[1][mask].abs().max() == 0                  # padded tokens: exactly zero gradient rows
 
 
+def test_fused_operator_hands_a_gradient_to_2d_reference_points():
+    """The decoder's first layer: 2-d reference points derived from the learned query embedding carry a gradient
+    (ms_deform_attn.py:149-152: location = ref + offset / (W, H)).  The fused merged operator derives it from d offsets;
+    against autograd through the PyTorch prologue + the unfused operator."""
+    from monosowa_amd.ms_deform_attn_func import MSDeformAttnFunction, MSDeformAttnFusedMergedFunction
+    MSDA = _msda()
+    torch.manual_seed(41)
+    levels = [(24, 40), (12, 20), (6, 10), (3, 5)]
+    B, M, D, L, P, Lq = 2, 8, 32, 4, 4, 275
+    shapes = torch.tensor(levels, dtype=torch.long, device="cuda")
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    MSDA.attach_host_geometry(shapes, lsi, levels, lsi.tolist())
+    S = int(shapes.prod(1).sum())
+    value = torch.randn(B, S, M, D, device="cuda", requires_grad=True)
+    pts = torch.rand(B, Lq, 2, device="cuda", requires_grad=True)
+    ratios = torch.rand(B, L, 2, device="cuda") * 0.2 + 0.8
+    proj = torch.cat([torch.randn(B, Lq, M * 32, device="cuda") * 2, torch.randn(B, Lq, M * 16, device="cuda")], -1).requires_grad_(True)
+    go = torch.randn(B, Lq, M * D, device="cuda")
+    ref = pts[:, :, None] * ratios[:, None]                               # depthaware_transformer.py:590-596
+    out = MSDeformAttnFusedMergedFunction.apply(value, shapes, lsi, proj, ref.contiguous())
+    out.backward(go)
+    got = [out.detach().clone(), value.grad.clone(), proj.grad.clone(), pts.grad.clone()]
+    value.grad = proj.grad = pts.grad = None
+    ref = pts[:, :, None] * ratios[:, None]
+    offsets, logits = proj[:, :, :M * 32].view(B, Lq, M, L, P, 2), proj[:, :, M * 32:].reshape(B, Lq, M, L * P)
+    aw = torch.softmax(logits, -1).view(B, Lq, M, L, P)
+    norm = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+    loc = ref[:, :, None, :, None, :] + offsets / norm[None, None, None, :, None, :]
+    out_u = MSDeformAttnFunction.apply(value, shapes, lsi, loc.contiguous(), aw.contiguous(), 64)
+    out_u.backward(go)
+    want = [out_u.detach(), value.grad, proj.grad, pts.grad]
+    for name, a, b in zip(("out", "grad_value", "grad_proj", "grad_reference_points"), got, want):
+        assert (a - b).abs().max() <= 2e-5 * b.abs().max(), (name, ((a - b).abs().max() / b.abs().max()).item())
+
+
 def test_train_val_cli_runs_an_epoch_and_writes_kitti_results(tmp_path):
     """tools/train_val.py (the reference's CLI): one tiny epoch on synthetic data through Trainer -> checkpoint ->
     Tester.inference -> KITTI result files, then `-e` evaluation-only from the saved checkpoint."""
