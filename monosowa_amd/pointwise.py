@@ -388,8 +388,8 @@ class _GroupNormNHWC(torch.autograd.Function):
                                                    raw_stream())
         if code:
             raise RuntimeError("mono_groupnorm_nhwc_bwd_f32 failed with code %d" % code)
-        gwb = part.sum(0).float()
-        return gx, gbias, gwb[:, 0].contiguous(), gwb[:, 1].contiguous(), None, None
+        gw, gb = part.sum(0, dtype=torch.float32).t().contiguous().unbind(0)      # [2, C]: two contiguous rows (2 launches, not 4)
+        return gx, gbias, gw, gb, None, None
 
 
 def group_norm(x, gn, relu=False, pre_bias=None):
