@@ -64,7 +64,9 @@ def deviation(ga, gb):
 
 for it in range(2):                            # second iteration: bucket views are live, AdamW state exists
     la, lc, lb = step(plain, crit_a, opt_a), step(twin, crit_c, opt_c), step(ddp, crit_b, opt_b)
-    assert torch.isfinite(la) and abs(la - lb) <= 1e-5 * abs(la), (la, lb)
+    # (second iteration: the three instances' weights already differ by Adam's sign flips of noise-level gradients -- the
+    # unwrapped twin measures what that does to the loss)
+    assert torch.isfinite(la) and abs(la - lb) <= (1e-5 if it == 0 else 1e-4) * abs(la) + 3 * abs(la - lc), (la, lb, lc)
     ga = {n: p.grad for n, p in plain.named_parameters() if p.grad is not None and n not in frozen}
     gc = {n: p.grad for n, p in twin.named_parameters() if p.grad is not None and n not in frozen}
     gb = {n: p.grad for n, p in wrapped_core.named_parameters() if p.grad is not None}
