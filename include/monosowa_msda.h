@@ -39,10 +39,14 @@
  * Errors: 0 on success; a positive value is a hipError_t from the launch (the reference only
  * printf's launch errors, cuh:948-952 -- this library returns them); negative values are
  * MSDA_E_* argument errors.  msda_strerror() names either kind.  The compute entry points hold no
- * per-call state and may be called from several threads (the autograd engine does); the one piece of
- * process-wide state is the kernel-generation option table (msda_set_option / MSDA_* environment
- * variables, read once at first use): every setting computes the same function, and changing it while
- * other threads launch is a benign race on plain ints, not a correctness hazard.
+ * per-call state and may be called from several threads (the autograd engine does).  Process-wide
+ * state, all of it behind mutexes or benign: (1) the kernel-generation option table (msda_set_option /
+ * MSDA_* environment variables, read once at first use): every setting computes the same function, and
+ * changing it while other threads launch is a race on plain ints, not a correctness hazard; (2) caches
+ * keyed by the pyramid: the window tiling (host) and, per device, the tile-window kernels' query table
+ * (0.3 MB of device memory, allocated and filled with a blocking copy on the first call for a geometry,
+ * kept for the life of the process) -- so the first call for a geometry must not happen inside a stream
+ * capture.
  */
 #ifndef MONOSOWA_MSDA_H_
 #define MONOSOWA_MSDA_H_
