@@ -47,6 +47,10 @@ int mono_dropout_add_layernorm_fwd_f32(const float *x, const float *z, const flo
 int mono_relu_dropout_fwd_f32(const float *h, float *y, long long n, float p, unsigned long long seed, void *stream);
 /* grad_h = grad_y / (1 - p) where y > 0 (kept and h > 0), else 0. */
 int mono_relu_dropout_bwd_f32(const float *grad_y, const float *y, float *grad_h, long long n, float p, void *stream);
+/* The same over a [rows, 256] matrix, plus colsum[256] = column sums of grad_h (the bias gradient of the linear in front);
+ * partials: mono_reduce_blocks(rows) * 256 floats of scratch. */
+int mono_relu_dropout_bwd_colsum_f32(const float *grad_y, const float *y, float *grad_h, float *colsum, float *partials, long long rows,
+                                     float p, void *stream);
 
 /* The matched-pair losses of SetCriterion (monodetr.py:1010-1103: 3D-centre and l/r/t/b L1, GIoU, Laplacian depth,
  * dimension-aware size L1, 12-bin heading cross entropy + residual L1) for all decoder layers in one launch.
@@ -73,8 +77,9 @@ int mono_adamw_step_f32(const void *table, int n_chunks, double beta1, double be
 /* Number of workgroups, = rows of scratch the two row reductions below need, for `rows` input rows. */
 int mono_reduce_blocks(long long rows);
 
-/* gx, gz [rows, 256]; ggamma_gbeta [2, 256] (ggamma then gbeta), overwritten.
- * partials: scratch of mono_reduce_blocks(rows) * 512 floats (per-workgroup partial sums; no atomics: deterministic). */
+/* gx, gz [rows, 256]; ggamma_gbeta [3, 256] (ggamma, gbeta, then the column sums of gz = the bias gradient of the linear whose
+ * output z is), overwritten.
+ * partials: scratch of mono_reduce_blocks(rows) * 768 floats (per-workgroup partial sums; no atomics: deterministic). */
 int mono_dropout_add_layernorm_bwd_f32(const float *gy, const float *s, const float *mean, const float *rstd,
                                        const float *gamma, float *gx, float *gz, float *ggamma_gbeta, float *partials,
                                        long long rows, int C, float p, unsigned long long seed, void *stream);

@@ -164,16 +164,16 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
 }
 
 // gs = rstd * (gy*gamma - mean(gy*gamma) - xhat * mean(gy*gamma*xhat));  gx = gs;  gz = gs * keep_scale;
-// ggamma = sum_rows gy * xhat, gbeta = sum_rows gy: per-workgroup partial rows [gridDim.x][512], added up by
+// ggamma = sum_rows gy * xhat, gbeta = sum_rows gy, gzsum = sum_rows gz: per-workgroup partial rows [gridDim.x][768], added up by
 // partial_sum_kernel (no same-address atomics)
 __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
     const float *__restrict__ gy, const float *__restrict__ s, const float *__restrict__ mean_in,
     const float *__restrict__ rstd_in, const float *__restrict__ gamma, float *__restrict__ gx, float *__restrict__ gz,
     float *__restrict__ partials, long long rows, unsigned threshold, float scale, unsigned long long seed) {
-  __shared__ float4 part[2][4][64];
+  __shared__ float4 part[3][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float4 g = reinterpret_cast<const float4 *>(gamma)[lane];
-  float4 acc_g = make_float4(0.f, 0.f, 0.f, 0.f), acc_b = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc_g = make_float4(0.f, 0.f, 0.f, 0.f), acc_b = make_float4(0.f, 0.f, 0.f, 0.f), acc_z = make_float4(0.f, 0.f, 0.f, 0.f);
   const long long wave_stride = (long long)gridDim.x * 4;
   for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += wave_stride) {
     const long long e = r * 256 + lane * 4;
@@ -193,23 +193,19 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
       gzv.z *= keep_scale(seed, e + 2, threshold, scale); gzv.w *= keep_scale(seed, e + 3, threshold, scale);
     }
     *reinterpret_cast<float4 *>(gz + e) = gzv;
+    acc_z.x += gzv.x; acc_z.y += gzv.y; acc_z.z += gzv.z; acc_z.w += gzv.w;       // sum_rows gz: the bias gradient of the linear behind z
     acc_g.x += gv.x * xh.x; acc_g.y += gv.y * xh.y; acc_g.z += gv.z * xh.z; acc_g.w += gv.w * xh.w;
     acc_b.x += gv.x; acc_b.y += gv.y; acc_b.z += gv.z; acc_b.w += gv.w;
   }
   part[0][wave][lane] = acc_g;
   part[1][wave][lane] = acc_b;
+  part[2][wave][lane] = acc_z;
   __syncthreads();
-  if (wave == 0) {
-    float4 a = part[0][0][lane], b = part[1][0][lane];
+  if (wave < 3) {                                                   // wave k adds up quantity k
+    float4 a = part[wave][0][lane];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      const float4 pa = part[0][w][lane], pb = part[1][w][lane];
-      a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w;
-      b.x += pb.x; b.y += pb.y; b.z += pb.z; b.w += pb.w;
-    }
-    float *dst = partials + (long long)blockIdx.x * 512 + lane * 4;
-    *reinterpret_cast<float4 *>(dst) = a;
-    *reinterpret_cast<float4 *>(dst + 256) = b;
+    for (int w = 1; w < 4; ++w) { const float4 pa = part[wave][w][lane]; a.x += pa.x; a.y += pa.y; a.z += pa.z; a.w += pa.w; }
+    *reinterpret_cast<float4 *>(partials + (long long)blockIdx.x * 768 + wave * 256 + lane * 4) = a;
   }
 }
 
@@ -235,6 +231,32 @@ __global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float *__re
     const float4 g = reinterpret_cast<const float4 *>(gy)[i], v = reinterpret_cast<const float4 *>(y)[i];
     reinterpret_cast<float4 *>(gh)[i] = make_float4(v.x > 0.f ? g.x * scale : 0.f, v.y > 0.f ? g.y * scale : 0.f,
                                                     v.z > 0.f ? g.z * scale : 0.f, v.w > 0.f ? g.w * scale : 0.f);
+  }
+}
+
+// the same over a [rows, 256] matrix, also leaving the column sums of grad_h (the bias gradient of the linear in front) as
+// per-workgroup partial rows [gridDim.x][256] for partial_sum_kernel
+__global__ __launch_bounds__(256) void relu_dropout_bwd_colsum_kernel(const float *__restrict__ gy, const float *__restrict__ y,
+                                                                      float *__restrict__ gh, float *__restrict__ partials,
+                                                                      long long rows, float scale) {
+  __shared__ float4 part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long wave_stride = (long long)gridDim.x * 4;
+  for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += wave_stride) {
+    const long long e = r * 256 + lane * 4;
+    const float4 g = *reinterpret_cast<const float4 *>(gy + e), v = *reinterpret_cast<const float4 *>(y + e);
+    const float4 o = make_float4(v.x > 0.f ? g.x * scale : 0.f, v.y > 0.f ? g.y * scale : 0.f, v.z > 0.f ? g.z * scale : 0.f,
+                                 v.w > 0.f ? g.w * scale : 0.f);
+    *reinterpret_cast<float4 *>(gh + e) = o;
+    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) { const float4 pa = part[w][lane]; acc.x += pa.x; acc.y += pa.y; acc.z += pa.z; acc.w += pa.w; }
+    *reinterpret_cast<float4 *>(partials + (long long)blockIdx.x * 256 + lane * 4) = acc;
   }
 }
 
@@ -445,8 +467,8 @@ int mono_dropout_add_layernorm_fwd_f32(const float *x, const float *z, const flo
   return (int)hipGetLastError();
 }
 
-// ggamma_gbeta: [2, 256] contiguous (ggamma then gbeta), overwritten.  partials: scratch of
-// mono_reduce_blocks(rows) * 512 floats.
+// ggamma_gbeta: [3, 256] contiguous (ggamma, gbeta, column sums of gz), overwritten.  partials: scratch of
+// mono_reduce_blocks(rows) * 768 floats.
 int mono_dropout_add_layernorm_bwd_f32(const float *gy, const float *s, const float *mean, const float *rstd,
                                        const float *gamma, float *gx, float *gz, float *ggamma_gbeta, float *partials,
                                        long long rows, int C, float p, unsigned long long seed, void *stream_) {
@@ -457,7 +479,7 @@ int mono_dropout_add_layernorm_bwd_f32(const float *gy, const float *s, const fl
   const int g = mono_reduce_blocks(rows);
   hipStream_t st = (hipStream_t)stream_;
   mono::dropout_add_ln_bwd_kernel<<<g, 256, 0, st>>>(gy, s, mean, rstd, gamma, gx, gz, partials, rows, threshold, scale, seed);
-  mono::partial_sum_kernel<<<2, 1024, 0, st>>>(partials, ggamma_gbeta, g, 512);
+  mono::partial_sum_kernel<<<3, 1024, 0, st>>>(partials, ggamma_gbeta, g, 768);
   return (int)hipGetLastError();
 }
 
@@ -475,6 +497,18 @@ int mono_relu_dropout_bwd_f32(const float *grad_y, const float *y, float *grad_h
   if (!grad_y || !y || !grad_h) return -1;
   if (n <= 0 || (n & 3) || !(p >= 0.f && p < 1.f) || ((uintptr_t)grad_y & 15) || ((uintptr_t)y & 15) || ((uintptr_t)grad_h & 15)) return -2;
   mono::relu_dropout_bwd_kernel<<<mono::grid_for_vec(n / 4), 256, 0, (hipStream_t)stream_>>>(grad_y, y, grad_h, n / 4, 1.f / (1.f - p));
+  return (int)hipGetLastError();
+}
+
+// grad_h [rows, 256] as above plus colsum[256] = its column sums; partials: mono_reduce_blocks(rows) * 256 floats of scratch.
+int mono_relu_dropout_bwd_colsum_f32(const float *grad_y, const float *y, float *grad_h, float *colsum, float *partials, long long rows,
+                                     float p, void *stream_) {
+  if (!grad_y || !y || !grad_h || !colsum || !partials) return -1;
+  if (rows <= 0 || !(p >= 0.f && p < 1.f) || ((uintptr_t)grad_y & 15) || ((uintptr_t)y & 15) || ((uintptr_t)grad_h & 15)) return -2;
+  const int g = mono_reduce_blocks(rows);
+  hipStream_t st = (hipStream_t)stream_;
+  mono::relu_dropout_bwd_colsum_kernel<<<g, 256, 0, st>>>(grad_y, y, grad_h, partials, rows, 1.f / (1.f - p));
+  mono::partial_sum_kernel<<<1, 1024, 0, st>>>(partials, colsum, g, 256);
   return (int)hipGetLastError();
 }
 

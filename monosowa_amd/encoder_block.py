@@ -12,12 +12,14 @@ import torch
 import torch.nn.functional as F
 
 from . import MultiScaleDeformableAttention as MSDA
-from .pointwise import colsum, colsum_levels, ln_backward, ln_forward, relu_dropout_backward, relu_dropout_forward
+from .pointwise import colsum, colsum_levels, ln_backward, ln_forward, relu_dropout_backward, relu_dropout_backward_colsum, relu_dropout_forward
 from .token_linear import weight_grad
 
 
 MERGED_PROJ = True      # sampling_offsets and attention_weights as one 384-wide GEMM read in place by the strided operator
 
+
+FUSED_BIAS_SUMS = True     # bias gradients of output_proj / linear2 / linear1 from the LayerNorm and ReLU backward passes themselves
 
 class _AttnBlock(torch.autograd.Function):
     """LayerNorm(src + dropout(output_proj(MSDA(value_proj(src), offsets(q), logits(q), ref))))"""
@@ -69,10 +71,12 @@ class _AttnBlock(torch.autograd.Function):
         C = src.shape[-1]
         sh, ls = ctx.host_geom                                 # the saved pyramid tensors may come back as new objects
         MSDA.attach_host_geometry(shapes, lsi, [(int(sh[2 * i]), int(sh[2 * i + 1])) for i in range(len(ls))], [int(x) for x in ls])
-        gx, gz, ggamma, gbeta = ln_backward(gy, s, mean, rstd, gamma, ctx.p, ctx.seed)
+        gx, gz, ggamma, gbeta, gbp = ln_backward(gy, s, mean, rstd, gamma, ctx.p, ctx.seed, with_gz_sum=True)   # gbp: d output_proj.bias
+        if not FUSED_BIAS_SUMS:
+            gbp = colsum(gz.view(-1, C))
         gz2 = gz.view(-1, C)
         ga = (gz2 @ wp).view_as(a)
-        gwp, gbp = weight_grad(gz2, a.view(-1, C)), colsum(gz2)
+        gwp = weight_grad(gz2, a.view(-1, C))
         src2, q2 = src.reshape(-1, C), q.reshape(-1, C)
         n_off = wo.shape[0]
         if ctx.merged:
@@ -133,14 +137,20 @@ class _FFNBlock(torch.autograd.Function):
     def backward(ctx, gy):
         x, hd, s, mean, rstd, w1, w2, gamma = ctx.saved_tensors
         C, Hd = x.shape[-1], hd.shape[-1]
-        gx, gf, ggamma, gbeta = ln_backward(gy, s, mean, rstd, gamma, ctx.p_res, ctx.seed)
+        gx, gf, ggamma, gbeta, gb2 = ln_backward(gy, s, mean, rstd, gamma, ctx.p_res, ctx.seed, with_gz_sum=True)    # gb2: d linear2.bias
+        if not FUSED_BIAS_SUMS:
+            gb2 = colsum(gf.view(-1, C))
         gf2 = gf.view(-1, C)
         ghd = (gf2 @ w2).view_as(hd)
-        gw2, gb2 = weight_grad(gf2, hd.view(-1, Hd)), colsum(gf2)
-        gh = relu_dropout_backward(ghd, hd, ctx.p_hidden) if ctx.p_hidden > 0 else ghd * (hd > 0)
+        gw2 = weight_grad(gf2, hd.view(-1, Hd))
+        if ctx.p_hidden > 0 and Hd == 256 and FUSED_BIAS_SUMS:
+            gh, gb1 = relu_dropout_backward_colsum(ghd, hd, ctx.p_hidden)        # d linear1.bias from the same pass
+        else:
+            gh = relu_dropout_backward(ghd, hd, ctx.p_hidden) if ctx.p_hidden > 0 else ghd * (hd > 0)
+            gb1 = colsum(gh.view(-1, Hd))
         gh2 = gh.view(-1, Hd)
         gx.view(-1, C).addmm_(gh2, w1)                       # d x: residual + FFN path
-        return gx, weight_grad(gh2, x.reshape(-1, C)), colsum(gh2), gw2, gb2, ggamma, gbeta, None, None, None
+        return gx, weight_grad(gh2, x.reshape(-1, C)), gb1, gw2, gb2, ggamma, gbeta, None, None, None
 
 
 def supported(layer, src, pos, reference_points, spatial_shapes, padding_mask):

@@ -11,7 +11,7 @@ _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmono
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
-           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32")
+           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32", "mono_relu_dropout_bwd_colsum_f32")
 _lib = None
 
 
@@ -51,6 +51,8 @@ def load():
         lib.mono_groupnorm_blocks.argtypes = [I, I]
         lib.mono_relu_dropout_fwd_f32.restype = I
         lib.mono_relu_dropout_fwd_f32.argtypes = [P, P, LL, F, U, P]
+        lib.mono_relu_dropout_bwd_colsum_f32.restype = I
+        lib.mono_relu_dropout_bwd_colsum_f32.argtypes = [P, P, P, P, P, LL, F, P]
         lib.mono_relu_dropout_bwd_f32.restype = I
         lib.mono_relu_dropout_bwd_f32.argtypes = [P, P, P, LL, F, P]
         lib.mono_matched_losses_fwd_f32.restype = I
@@ -305,19 +307,22 @@ def ln_forward(x, z, weight, bias, p, eps):
     return y, s, mean, rstd, seed
 
 
-def ln_backward(gy, s, mean, rstd, weight, p, seed):
-    """-> (gx, gz, gweight, gbias) of ``ln_forward``."""
+def ln_backward(gy, s, mean, rstd, weight, p, seed, with_gz_sum=False):
+    """-> (gx, gz, gweight, gbias) of ``ln_forward``; with_gz_sum: also gz summed over the rows (the kernel accumulates it
+    anyway: it is the bias gradient of the linear layer whose output z is -- a 167 MB pass saved per encoder norm)."""
     gy = same_layout(s, gy)
     gx, gz = torch.empty_like(s), torch.empty_like(s)
     rows = s.numel() // 256
-    gw = torch.empty(2, 256, dtype=torch.float32, device=s.device)
-    partials = torch.empty(load().mono_reduce_blocks(rows) * 512, dtype=torch.float32, device=s.device)
+    gw = torch.empty(3, 256, dtype=torch.float32, device=s.device)
+    partials = torch.empty(load().mono_reduce_blocks(rows) * 768, dtype=torch.float32, device=s.device)
     with torch.cuda.device(s.device):
         code = load().mono_dropout_add_layernorm_bwd_f32(
             gy.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), weight.data_ptr(), gx.data_ptr(), gz.data_ptr(),
             gw.data_ptr(), partials.data_ptr(), rows, 256, float(p), seed, raw_stream())
     if code:
         raise RuntimeError("mono_dropout_add_layernorm_bwd_f32 failed with code %d" % code)
+    if with_gz_sum:
+        return gx, gz, gw[0], gw[1], gw[2]
     return gx, gz, gw[0], gw[1]
 
 
@@ -515,6 +520,24 @@ def relu_dropout_forward(h, p):
     if code:
         raise RuntimeError("mono_relu_dropout_fwd_f32 failed with code %d" % code)
     return y
+
+
+def relu_dropout_backward_colsum(gy, y, p):
+    """-> (grad_h, grad_h summed over the rows) for a [..., 256] activation: one pass for both (the sum is the bias gradient
+    of the linear in front)."""
+    assert y.shape[-1] == 256
+    gy = same_layout(y, gy)
+    gh = torch.empty_like(y)
+    rows = y.numel() // 256
+    lib = load()
+    out = torch.empty(256, dtype=torch.float32, device=y.device)
+    partials = torch.empty(lib.mono_reduce_blocks(rows) * 256, dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        code = lib.mono_relu_dropout_bwd_colsum_f32(gy.data_ptr(), y.data_ptr(), gh.data_ptr(), out.data_ptr(), partials.data_ptr(), rows,
+                                                    float(p), raw_stream())
+    if code:
+        raise RuntimeError("mono_relu_dropout_bwd_colsum_f32 failed with code %d" % code)
+    return gh, out
 
 
 def relu_dropout_backward(gy, y, p):
