@@ -579,6 +579,15 @@ int mono_colsum_f32(const float *g, float *out, float *partials, long long rows,
   return (int)hipGetLastError();
 }
 
+// out[c] = sum_k x[k][c] for a contiguous [n, C] stack of n slices (split-K partial products: n = 16..64, C = out * in of a weight
+// matrix): the generic PyTorch reduction over dim 0 runs this shape at 0.24 TB/s (70 us for 64 x 256 x 256).  C % 4 == 0.
+int mono_sum_slices_f32(const float *x, float *out, int n, long long C, void *stream_) {
+  if (!x || !out) return -1;
+  if (n <= 0 || C <= 0 || (C & 3) || C > (1ll << 30) || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return -2;
+  mono::partial_sum_kernel<<<(unsigned)((C / 4 + 63) / 64), 1024, 0, (hipStream_t)stream_>>>(x, out, n, (int)C);
+  return (int)hipGetLastError();
+}
+
 // Column sums of a [batch, rows, C] view whose batches are batch_stride floats apart (rows of a batch contiguous):
 // out[c] = sum_{b, r} g[b * batch_stride + r * C + c].  partials: mono_reduce_blocks(batch * rows) * C floats.
 int mono_colsum_strided_f32(const float *g, float *out, float *partials, int batch, long long rows, long long batch_stride,

@@ -11,7 +11,7 @@ _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmono
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
-           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32", "mono_relu_dropout_bwd_colsum_f32")
+           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32", "mono_relu_dropout_bwd_colsum_f32", "mono_sum_slices_f32")
 _lib = None
 
 
@@ -51,6 +51,8 @@ def load():
         lib.mono_groupnorm_blocks.argtypes = [I, I]
         lib.mono_relu_dropout_fwd_f32.restype = I
         lib.mono_relu_dropout_fwd_f32.argtypes = [P, P, LL, F, U, P]
+        lib.mono_sum_slices_f32.restype = I
+        lib.mono_sum_slices_f32.argtypes = [P, P, I, LL, P]
         lib.mono_relu_dropout_bwd_colsum_f32.restype = I
         lib.mono_relu_dropout_bwd_colsum_f32.argtypes = [P, P, P, P, P, LL, F, P]
         lib.mono_relu_dropout_bwd_f32.restype = I
@@ -435,6 +437,20 @@ def colsum_levels(g3, bounds):
             if code:
                 raise RuntimeError("mono_colsum_strided_f32 failed with code %d" % code)
     return out
+
+
+def sum_slices(t):
+    """``t.sum(0)`` of a contiguous float32 GPU stack [n, ...] (the slices of a split-K weight gradient): one coalesced pass; the
+    generic reduction over dim 0 reaches 0.24 TB/s on [64, 256, 256]."""
+    inner = t[0].numel() if t.dim() > 1 and t.size(0) > 0 else 0
+    if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and inner and inner % 4 == 0 and t.data_ptr() % 16 == 0:
+        out = torch.empty(t.shape[1:], dtype=torch.float32, device=t.device)
+        with torch.cuda.device(t.device):
+            code = load().mono_sum_slices_f32(t.data_ptr(), out.data_ptr(), t.size(0), inner, raw_stream())
+        if code:
+            raise RuntimeError("mono_sum_slices_f32 failed with code %d" % code)
+        return out
+    return t.sum(0)
 
 
 COLSUM_MAX_C = 512     # wider matrices: the PyTorch reduction is as fast

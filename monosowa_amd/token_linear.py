@@ -10,8 +10,9 @@ Same math as ``F.linear`` (fp32 summation order differs in the weight gradient: 
 import torch
 import torch.nn.functional as F
 
-from .pointwise import colsum
+from .pointwise import colsum, sum_slices
 
+USE_SUM_SLICES = True     # the slices of a split-K weight gradient added by one coalesced pass (pointwise.sum_slices)
 MIN_TOKENS = 32768      # split-K weight gradient from here on
 MIN_ROWS = int(__import__('os').environ.get('MONOSOWA_TL_MIN_ROWS', '32768'))   # our backward from here on
 
@@ -27,7 +28,8 @@ def weight_grad(g2, x2):
     """g2^T @ x2 for [tokens, out] / [tokens, in] matrices: split-K batched GEMM when there are many tokens."""
     s = _slices(x2.shape[0]) if x2.shape[0] >= MIN_TOKENS else 0
     if s:
-        return torch.bmm(g2.view(s, -1, g2.shape[1]).transpose(1, 2), x2.view(s, -1, x2.shape[1])).sum(0)
+        parts = torch.bmm(g2.view(s, -1, g2.shape[1]).transpose(1, 2), x2.view(s, -1, x2.shape[1]))
+        return sum_slices(parts) if USE_SUM_SLICES else parts.sum(0)
     return g2.t() @ x2
 
 
