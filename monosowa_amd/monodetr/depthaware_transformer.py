@@ -60,10 +60,18 @@ def merged_first_layers(x, heads):
     linear layers run as ONE GEMM over the concatenated weights (one forward launch, one set of backward kernels and one
     gradient for ``x`` instead of one per head), the rest of every MLP continues from its column block."""
     firsts = [h.layers[0] if isinstance(h, MLP) else h for h in heads]
-    w = torch.cat([f.weight for f in firsts])
-    b = torch.cat([f.bias for f in firsts])
-    parts = F.linear(x, w, b).split([f.out_features for f in firsts], dim=-1)
-    return [h.forward_from_first(p) if isinstance(h, MLP) else p for h, p in zip(heads, parts)]
+    # widest blocks first (their columns stay 16-byte aligned), and the total padded to a multiple of 4 columns with zero rows:
+    # the bias gradient of an odd-width GEMM ([8800, 515].sum(0)) falls off ATen's vectorised reduction (95 us instead of 17)
+    order = sorted(range(len(firsts)), key=lambda i: -firsts[i].out_features)
+    widths = [firsts[i].out_features for i in order]
+    pad = -sum(widths) % 4
+    ws, bs = [firsts[i].weight for i in order], [firsts[i].bias for i in order]
+    if pad:
+        ws.append(ws[0].new_zeros(pad, ws[0].shape[1]))
+        bs.append(bs[0].new_zeros(pad))
+    parts = F.linear(x, torch.cat(ws), torch.cat(bs)).split(widths + ([pad] if pad else []), dim=-1)
+    by_head = {i: parts[k] for k, i in enumerate(order)}
+    return [h.forward_from_first(by_head[i]) if isinstance(h, MLP) else by_head[i] for i, h in enumerate(heads)]
 
 
 def _clones(module, n):
