@@ -74,6 +74,10 @@ int mono_matched_losses_bwd_f32(const float *boxes, const float *depth, const fl
  * (int32 elements per chunk, any size), then wd[n_chunks] (float weight decay). */
 int mono_adamw_step_f32(const void *table, int n_chunks, double beta1, double beta2, double eps, double step_size, void *stream);
 
+/* out[c] = sum_r g[r][c] for ANY width C <= 1024 (odd widths too: 81 depth bins); partials: mono_colsum_any_blocks(rows) * C floats. */
+int mono_colsum_any_blocks(long long rows);
+int mono_colsum_any_f32(const float *g, float *out, float *partials, long long rows, int C, void *stream);
+
 /* out[c] = sum_k x[k][c] over a contiguous stack [n, C] of n slices (the partial products of a split-K weight gradient); C % 4 == 0,
  * 16-byte aligned pointers. */
 int mono_sum_slices_f32(const float *x, float *out, int n, long long C, void *stream);

@@ -305,6 +305,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ g
   }
 }
 
+// Column sums for ANY C <= 1024 (81 depth bins, 3 classes ...): thread = column (+ 256, + 512, ...), a workgroup walks its rows;
+// the partial rows are added by partial_sum_scalar_kernel.  (ATen's reduction takes 308 us for [30720, 81].)
+__global__ __launch_bounds__(256) void colsum_scalar_kernel(const float *__restrict__ g, float *__restrict__ partials, long long rows,
+                                                            int C, int rows_per_block) {
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long long r = r0;
+    for (; r + 3 < r1; r += 4) { a0 += g[r * C + c]; a1 += g[(r + 1) * C + c]; a2 += g[(r + 2) * C + c]; a3 += g[(r + 3) * C + c]; }
+    for (; r < r1; ++r) a0 += g[r * C + c];
+    partials[(long long)blockIdx.x * C + c] = (a0 + a1) + (a2 + a3);
+  }
+}
+__global__ __launch_bounds__(256) void partial_sum_scalar_kernel(const float *__restrict__ partials, float *__restrict__ out, int n, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int k = 0; k < n; ++k) a += partials[(long long)k * C + c];
+  out[c] = a;
+}
+
 // out[c] = sum_k partials[k][c], k < n: one 16-wave workgroup per 64 float4 columns, the waves split the rows.
 __global__ __launch_bounds__(1024) void partial_sum_kernel(const float *__restrict__ partials, float *__restrict__ out, int n, int C) {
   __shared__ float4 red[15][64];
@@ -576,6 +598,22 @@ int mono_colsum_f32(const float *g, float *out, float *partials, long long rows,
   else if (C <= 512) mono::colsum_kernel<2><<<grid, 256, 0, st>>>(g, partials, rows, C, rpb, rows, 0);
   else mono::colsum_kernel<4><<<grid, 256, 0, st>>>(g, partials, rows, C, rpb, rows, 0);
   mono::partial_sum_kernel<<<(C / 4 + 63) / 64, 1024, 0, st>>>(partials, out, grid, C);
+  return (int)hipGetLastError();
+}
+
+// out[c] = sum_r g[r][c] for any C <= 1024 (no alignment or width requirement); partials: mono_colsum_any_blocks(rows) * C floats.
+int mono_colsum_any_blocks(long long rows) {
+  const long long b = (rows + 127) / 128;
+  return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+}
+int mono_colsum_any_f32(const float *g, float *out, float *partials, long long rows, int C, void *stream_) {
+  if (!g || !out || !partials) return -1;
+  if (rows <= 0 || C <= 0 || C > 1024) return -2;
+  const int grid = mono_colsum_any_blocks(rows);
+  const int rpb = (int)((rows + grid - 1) / grid);
+  hipStream_t st = (hipStream_t)stream_;
+  mono::colsum_scalar_kernel<<<grid, 256, 0, st>>>(g, partials, rows, C, rpb);
+  mono::partial_sum_scalar_kernel<<<(C + 255) / 256, 256, 0, st>>>(partials, out, grid, C);
   return (int)hipGetLastError();
 }
 

@@ -784,7 +784,7 @@ def test_groupnorm_nhwc_matches_torch(shape, relu):
         assert (a.double() - b).abs().max() <= 3e-5 * max(b.abs().max().item(), 1.0), n
 
 
-@pytest.mark.parametrize("rows,C", [(8800, 256), (163200, 128), (30720, 512), (777, 1024), (5, 24), (1, 4)])
+@pytest.mark.parametrize("rows,C", [(8800, 256), (163200, 128), (30720, 512), (777, 1024), (5, 24), (1, 4), (30720, 81), (8800, 3), (131, 1023)])
 def test_colsum_matches_torch(rows, C):
     """mono_colsum_f32 (bias gradients) equals a float64 column sum."""
     from monosowa_amd.pointwise import colsum
