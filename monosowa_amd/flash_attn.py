@@ -7,6 +7,7 @@ import os
 import torch
 
 from ._lib import raw_stream
+from .token_linear import linear as fast_linear
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_attn.so")
 SYMBOLS = ("mono_attn_forward_f32", "mono_attn_backward_f32")
@@ -150,8 +151,8 @@ def mha_forward(mha, query, key, value):
         # the [L, B, E] view of a batch-major buffer (the decoder's queries, tokens cut out of an NHWC map): project the buffer as
         # it lies -- a non-contiguous input costs F.linear a copy and an unfused bias add -- and hand back the same kind of view
         if not x.is_contiguous() and x.transpose(0, 1).is_contiguous():
-            return torch.nn.functional.linear(x.transpose(0, 1), w_, b_).transpose(0, 1)
-        return torch.nn.functional.linear(x, w_, b_)
+            return fast_linear(x.transpose(0, 1), w_, b_).transpose(0, 1)
+        return fast_linear(x, w_, b_)
     # row blocks of the packed projection and column blocks of a merged output come from ONE split each: its backward is a
     # single concatenation, where every `w[a:b]` slice would zero-fill a full-size gradient, copy its block in and have
     # autograd add the pieces (5 launches per pair; 15 per call over weights, biases and activations)
@@ -169,8 +170,8 @@ def mha_forward(mha, query, key, value):
     heads = lambda t, L: t.unflatten(-1, (H, 32)).permute(1, 2, 0, 3)           # [L,B,E] -> [B,H,L,32] view
     o = attention(heads(q, Lq), heads(k, Lk), heads(v, Lk), mha.dropout if mha.training else 0.0)
     if _batch_major(o):                                 # o lies like q: out_proj on [B, Lq, E], returned as its [Lq, B, E] view
-        return mha.out_proj(o.permute(0, 2, 1, 3).reshape(B, Lq, E)).transpose(0, 1)
-    return mha.out_proj(o.permute(2, 0, 1, 3).reshape(Lq, B, E))
+        return fast_linear(o.permute(0, 2, 1, 3).reshape(B, Lq, E), mha.out_proj.weight, mha.out_proj.bias).transpose(0, 1)
+    return fast_linear(o.permute(2, 0, 1, 3).reshape(Lq, B, E), mha.out_proj.weight, mha.out_proj.bias)
 
 
 def mha_supported(mha, query, key, value):

@@ -22,7 +22,7 @@ from ..ms_deform_attn import MSDeformAttn
 from .. import encoder_block
 from ..flash_attn import mha_forward, mha_supported
 from ..pointwise import dropout_add_layernorm, refine_reference, refine_reference_supported, relu_dropout
-from ..token_linear import token_linear
+from ..token_linear import linear as fast_linear, token_linear
 
 
 LEVEL_EMBED_IN_BLOCK = True   # level_embed gradient from per-level sums inside the encoder blocks (constant pos tensor)
@@ -69,7 +69,7 @@ def merged_first_layers(x, heads):
     if pad:
         ws.append(ws[0].new_zeros(pad, ws[0].shape[1]))
         bs.append(bs[0].new_zeros(pad))
-    parts = F.linear(x, torch.cat(ws), torch.cat(bs)).split(widths + ([pad] if pad else []), dim=-1)
+    parts = fast_linear(x, torch.cat(ws), torch.cat(bs)).split(widths + ([pad] if pad else []), dim=-1)
     by_head = {i: parts[k] for k, i in enumerate(order)}
     return [h.forward_from_first(by_head[i]) if isinstance(h, MLP) else by_head[i] for i, h in enumerate(heads)]
 
@@ -275,8 +275,8 @@ class DepthAwareDecoderLayer(nn.Module):
             # x Wc^T + x Wp^T = x (Wc + Wp)^T -- one GEMM per q / k (and one set of backward kernels) instead of two plus an add
             # (-0.65 ms/step; composing further with the attention module's own input projections measured +1.0 ms: the
             # extra 256^3 products and their backward cost more than the two [8800, 256] GEMMs they replace)
-            q = F.linear(x, self.sa_qcontent_proj.weight + self.sa_qpos_proj.weight, self.sa_qcontent_proj.bias + self.sa_qpos_proj.bias)
-            k = F.linear(x, self.sa_kcontent_proj.weight + self.sa_kpos_proj.weight, self.sa_kcontent_proj.bias + self.sa_kpos_proj.bias)
+            q = fast_linear(x, self.sa_qcontent_proj.weight + self.sa_qpos_proj.weight, self.sa_qcontent_proj.bias + self.sa_qpos_proj.bias)
+            k = fast_linear(x, self.sa_kcontent_proj.weight + self.sa_kpos_proj.weight, self.sa_kcontent_proj.bias + self.sa_kpos_proj.bias)
         else:
             q = self.sa_qcontent_proj(x) + self.sa_qpos_proj(x)
             k = self.sa_kcontent_proj(x) + self.sa_kpos_proj(x)

@@ -13,7 +13,7 @@ from torch import nn
 from torch.nn.init import constant_, xavier_uniform_
 
 from . import ms_deform_attn_func as _func
-from .token_linear import token_linear
+from .token_linear import linear as fast_linear, token_linear
 
 
 def _is_power_of_2(n):
@@ -94,7 +94,7 @@ class MSDeformAttn(nn.Module):
             # a masked_fill pass over the value tensor, and `value` may be a column block of a wider projection.
             w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight])
             b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias])
-            proj = F.linear(query, w, b)
+            proj = fast_linear(query, w, b)
             v4 = value.unflatten(-1, (H, self.d_model // H))                       # a view, also of a column block
             if not (v4.stride(3) == 1 and v4.stride(2) == v4.shape[3] and v4.stride(1) % 4 == 0 and v4.data_ptr() % 16 == 0
                     and (N == 1 or v4.stride(0) == Len_in * v4.stride(1))):

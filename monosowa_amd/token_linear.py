@@ -54,6 +54,19 @@ class _TokenLinear(torch.autograd.Function):
         return gx, gw, gb
 
 
+FAST_LINEAR = True        # `linear()` below: our backward for every GEMM of >= FAST_MIN_ROWS tokens
+FAST_MIN_ROWS = 2048
+
+
+def linear(x, weight, bias=None):
+    """``F.linear`` whose backward is ours on the GPU: the bias gradient through the column-sum kernels (10 us for [8800, 256];
+    the reduction inside AddmmBackward takes 25), the weight gradient split over K when there are enough tokens."""
+    if FAST_LINEAR and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and weight.requires_grad \
+            and x.numel() // x.shape[-1] >= FAST_MIN_ROWS:
+        return _TokenLinear.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
 def token_linear(x, linear):
     """``linear(x)`` for an ``nn.Linear``.  On the GPU under autograd the backward is ours: split-K weight gradient
     when there are enough tokens, bias gradient through the column-sum kernel."""
@@ -61,6 +74,8 @@ def token_linear(x, linear):
         # the [L, B, C] view of a batch-major buffer: the GEMM runs on the buffer as it lies (a non-contiguous input costs
         # F.linear a copy and an unfused bias add), the result is handed back as the same kind of view
         return token_linear(x.transpose(0, 1), linear).transpose(0, 1)
-    if x.is_cuda and torch.is_grad_enabled() and linear.weight.requires_grad and x.numel() // x.shape[-1] >= MIN_ROWS:
+    rows = x.numel() // x.shape[-1]
+    if x.is_cuda and torch.is_grad_enabled() and linear.weight.requires_grad and \
+            (rows >= MIN_ROWS or (FAST_LINEAR and rows >= FAST_MIN_ROWS and x.dtype == torch.float32)):
         return _TokenLinear.apply(x, linear.weight, linear.bias)
     return linear(x)
