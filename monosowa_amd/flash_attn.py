@@ -147,6 +147,14 @@ def mha_forward(mha, query, key, value):
     w, bias = mha.in_proj_weight, mha.in_proj_bias
     Lq, B, _ = query.shape
     Lk = key.size(0)
+    def lin2(x, w_, b_):
+        """two column blocks of one projection; for a batch-major input the split happens on the batch-major output, so that its
+        backward concatenates the two gradients in the layout the GEMM's backward wants (no [B, L, 2 E] copy)"""
+        if not x.is_contiguous() and x.transpose(0, 1).is_contiguous():
+            a, b2 = fast_linear(x.transpose(0, 1), w_, b_).split(E, -1)
+            return a.transpose(0, 1), b2.transpose(0, 1)
+        return fast_linear(x, w_, b_).split(E, -1)
+
     def lin(x, w_, b_):
         # the [L, B, E] view of a batch-major buffer (the decoder's queries, tokens cut out of an NHWC map): project the buffer as
         # it lies -- a non-contiguous input costs F.linear a copy and an unfused bias add -- and hand back the same kind of view
@@ -158,12 +166,12 @@ def mha_forward(mha, query, key, value):
     # autograd add the pieces (5 launches per pair; 15 per call over weights, biases and activations)
     if query is key:                                    # depth encoder: q = k = src + pos, v = src
         (w_qk, w_v), (b_qk, b_v) = w.split([2 * E, E]), bias.split([2 * E, E])
-        q, k = lin(query, w_qk, b_qk).split(E, -1)
+        q, k = lin2(query, w_qk, b_qk)
         v = lin(value, w_v, b_v)
     elif key is value:                                  # decoder: k = v = depth-aware tokens
         (w_q, w_kv), (b_q, b_kv) = w.split([E, 2 * E]), bias.split([E, 2 * E])
         q = lin(query, w_q, b_q)
-        k, v = lin(key, w_kv, b_kv).split(E, -1)
+        k, v = lin2(key, w_kv, b_kv)
     else:
         (w_q, w_k, w_v), (b_q, b_k, b_v) = w.split(E), bias.split(E)
         q, k, v = lin(query, w_q, b_q), lin(key, w_k, b_k), lin(value, w_v, b_v)
