@@ -23,6 +23,9 @@ int mono_bias_relu_mask_f32(float *y, const float *bias, const float *residual, 
                             void *stream);
 int mono_relu_grad_mask_f32(const float *grad_a, const float *grad_b, const unsigned char *mask, float *grad_in, long long n,
                             void *stream);
+/* the same for three gradients (a tensor with three consumers) */
+int mono_relu_grad_mask3_f32(const float *grad_a, const float *grad_b, const float *grad_c, const unsigned char *mask, float *grad_in,
+                             long long n, void *stream);
 
 /* Frozen batch-norm + ReLU after a convolution without residual, applied here instead of folded into the weights
  * (backbone.py:28-65): y = relu(y * scale[c] + shift[c]) in place + byte mask; grad_in = grad * mask * scale[c]. */

@@ -51,6 +51,21 @@ __global__ __launch_bounds__(256) void bias_relu_mask_kernel(float *__restrict__
     reinterpret_cast<float4 *>(y)[i] = v;
   }
 }
+// three gradients meeting at one ReLU output (a stage output of the backbone: the next stage's first convolution, its identity
+// branch, and the feature-pyramid projection outside the body)
+__global__ __launch_bounds__(256) void relu_grad_mask3_kernel(const float *__restrict__ ga, const float *__restrict__ gb,
+                                                              const float *__restrict__ gc, const unsigned char *__restrict__ mask,
+                                                              float *__restrict__ grad_in, long long n_vec) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    float4 a = reinterpret_cast<const float4 *>(ga)[i];
+    const float4 b = reinterpret_cast<const float4 *>(gb)[i], c = reinterpret_cast<const float4 *>(gc)[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+    const unsigned m = mask[i];
+    reinterpret_cast<float4 *>(grad_in)[i] = make_float4((m & 1u) ? a.x : 0.f, (m & 2u) ? a.y : 0.f, (m & 4u) ? a.z : 0.f, (m & 8u) ? a.w : 0.f);
+  }
+}
 template <bool TWO>
 __global__ __launch_bounds__(256) void relu_grad_mask_kernel(const float *__restrict__ ga, const float *__restrict__ gb,
                                                              const unsigned char *__restrict__ mask, float *__restrict__ grad_in,
@@ -455,6 +470,14 @@ int mono_relu_grad_mask_f32(const float *grad_a, const float *grad_b, const unsi
   const int g = mono::grid_for_vec(n / 4);
   if (grad_b) mono::relu_grad_mask_kernel<true><<<g, 256, 0, (hipStream_t)stream_>>>(grad_a, grad_b, mask, grad_in, n / 4);
   else mono::relu_grad_mask_kernel<false><<<g, 256, 0, (hipStream_t)stream_>>>(grad_a, nullptr, mask, grad_in, n / 4);
+  return (int)hipGetLastError();
+}
+
+int mono_relu_grad_mask3_f32(const float *grad_a, const float *grad_b, const float *grad_c, const unsigned char *mask, float *grad_in,
+                             long long n, void *stream_) {
+  if (!grad_a || !grad_b || !grad_c || !mask || !grad_in) return -1;
+  if (n <= 0 || (n & 3) || ((uintptr_t)grad_a & 15) || ((uintptr_t)grad_b & 15) || ((uintptr_t)grad_c & 15) || ((uintptr_t)grad_in & 15)) return -2;
+  mono::relu_grad_mask3_kernel<<<mono::grid_for_vec(n / 4), 256, 0, (hipStream_t)stream_>>>(grad_a, grad_b, grad_c, mask, grad_in, n / 4);
   return (int)hipGetLastError();
 }
 

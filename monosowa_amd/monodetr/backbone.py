@@ -92,15 +92,15 @@ def folded_weight(conv, bn, scale):
     return cached[1]
 
 
-def conv_bn_fork(x, conv, bn, residual):
+def conv_bn_fork(x, conv, bn, residual, n_out=2):
     """``conv_bn(x, conv, bn, residual)`` returned as a pair for its two consumers (next block's first convolution and
     identity branch): their gradients are added inside the fused ReLU backward (``pointwise.bias_act_fork``)."""
     if isinstance(bn, FrozenBatchNorm2d):
         scale, shift = bn.scale_shift()
         y = F.conv2d(x, folded_weight(conv, bn, scale), None, conv.stride, conv.padding, conv.dilation, conv.groups)
-        return bias_act_fork(y, shift, residual)
+        return bias_act_fork(y, shift, residual, n_out)
     out = conv_bn(x, conv, bn, residual)
-    return out, out
+    return (out,) * n_out
 
 
 def conv_bn(x, conv, bn, residual=None, relu=True):
@@ -144,7 +144,7 @@ class Bottleneck(nn.Module):
         out = conv_bn(xa, self.conv1, self.bn1)
         out = conv_bn(out, self.conv2, self.bn2)
         identity = xb if self.downsample is None else conv_bn(xb, self.downsample[0], self.downsample[1], relu=False)
-        return conv_bn_fork(out, self.conv3, self.bn3, identity)
+        return conv_bn_fork(out, self.conv3, self.bn3, identity, getattr(self, "n_out", 2))
 
 
 _DEPTHS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}
@@ -188,12 +188,19 @@ class ResNetBody(nn.Module):
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
         # blocks hand (a, b) pairs to each other (one tensor object per consumer, see Bottleneck.forward); the stage
         # outputs that leave the body are the first members
+        # a stage output that also leaves the body (layer2 / layer3 with intermediate layers) has a third consumer: its last block
+        # returns three handles, the third goes out; layer4's two handles serve the two projections that read c5 (the second
+        # one rides along as `fork_twin`): no gradient accumulation pass over any stage output
         x = self.layer1(x)
+        if self.return_interm_layers:
+            self.layer2[-1].n_out = self.layer3[-1].n_out = 3
         c3 = self.layer2(x)
-        c4 = self.layer3(c3)
-        c5 = self.layer4(c4)
-        c3, c4, c5 = c3[0], c4[0], c5[0]
-        return {"0": c3, "1": c4, "2": c5} if self.return_interm_layers else {"0": c5}
+        c4 = self.layer3(c3[:2])
+        c5 = self.layer4(c4[:2])
+        out5 = c5[0]
+        if c5[1] is not c5[0]:
+            out5.fork_twin = c5[1]
+        return {"0": c3[-1], "1": c4[-1], "2": out5} if self.return_interm_layers else {"0": out5}
 
 
 class Backbone(nn.Module):

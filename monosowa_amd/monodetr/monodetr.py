@@ -133,7 +133,8 @@ class MonoDETR(nn.Module):
             srcs.append(self._project(l, src))
             masks.append(mask)
         for l in range(len(srcs), self.num_feature_levels):   # extra stride-2 levels from C5
-            src = self._project(l, features[-1].tensors if l == len(features) else srcs[-1])
+            last = features[-1].tensors
+            src = self._project(l, getattr(last, "fork_twin", last) if l == len(features) else srcs[-1])      # (c5's second handle)
             mask = torch.zeros(src.shape[0], src.shape[2], src.shape[3], dtype=torch.bool, device=src.device)
             pos.append(self.backbone[1](NestedTensor(src, mask, all_valid=True)).to(src.dtype))
             srcs.append(src)

@@ -11,7 +11,7 @@ _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmono
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
-           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32", "mono_relu_dropout_bwd_colsum_f32", "mono_sum_slices_f32", "mono_colsum_any_blocks", "mono_colsum_any_f32")
+           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32", "mono_relu_dropout_bwd_colsum_f32", "mono_sum_slices_f32", "mono_colsum_any_blocks", "mono_colsum_any_f32", "mono_relu_grad_mask3_f32")
 _lib = None
 
 
@@ -55,6 +55,8 @@ def load():
         lib.mono_colsum_any_blocks.argtypes = [LL]
         lib.mono_colsum_any_f32.restype = I
         lib.mono_colsum_any_f32.argtypes = [P, P, P, LL, I, P]
+        lib.mono_relu_grad_mask3_f32.restype = I
+        lib.mono_relu_grad_mask3_f32.argtypes = [P, P, P, P, P, LL, P]
         lib.mono_sum_slices_f32.restype = I
         lib.mono_sum_slices_f32.argtypes = [P, P, I, LL, P]
         lib.mono_relu_dropout_bwd_colsum_f32.restype = I
@@ -193,7 +195,7 @@ class _BiasActFork(torch.autograd.Function):
     a ResNet block output; the backward adds their gradients and applies the ReLU mask in one pass."""
 
     @staticmethod
-    def forward(ctx, y, bias, residual):
+    def forward(ctx, y, bias, residual, n_out=2):
         rows = y.numel() // y.size(1)
         mask = torch.empty(y.numel() // 4, dtype=torch.uint8, device=y.device) if USE_RELU_MASK else None
         with torch.cuda.device(y.device):
@@ -209,42 +211,45 @@ class _BiasActFork(torch.autograd.Function):
         ctx.masked = mask is not None
         ctx.shape = y.shape
         ctx.bias_grad = bias.requires_grad
-        return y, y.detach()
+        return (y, y.detach()) if n_out == 2 else (y, y.detach(), y.detach())
 
     @staticmethod
-    def backward(ctx, ga, gb):
+    def backward(ctx, ga, gb, gc=None):
         (y,) = ctx.saved_tensors                       # the byte mask when ctx.masked
         cl = lambda t: t.contiguous(memory_format=torch.channels_last)
         lib = load()
         g = torch.empty(ctx.shape, dtype=torch.float32, device=y.device, memory_format=torch.channels_last)
         n = g.numel()
+        given = [cl(t) for t in (ga, gb, gc) if t is not None]
+        if len(given) == 3 and not ctx.masked:
+            given = [given[0] + given[1], given[2]]          # (only the byte-mask form has a three-gradient kernel)
         with torch.cuda.device(y.device):
             st = raw_stream()
-            if ga is not None and gb is not None:
-                ga, gb = cl(ga), cl(gb)
+            if len(given) == 3:
+                code = lib.mono_relu_grad_mask3_f32(given[0].data_ptr(), given[1].data_ptr(), given[2].data_ptr(), y.data_ptr(), g.data_ptr(), n, st)
+            elif len(given) == 2:
                 if ctx.masked:
-                    code = lib.mono_relu_grad_mask_f32(ga.data_ptr(), gb.data_ptr(), y.data_ptr(), g.data_ptr(), n, st)
+                    code = lib.mono_relu_grad_mask_f32(given[0].data_ptr(), given[1].data_ptr(), y.data_ptr(), g.data_ptr(), n, st)
                 else:
-                    code = lib.mono_relu_grad2_f32(ga.data_ptr(), gb.data_ptr(), y.data_ptr(), g.data_ptr(), n, st)
+                    code = lib.mono_relu_grad2_f32(given[0].data_ptr(), given[1].data_ptr(), y.data_ptr(), g.data_ptr(), n, st)
             else:
-                one = cl(ga if ga is not None else gb)
                 if ctx.masked:
-                    code = lib.mono_relu_grad_mask_f32(one.data_ptr(), None, y.data_ptr(), g.data_ptr(), n, st)
+                    code = lib.mono_relu_grad_mask_f32(given[0].data_ptr(), None, y.data_ptr(), g.data_ptr(), n, st)
                 else:
-                    code = lib.mono_relu_grad_f32(one.data_ptr(), y.data_ptr(), g.data_ptr(), n, st)
+                    code = lib.mono_relu_grad_f32(given[0].data_ptr(), y.data_ptr(), g.data_ptr(), n, st)
         if code:
             raise RuntimeError("mono_relu_grad(2)_f32 failed with code %d" % code)
-        return g, (g.sum((0, 2, 3)) if ctx.bias_grad else None), g
+        return g, (g.sum((0, 2, 3)) if ctx.bias_grad else None), g, None
 
 
-def bias_act_fork(y, bias, residual):
-    """``relu(y + bias + residual)`` twice -- ``(a, b)`` with ``a is b`` semantically, meant for exactly two
-    consumers (see ``_BiasActFork``); plain PyTorch (the same tensor twice) off the HIP path."""
+def bias_act_fork(y, bias, residual, n_out=2):
+    """``relu(y + bias + residual)`` ``n_out`` (2 or 3) times -- the same values as separate tensor objects, one per consumer
+    (see ``_BiasActFork``); plain PyTorch (the same tensor repeated) off the HIP path."""
     if _nhwc_ok(y) and bias.is_cuda and bias.dtype == torch.float32 and bias.data_ptr() % 16 == 0 \
             and _nhwc_ok(residual) and residual.shape == y.shape and torch.is_grad_enabled() and y.requires_grad:
-        return _BiasActFork.apply(y, bias.contiguous(), residual)
+        return _BiasActFork.apply(y, bias.contiguous(), residual, n_out)
     out = bias_act(y, bias, residual, True)
-    return out, out
+    return (out,) * n_out
 
 
 def bias_act(y, bias, residual=None, relu=True):
