@@ -704,6 +704,9 @@ def ddn_loss_supported(logits, boxes, depth, valid):
             and boxes.dtype == torch.float32 and depth.dtype == torch.float32 and valid.dtype == torch.bool)
 
 
+DDN_EAGER_BACKWARD = True     # see _DDNLoss.forward
+
+
 class _DDNLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, boxes, depth, valid, alpha, gamma, fg_weight, bg_weight, depth_min, depth_max):
@@ -718,12 +721,29 @@ class _DDNLoss(torch.autograd.Function):
                                          raw_stream())
         if code:
             raise RuntimeError("mono_ddn_loss_fwd_f32 failed with code %d" % code)
-        ctx.save_for_backward(logits, boxes, depth, valid)
         ctx.consts = (alpha, gamma, fg_weight, bg_weight, depth_min, depth_max)
+        ctx.eager = None
+        if DDN_EAGER_BACKWARD and logits.requires_grad:
+            # the gradient for an upstream factor of 1, evaluated NOW: the criterion calls this between the two halves of the
+            # matcher, where the GPU would otherwise idle while the host solves the assignments -- 0.16 ms of the backward
+            # moved under that wait; backward() only scales it
+            one = torch.ones(1, dtype=torch.float32, device=logits.device)
+            grad = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=logits.device)
+            code = lib.mono_ddn_loss_bwd_f32(logits.data_ptr(), boxes.data_ptr(), depth.data_ptr(), valid.data_ptr(), one.data_ptr(),
+                                             grad.data_ptr(), B, C, H, W, N, sb, sc, sp, *ctx.consts, raw_stream())
+            if code:
+                raise RuntimeError("mono_ddn_loss_bwd_f32 failed with code %d" % code)
+            ctx.save_for_backward(grad)
+            ctx.eager = True
+        else:
+            ctx.save_for_backward(logits, boxes, depth, valid)
         return partial.sum() / (B * H * W)
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.eager:
+            (grad,) = ctx.saved_tensors
+            return (grad * g,) + (None,) * 9
         logits, boxes, depth, valid = ctx.saved_tensors
         B, C, H, W = logits.shape
         sb, sc, sp = _ddn_strides(logits)
