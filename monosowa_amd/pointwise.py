@@ -498,16 +498,21 @@ COLSUM_MAX_C = 512     # wider matrices: the PyTorch reduction is as fast
 def colsum(g2):
     """``g2.sum(0)`` of a [rows, C] matrix (bias gradients); HIP kernel for contiguous float32 GPU input with
     C % 4 == 0 and C <= 512 (wider matrices: the PyTorch reduction is as fast), torch otherwise."""
-    if g2.is_cuda and g2.dtype == torch.float32 and g2.dim() == 2 and g2.is_contiguous() and g2.size(1) % 4 == 0 \
-            and g2.size(1) <= COLSUM_MAX_C and g2.size(0) > 0 and g2.data_ptr() % 16 == 0:
-        out = torch.empty(g2.size(1), dtype=torch.float32, device=g2.device)
-        partials = torch.empty(load().mono_reduce_blocks(g2.size(0)) * g2.size(1), dtype=torch.float32, device=g2.device)
-        with torch.cuda.device(g2.device):
-            code = load().mono_colsum_f32(g2.data_ptr(), out.data_ptr(), partials.data_ptr(), g2.size(0), g2.size(1),
-                                          raw_stream())
+    rows, C = (g2.shape if g2.dim() == 2 else (0, 0))
+    if rows > 0 and C % 4 == 0 and C <= COLSUM_MAX_C and g2.is_cuda and g2.dtype == torch.float32 and g2.is_contiguous() \
+            and g2.data_ptr() % 16 == 0:
+        lib = load()
+        # one allocation: [out | partial rows]  (the host side of this call is on the step's critical path, see token_linear)
+        buf = torch.empty((lib.mono_reduce_blocks(rows) + 1) * C, dtype=torch.float32, device=g2.device)
+        p0 = buf.data_ptr()
+        if g2.device.index == torch.cuda.current_device():
+            code = lib.mono_colsum_f32(g2.data_ptr(), p0, p0 + 4 * C, rows, C, raw_stream())
+        else:
+            with torch.cuda.device(g2.device):
+                code = lib.mono_colsum_f32(g2.data_ptr(), p0, p0 + 4 * C, rows, C, raw_stream())
         if code:
             raise RuntimeError("mono_colsum_f32 failed with code %d" % code)
-        return out
+        return buf[:C]
     if g2.is_cuda and g2.dtype == torch.float32 and g2.dim() == 2 and g2.is_contiguous() and 16 <= g2.size(1) <= 1024 and g2.size(1) % 4 \
             and g2.size(0) > 0:
         lib = load()                                   # odd widths fall off ATen's vectorised reduction: 308 us for [30720, 81], 59 here
