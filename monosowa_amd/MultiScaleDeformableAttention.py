@@ -20,6 +20,8 @@ import sys
 
 import torch
 
+from ._lib import on_device
+
 from . import _lib
 
 __all__ = ["ms_deform_attn_forward", "ms_deform_attn_backward", "ms_deform_attn_fused_forward",
@@ -107,7 +109,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     if host_geom is None:      # only a pre-attached copy is used here: the forward never synchronises for it
         host_geom = getattr(spatial_shapes, "_msda_host_geometry", None) or (None, None)
     timer = LaunchTimer.active
-    with torch.cuda.device(value.device):
+    with on_device(value.device):
         stream = torch.cuda.current_stream() if timer is not None else None      # (a Stream object only for the events)
         raw = _lib.raw_stream()
         if timer is not None:
@@ -162,7 +164,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     if host_geom is None:
         host_geom = host_geometry(spatial_shapes, level_start_index) if ws_bytes else (None, None)
     timer = LaunchTimer.active
-    with torch.cuda.device(value.device):
+    with on_device(value.device):
         stream = torch.cuda.current_stream() if timer is not None else None      # (a Stream object only for the events)
         raw = _lib.raw_stream()
         if timer is not None:
@@ -205,7 +207,7 @@ def ms_deform_attn_fused_forward(value, spatial_shapes, level_start_index, sampl
     geom = host_geometry(spatial_shapes, level_start_index)
     out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
     timer = LaunchTimer.active
-    with torch.cuda.device(value.device):
+    with on_device(value.device):
         stream = torch.cuda.current_stream() if timer is not None else None      # (a Stream object only for the events)
         raw = _lib.raw_stream()
         if timer is not None:
@@ -234,7 +236,7 @@ def ms_deform_attn_fused_backward(value, spatial_shapes, level_start_index, samp
     ws_bytes = lib.msda_backward_workspace_bytes(B, S, M, D, L, Lq, P, 4)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
     timer = LaunchTimer.active
-    with torch.cuda.device(value.device):
+    with on_device(value.device):
         stream = torch.cuda.current_stream() if timer is not None else None      # (a Stream object only for the events)
         raw = _lib.raw_stream()
         if timer is not None:
@@ -284,7 +286,7 @@ def _fused_forward_view(value, spatial_shapes, level_start_index, proj, referenc
     loc = torch.empty((B, M, L, Lq, P, 2), dtype=value.dtype, device=value.device) if save else None
     attw = torch.empty((B, M, L, Lq, P), dtype=value.dtype, device=value.device) if save else None
     timer = LaunchTimer.active
-    with torch.cuda.device(value.device):
+    with on_device(value.device):
         stream = torch.cuda.current_stream() if timer is not None else None      # (a Stream object only for the events)
         raw = _lib.raw_stream()
         if timer is not None:
@@ -314,7 +316,7 @@ def _fused_backward_view(value, spatial_shapes, level_start_index, a, b, saved, 
     ws_bytes = lib.msda_backward_workspace_bytes(B, S, M, D, L, Lq, P, 4)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
     timer = LaunchTimer.active
-    with torch.cuda.device(value.device):
+    with on_device(value.device):
         stream = torch.cuda.current_stream() if timer is not None else None      # (a Stream object only for the events)
         raw = _lib.raw_stream()
         if timer is not None:

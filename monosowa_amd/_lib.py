@@ -87,3 +87,18 @@ def raw_stream():
     host-bound stretch of a train step."""
     import torch
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+
+import contextlib
+
+_SAME_DEVICE = contextlib.nullcontext()
+
+
+def on_device(device):
+    """``with on_device(t.device):`` -- makes ``device`` current for a launch.  A no-op object when it already is (one process per
+    GPU: always): ``torch.cuda.device(...)`` costs 5-8 us of host time per use, and the launches of the decoder's backward sit
+    right behind the matcher's synchronisation where the GPU waits for the host."""
+    import torch
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _SAME_DEVICE
+    return torch.cuda.device(device)

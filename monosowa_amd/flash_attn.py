@@ -6,7 +6,7 @@ import os
 
 import torch
 
-from ._lib import raw_stream
+from ._lib import raw_stream, on_device
 from .token_linear import linear as fast_linear
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_attn.so")
@@ -59,7 +59,7 @@ def forward(q, k, v, scale, p, seed):
     B, H, Lq, _ = q.shape
     o = torch.empty((B, H, Lq, 32), dtype=torch.float32, device=q.device)
     lse = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
-    with torch.cuda.device(q.device):
+    with on_device(q.device):
         code = load().mono_attn_forward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Lq,
                                             k.size(2), 32, _strides(q), _strides(k), _strides(v), _strides(o), float(scale),
                                             float(p), seed, raw_stream())
@@ -89,7 +89,7 @@ def backward(q, k, v, o, lse, dout, scale, p, seed):
     dq, dk, dv = _like_heads(q), _like_heads(k), _like_heads(v)
     delta = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
     assert dout.stride() == o.stride()
-    with torch.cuda.device(q.device):
+    with on_device(q.device):
         code = load().mono_attn_backward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), dout.data_ptr(),
                                              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Lq, Lk, 32,
                                              _strides(q), _strides(k), _strides(v), _strides(o), _strides(dq), _strides(dk),
@@ -107,7 +107,7 @@ class _Attention(torch.autograd.Function):
         B, H, Lq, _ = q.shape
         o = _like_heads(q)                           # [Lq, B, H*32] or, for a batch-major q, [B, Lq, H*32]
         lse = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
-        with torch.cuda.device(q.device):
+        with on_device(q.device):
             code = load().mono_attn_forward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Lq,
                                                 k.size(2), 32, _strides(q), _strides(k), _strides(v), _strides(o), float(scale),
                                                 float(p), seed, raw_stream())

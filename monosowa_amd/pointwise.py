@@ -5,7 +5,7 @@ import os
 
 import torch
 
-from ._lib import raw_stream
+from ._lib import raw_stream, on_device
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
@@ -113,7 +113,7 @@ class _BiasAct(torch.autograd.Function):
         rows = y.numel() // y.size(1)
         res_ptr = residual.data_ptr() if residual is not None else None
         mask = None
-        with torch.cuda.device(y.device):
+        with on_device(y.device):
             st = raw_stream()
             if relu and USE_RELU_MASK and (y.requires_grad or (residual is not None and residual.requires_grad)):
                 mask = torch.empty(y.numel() // 4, dtype=torch.uint8, device=y.device)
@@ -137,7 +137,7 @@ class _BiasAct(torch.autograd.Function):
             (y,) = ctx.saved_tensors                   # the byte mask when ctx.masked
             grad = grad.contiguous(memory_format=torch.channels_last)
             g = torch.empty_like(grad, memory_format=torch.channels_last)
-            with torch.cuda.device(y.device):
+            with on_device(y.device):
                 if ctx.masked:
                     code = load().mono_relu_grad_mask_f32(grad.data_ptr(), None, y.data_ptr(), g.data_ptr(), grad.numel(),
                                                           raw_stream())
@@ -159,7 +159,7 @@ class _AffineRelu(torch.autograd.Function):
     def forward(ctx, y, scale, shift):
         rows, C = y.numel() // y.size(1), y.size(1)
         mask = torch.empty(y.numel() // 4, dtype=torch.uint8, device=y.device)
-        with torch.cuda.device(y.device):
+        with on_device(y.device):
             code = load().mono_affine_relu_mask_f32(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), mask.data_ptr(), rows, C,
                                                     raw_stream())
         if code:
@@ -173,7 +173,7 @@ class _AffineRelu(torch.autograd.Function):
         mask, scale = ctx.saved_tensors
         grad = grad.contiguous(memory_format=torch.channels_last)
         g = torch.empty_like(grad, memory_format=torch.channels_last)
-        with torch.cuda.device(grad.device):
+        with on_device(grad.device):
             code = load().mono_affine_relu_grad_f32(grad.data_ptr(), mask.data_ptr(), scale.data_ptr(), g.data_ptr(),
                                                     grad.numel() // grad.size(1), grad.size(1), raw_stream())
         if code:
@@ -198,7 +198,7 @@ class _BiasActFork(torch.autograd.Function):
     def forward(ctx, y, bias, residual, n_out=2):
         rows = y.numel() // y.size(1)
         mask = torch.empty(y.numel() // 4, dtype=torch.uint8, device=y.device) if USE_RELU_MASK else None
-        with torch.cuda.device(y.device):
+        with on_device(y.device):
             st = raw_stream()
             if mask is not None:
                 code = load().mono_bias_relu_mask_f32(y.data_ptr(), bias.data_ptr(), residual.data_ptr(), mask.data_ptr(), rows, y.size(1), st)
@@ -223,7 +223,7 @@ class _BiasActFork(torch.autograd.Function):
         given = [cl(t) for t in (ga, gb, gc) if t is not None]
         if len(given) == 3 and not ctx.masked:
             given = [given[0] + given[1], given[2]]          # (only the byte-mask form has a three-gradient kernel)
-        with torch.cuda.device(y.device):
+        with on_device(y.device):
             st = raw_stream()
             if len(given) == 3:
                 code = lib.mono_relu_grad_mask3_f32(given[0].data_ptr(), given[1].data_ptr(), given[2].data_ptr(), y.data_ptr(), g.data_ptr(), n, st)
@@ -309,7 +309,7 @@ def ln_forward(x, z, weight, bias, p, eps):
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
     seed = _next_seed() if p > 0 else 0
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         code = load().mono_dropout_add_layernorm_fwd_f32(
             x.data_ptr(), z.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), s.data_ptr(), mean.data_ptr(),
             rstd.data_ptr(), rows, 256, float(p), seed, float(eps), raw_stream())
@@ -326,7 +326,7 @@ def ln_backward(gy, s, mean, rstd, weight, p, seed, with_gz_sum=False):
     rows = s.numel() // 256
     gw = torch.empty(3, 256, dtype=torch.float32, device=s.device)
     partials = torch.empty(load().mono_reduce_blocks(rows) * 768, dtype=torch.float32, device=s.device)
-    with torch.cuda.device(s.device):
+    with on_device(s.device):
         code = load().mono_dropout_add_layernorm_bwd_f32(
             gy.data_ptr(), s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), weight.data_ptr(), gx.data_ptr(), gz.data_ptr(),
             gw.data_ptr(), partials.data_ptr(), rows, 256, float(p), seed, raw_stream())
@@ -373,7 +373,7 @@ class _GroupNormNHWC(torch.autograd.Function):
         y = torch.empty_like(x)                                       # keeps the channels_last strides
         stats = torch.zeros(B, 32, 2, dtype=torch.float64, device=x.device)
         mean_rstd = torch.empty(B, 32, 2, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             code = load().mono_groupnorm_nhwc_fwd_f32(x.data_ptr(), pre_bias.data_ptr() if pre_bias is not None else None,
                                                       weight.data_ptr(), bias.data_ptr(), y.data_ptr(), stats.data_ptr(),
                                                       mean_rstd.data_ptr(), B, H * W, C, 32, float(eps), int(relu),
@@ -397,7 +397,7 @@ class _GroupNormNHWC(torch.autograd.Function):
             gbias = torch.empty(C, dtype=torch.float32, device=x.device)
             partials = torch.empty(lib.mono_groupnorm_blocks(B, H * W) * C, dtype=torch.float32, device=x.device)
         ptr = lambda t: t.data_ptr() if t is not None else None
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             code = lib.mono_groupnorm_nhwc_bwd_f32(gy.data_ptr(), x.data_ptr(), ptr(pre_bias), ptr(y if ctx.relu else None),
                                                    mean_rstd.data_ptr(), weight.data_ptr(), gx.data_ptr(), part.data_ptr(),
                                                    ptr(gbias), ptr(partials), B, H * W, C, 32, int(ctx.relu),
@@ -438,7 +438,7 @@ def colsum_levels(g3, bounds):
     B, S, C = g3.shape
     out = torch.empty((len(bounds), C), dtype=torch.float32, device=g3.device)
     lib = load()
-    with torch.cuda.device(g3.device):
+    with on_device(g3.device):
         st = raw_stream()
         for i, (a, b) in enumerate(bounds):
             partials = torch.empty(lib.mono_reduce_blocks(B * (b - a)) * C, dtype=torch.float32, device=g3.device)
@@ -484,7 +484,7 @@ def sum_slices(t):
     inner = t[0].numel() if t.dim() > 1 and t.size(0) > 0 else 0
     if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and inner and inner % 4 == 0 and t.data_ptr() % 16 == 0:
         out = torch.empty(t.shape[1:], dtype=torch.float32, device=t.device)
-        with torch.cuda.device(t.device):
+        with on_device(t.device):
             code = load().mono_sum_slices_f32(t.data_ptr(), out.data_ptr(), t.size(0), inner, raw_stream())
         if code:
             raise RuntimeError("mono_sum_slices_f32 failed with code %d" % code)
@@ -508,7 +508,7 @@ def colsum(g2):
         if g2.device.index == torch.cuda.current_device():
             code = lib.mono_colsum_f32(g2.data_ptr(), p0, p0 + 4 * C, rows, C, raw_stream())
         else:
-            with torch.cuda.device(g2.device):
+            with on_device(g2.device):
                 code = lib.mono_colsum_f32(g2.data_ptr(), p0, p0 + 4 * C, rows, C, raw_stream())
         if code:
             raise RuntimeError("mono_colsum_f32 failed with code %d" % code)
@@ -518,7 +518,7 @@ def colsum(g2):
         lib = load()                                   # odd widths fall off ATen's vectorised reduction: 308 us for [30720, 81], 59 here
         out = torch.empty(g2.size(1), dtype=torch.float32, device=g2.device)
         partials = torch.empty(lib.mono_colsum_any_blocks(g2.size(0)) * g2.size(1), dtype=torch.float32, device=g2.device)
-        with torch.cuda.device(g2.device):
+        with on_device(g2.device):
             code = lib.mono_colsum_any_f32(g2.data_ptr(), out.data_ptr(), partials.data_ptr(), g2.size(0), g2.size(1), raw_stream())
         if code:
             raise RuntimeError("mono_colsum_any_f32 failed with code %d" % code)
@@ -573,7 +573,7 @@ class FusedAdamWPlan:
         self.dev.copy_(self.host, non_blocking=True)
         self.copied = torch.cuda.Event()
         self.copied.record()
-        with torch.cuda.device(self.device):
+        with on_device(self.device):
             code = load().mono_adamw_step_f32(self.dev.data_ptr(), self.n_chunks, beta1, beta2, eps, step_size,
                                               raw_stream())
         if code:
@@ -585,7 +585,7 @@ def relu_dropout_forward(h, p):
     if not row_dense(h):
         h = h.contiguous()
     y = torch.empty_like(h)                      # elementwise: memory order, strides kept
-    with torch.cuda.device(h.device):
+    with on_device(h.device):
         code = load().mono_relu_dropout_fwd_f32(h.data_ptr(), y.data_ptr(), h.numel(), float(p), _next_seed(), raw_stream())
     if code:
         raise RuntimeError("mono_relu_dropout_fwd_f32 failed with code %d" % code)
@@ -602,7 +602,7 @@ def relu_dropout_backward_colsum(gy, y, p):
     lib = load()
     out = torch.empty(256, dtype=torch.float32, device=y.device)
     partials = torch.empty(lib.mono_reduce_blocks(rows) * 256, dtype=torch.float32, device=y.device)
-    with torch.cuda.device(y.device):
+    with on_device(y.device):
         code = lib.mono_relu_dropout_bwd_colsum_f32(gy.data_ptr(), y.data_ptr(), gh.data_ptr(), out.data_ptr(), partials.data_ptr(), rows,
                                                     float(p), raw_stream())
     if code:
@@ -613,7 +613,7 @@ def relu_dropout_backward_colsum(gy, y, p):
 def relu_dropout_backward(gy, y, p):
     gy = same_layout(y, gy)
     gh = torch.empty_like(y)
-    with torch.cuda.device(y.device):
+    with on_device(y.device):
         code = load().mono_relu_dropout_bwd_f32(gy.data_ptr(), y.data_ptr(), gh.data_ptr(), y.numel(), float(p), raw_stream())
     if code:
         raise RuntimeError("mono_relu_dropout_bwd_f32 failed with code %d" % code)
@@ -655,7 +655,7 @@ class _MatchedLosses(torch.autograd.Function):
         out = torch.empty((NL, 6), dtype=torch.float32, device=boxes.device)
         comp = torch.empty(NL, dtype=torch.float32, device=boxes.device)
         tensors = (boxes, depth, dims, angle, idx, t_box, t_depth, t_size, t_bin, t_res)
-        with torch.cuda.device(boxes.device):
+        with on_device(boxes.device):
             code = load().mono_matched_losses_fwd_f32(*[t.data_ptr() for t in tensors], out.data_ptr(), comp.data_ptr(), NL, B, Q, K,
                                                       raw_stream())
         if code:
@@ -675,7 +675,7 @@ class _MatchedLosses(torch.autograd.Function):
         g_boxes, g_depth = flat[:n * 6].view(NL, B, Q, 6), flat[n * 6:n * 8].view(NL, B, Q, 2)
         g_dims, g_angle = flat[n * 8:n * 11].view(NL, B, Q, 3), flat[n * 11:].view(NL, B, Q, 24)
         go = go.contiguous()
-        with torch.cuda.device(boxes.device):
+        with on_device(boxes.device):
             code = load().mono_matched_losses_bwd_f32(*[t.data_ptr() for t in tensors], comp.data_ptr(), go.data_ptr(),
                                                       g_boxes.data_ptr(), g_depth.data_ptr(), g_dims.data_ptr(), g_angle.data_ptr(),
                                                       NL, B, Q, K, raw_stream())
@@ -811,7 +811,7 @@ class _FocalClassification(torch.autograd.Function):
         NL, B, Q, C = logits.shape
         K = idx.size(2)
         out = torch.empty((NL, 3), dtype=torch.float32, device=logits.device)
-        with torch.cuda.device(logits.device):
+        with on_device(logits.device):
             code = load().mono_focal_fwd_f32(logits.data_ptr(), idx.data_ptr(), labels.data_ptr(), sizes.data_ptr(), out.data_ptr(),
                                              NL, B, Q, C, K, alpha, gamma, raw_stream())
         if code:
@@ -826,7 +826,7 @@ class _FocalClassification(torch.autograd.Function):
         NL, B, Q, C = logits.shape
         g = go[:, 0].contiguous()                       # class / cardinality errors carry no gradient
         grad = torch.empty_like(logits)
-        with torch.cuda.device(logits.device):
+        with on_device(logits.device):
             code = load().mono_focal_bwd_f32(logits.data_ptr(), idx.data_ptr(), labels.data_ptr(), g.data_ptr(), grad.data_ptr(),
                                              NL, B, Q, C, idx.size(2), *ctx.consts, raw_stream())
         if code:
@@ -861,7 +861,7 @@ def match_cost_blocks(logits, boxes, labels, tboxes, cols, w_class, w_3d, w_bbox
     labels, tboxes = labels.to(torch.int64).contiguous(), tboxes.to(torch.float32).contiguous()
     cols = cols.to(torch.int64).contiguous()
     out = torch.empty((NL, B, Q, N), dtype=torch.float32, device=logits.device)
-    with torch.cuda.device(logits.device):
+    with on_device(logits.device):
         code = load().mono_match_cost_f32(logits.data_ptr(), boxes.data_ptr(), labels.data_ptr(), tboxes.data_ptr(), cols.data_ptr(),
                                           out.data_ptr(), NL, B, Q, C, N, float(w_class), float(w_3d), float(w_bbox), float(w_giou),
                                           raw_stream())
@@ -879,7 +879,7 @@ class _HeadTail(torch.autograd.Function):
         coords = torch.empty((B, Q, 6), dtype=torch.float32, device=tmp.device)
         dave = torch.empty((B, Q, 2), dtype=torch.float32, device=tmp.device)
         rp, rd = (ref.data_ptr(), ref.shape[-1]) if ref is not None else (None, 0)
-        with torch.cuda.device(tmp.device):
+        with on_device(tmp.device):
             code = load().mono_head_tail_fwd_f32(tmp.data_ptr(), size3d.data_ptr(), depth_reg.data_ptr(), wdepth.data_ptr(), fu.data_ptr(),
                                                  img_h.data_ptr(), coords.data_ptr(), dave.data_ptr(), B, Q, H, W, rp, rd, raw_stream())
         if code:
@@ -897,7 +897,7 @@ class _HeadTail(torch.autograd.Function):
         gc = g_coords.contiguous() if g_coords is not None else None
         gd = g_dave.contiguous() if g_dave is not None else None
         rp, rd = (ref.data_ptr(), ref.shape[-1]) if ref is not None else (None, 0)
-        with torch.cuda.device(tmp.device):
+        with on_device(tmp.device):
             code = load().mono_head_tail_bwd_f32(tmp.data_ptr(), size3d.data_ptr(), depth_reg.data_ptr(), wdepth.data_ptr(), fu.data_ptr(),
                                                  img_h.data_ptr(), gc.data_ptr() if gc is not None else None,
                                                  gd.data_ptr() if gd is not None else None, g_tmp.data_ptr(), g_size.data_ptr(),
@@ -931,7 +931,7 @@ def refine_reference(tmp, ref):
     tmp, ref = tmp.detach().contiguous(), ref.detach().contiguous()
     out = torch.empty_like(tmp)
     n = tmp.numel() // 6
-    with torch.cuda.device(tmp.device):
+    with on_device(tmp.device):
         code = load().mono_refine_reference_f32(tmp.data_ptr(), ref.data_ptr(), out.data_ptr(), n, ref.shape[-1], raw_stream())
     if code:
         raise RuntimeError("mono_refine_reference_f32 failed with code %d" % code)
