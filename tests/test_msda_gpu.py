@@ -796,6 +796,28 @@ def test_colsum_matches_torch(rows, C):
     assert (got.double() - ref).abs().max() <= 2e-6 * g.abs().double().sum(0).max()
 
 
+def test_sum_slices_and_channel_bias():
+    """pointwise.sum_slices (the slices of a split-K weight gradient) and conv_channel_bias (bias-free convolution + bias node
+    whose gradient is a row sum of the channels-last gradient, odd channel counts included) against plain PyTorch."""
+    from monosowa_amd.pointwise import conv_channel_bias, sum_slices
+    torch.manual_seed(8)
+    t = torch.randn(64, 256, 384, device="cuda")
+    assert (sum_slices(t) - t.double().sum(0).float()).abs().max() <= 2e-5
+    t = torch.randn(3, 5, 8, device="cuda")
+    assert (sum_slices(t) - t.sum(0)).abs().max() <= 1e-6
+    conv = torch.nn.Conv2d(32, 81, 1).cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(4, 32, 24, 80, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    go = torch.randn(4, 81, 24, 80, device="cuda").contiguous(memory_format=torch.channels_last)
+    res = []
+    for f in (lambda: conv_channel_bias(conv, x), lambda: conv(x)):
+        x.grad = conv.weight.grad = conv.bias.grad = None
+        y = f()
+        (y * go).sum().backward()
+        res.append([y.detach().clone(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()])
+    for a, b in zip(*res):
+        assert (a - b).abs().max() <= 2e-5 * max(b.abs().max().item(), 1e-3)
+
+
 # ---- fp32 attention (libmonosowa_attn.so) ------------------------------------------------------------------
 def _heads(L, B, H):
     return torch.randn(L, B, H * 32, device="cuda").view(L, B, H, 32).permute(1, 2, 0, 3)
@@ -949,6 +971,32 @@ def test_resnet_stage_with_forked_relu_backward_matches_plain_autograd():
     ref = run(plain)
     assert len(ours) == len(ref) and len(ours) > 10
     for a, b in zip(ours, ref):
+        assert (a - b).abs().max() <= 2e-5 * max(b.abs().max().item(), 1e-3)
+
+    # a stage output with THREE consumers (the next stage's first convolution, its identity branch, the pyramid projection):
+    # the last block hands out three handles, their gradients meet in mono_relu_grad_mask3_f32
+    tail = Bottleneck(128, 32).cuda().to(memory_format=torch.channels_last)
+    side = torch.nn.Conv2d(128, 16, 1).cuda().to(memory_format=torch.channels_last)
+    params3 = params + [p for p in tail.parameters() if p.requires_grad] + list(side.parameters())
+    go2 = torch.randn(2, 16, 12, 20, device="cuda").contiguous(memory_format=torch.channels_last)
+
+    def run3(three):
+        x.grad = None
+        for p in params3:
+            p.grad = None
+        blocks[-1].n_out = 3 if three else 2
+        if three:
+            h = blocks(x)
+            assert len(h) == 3
+            y, z = tail(h[:2])[0], side(h[2])
+        else:
+            h = plain(x)
+            y, z = tail(h)[0], side(h)
+        ((y * go).sum() + (z * go2).sum()).backward()
+        blocks[-1].n_out = 2
+        return [y.detach().clone(), z.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in params3]
+    ours3, ref3 = run3(True), run3(False)
+    for a, b in zip(ours3, ref3):
         assert (a - b).abs().max() <= 2e-5 * max(b.abs().max().item(), 1e-3)
 
 
