@@ -170,6 +170,7 @@ class VisualEncoder(nn.Module):
 # ----------------------------------------------------------------------------------------------
 # decoder
 # ----------------------------------------------------------------------------------------------
+BROADCAST_POS = True         # all-valid masks: one [1, S, C] positional tensor for the whole batch
 FUSED_REFINE = True          # the decoder's detached reference refinement as one launch (csrc/head_tail.hip)
 MERGE_VALUE_PROJ = True      # the decoder layers' value_proj(memory) as one GEMM
 
@@ -451,6 +452,8 @@ class DepthAwareTransformer(nn.Module):
             shapes.append((h, w))
             src_flat.append(src.flatten(2).transpose(1, 2))
             mask_flat.append(mask.flatten(1))
+            if all_valid and BROADCAST_POS:
+                pos = pos[:1]       # the sine encoding of an all-valid mask is the same for every image: [1, HW, C], broadcast by its users
             pos_flat.append(pos.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1))
         src_flat = torch.cat(src_flat, 1)
         mask_flat = torch.cat(mask_flat, 1)
