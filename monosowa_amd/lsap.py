@@ -68,7 +68,7 @@ def match_groups(cost, sizes, group_num, padded=False):
     return out
 
 
-N_THREADS = max(1, min(4, (os.cpu_count() or 1) // 2))
+N_THREADS = max(1, min(8, (os.cpu_count() or 1) // 2))      # persistent pool in the library: 0.13 ms for the 528 problems of a train step (4 threads: 0.21)
 
 
 def match_flat(cost, sizes, group_num, padded=False, n_threads=None):
