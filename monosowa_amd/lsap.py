@@ -71,7 +71,20 @@ def match_groups(cost, sizes, group_num, padded=False):
 N_THREADS = max(1, min(8, (os.cpu_count() or 1) // 2))      # persistent pool in the library: 0.13 ms for the 528 problems of a train step (4 threads: 0.21)
 
 
-def match_flat(cost, sizes, group_num, padded=False, n_threads=None):
+_pinned = {}
+
+
+def _pinned_idx(n):
+    """a reusable pinned int64 buffer of >= n elements as a numpy view (the criterion copies the indices to the device: from
+    pageable memory that copy blocks the host until everything queued before it has run; from pinned memory it is queued)"""
+    import torch
+    buf = _pinned.get("idx")
+    if buf is None or buf.numel() < n:
+        buf = _pinned["idx"] = torch.empty(max(n, 1 << 14), dtype=torch.int64).pin_memory()
+    return buf
+
+
+def match_flat(cost, sizes, group_num, padded=False, n_threads=None, pinned=False):
     """Same assignments as ``match_groups`` as one int64 array [3, NL, K]: (image, query, target index offset by the
     targets of the images before it), K pairs per layer in (image, group) order -- the index tensor of the criterion's
     flat losses; solved on ``n_threads`` host threads."""
@@ -82,9 +95,14 @@ def match_flat(cost, sizes, group_num, padded=False, n_threads=None):
     assert (int(sizes.max(initial=0)) <= T) if padded else (int(sizes.sum()) == T)
     gq = Q // group_num
     K = int(sum(group_num * min(gq, int(n)) for n in sizes))
-    idx = np.empty((3, NL, K), np.int64)
+    if pinned:                                    # -> a torch tensor view of the pinned buffer (valid until the next call)
+        holder = _pinned_idx(3 * NL * K)[:3 * NL * K].view(3, NL, K)
+        idx_ptr, idx = holder.data_ptr(), holder
+    else:
+        idx = np.empty((3, NL, K), np.int64)
+        idx_ptr = idx.ctypes.data
     got = _load().lsap_match_flat_f32(cost.ctypes.data, NL, B, Q, T, sizes.ctypes.data, group_num, int(padded),
-                                      idx.ctypes.data, N_THREADS if n_threads is None else n_threads)
+                                      idx_ptr, N_THREADS if n_threads is None else n_threads)
     if got < 0:
         raise ValueError("cost matrix is infeasible")
     assert got == K

@@ -338,9 +338,11 @@ class SetCriterion(nn.Module):
             scale_col = _dev([inv, 1.0, 1.0] + [inv] * 6, f32, dev).view(9, 1) if inv is not None else \
                 torch.cat([1.0 / nb.reshape(1), nb.new_ones(2), (1.0 / nb.reshape(1)).expand(6)]).view(9, 1)
 
-        idx_host = self.matcher.match_layers_end_flat(pending)                 # [3, NL, K] int64 (host)
+        idx_host = self.matcher.match_layers_end_flat(pending)                 # [3, NL, K] int64 (host: numpy, or a pinned tensor)
         K = idx_host.shape[2]
-        idx = torch.from_numpy(idx_host).to(dev, non_blocking=True)
+        # from the matcher's pinned buffer the copy is queued behind the depth-map kernels still running; from pageable memory
+        # the host would wait for them here, with the whole backward still to enqueue
+        idx = (idx_host if torch.is_tensor(idx_host) else torch.from_numpy(idx_host)).to(dev, non_blocking=True)
         if fused_tail and K > 0 and focal_classification_supported(logits, idx):
             # the whole criterion behind the matching in four launches: classification side + matched-pair losses, forward
             # and backward (csrc/matched_losses.hip), the loss matrix in two more

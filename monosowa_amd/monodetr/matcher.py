@@ -162,7 +162,7 @@ class HungarianMatcher(nn.Module):
             blocks, done = payload
             if done is not None:
                 done.synchronize()                                                    # the step's one host sync
-            return lsap.match_flat(blocks.numpy(), np.asarray(sizes, np.int64), group_num, padded=True)
+            return lsap.match_flat(blocks.numpy(), np.asarray(sizes, np.int64), group_num, padded=True, pinned=done is not None)
         matches = self.match_layers_end(handle)
         offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
         b_idx = np.stack([np.concatenate([np.full(len(s), b, np.int64) for b, (s, _) in enumerate(layer)]) for layer in matches])
