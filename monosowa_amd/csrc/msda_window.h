@@ -15,7 +15,10 @@
 namespace msda {
 
 constexpr int kWinLevels = 4;
-constexpr int kWinThreads = 1024;                    // forward: 16 waves, one workgroup per CU owns the LDS
+#ifndef MSDA_WIN_THREADS_FWD
+#define MSDA_WIN_THREADS_FWD 1024
+#endif
+constexpr int kWinThreads = MSDA_WIN_THREADS_FWD;    // forward: 16 waves, one workgroup per CU owns the LDS (measured: 12 waves 0.376 ms, 8 waves 0.411 ms against 0.323 with 16)
 #ifndef MSDA_WIN_THREADS_BWD
 #define MSDA_WIN_THREADS_BWD 768
 #endif
