@@ -665,6 +665,42 @@ def test_fused_operator_hands_a_gradient_to_2d_reference_points():
         assert (a - b).abs().max() <= 2e-5 * b.abs().max(), (name, ((a - b).abs().max() / b.abs().max()).item())
 
 
+def test_self_attention_shape_beyond_the_window_kernels_addressing_range():
+    """The tile-window kernels address a (batch, head) plane with 32-bit offsets: S < 2^17 tokens.  A larger pyramid at the
+    self-attention shape must take the record kernels (saved prologue reported unsupported) and still equal the unfused
+    operator."""
+    from monosowa_amd.ms_deform_attn_func import MSDeformAttnFunction, MSDeformAttnFusedMergedFunction
+    MSDA = _msda()
+    torch.manual_seed(47)
+    levels = [(256, 416), (128, 208), (64, 104), (32, 52)]            # S = 141,440 >= 2^17
+    B, M, D, L, P = 1, 2, 32, 4, 4
+    shapes = torch.tensor(levels, dtype=torch.long, device="cuda")
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    MSDA.attach_host_geometry(shapes, lsi, levels, lsi.tolist())
+    S = int(shapes.prod(1).sum())
+    assert S >= 1 << 17
+    Lq = S
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, device="cuda") + 0.5) / h, (torch.arange(w, device="cuda") + 0.5) / w,
+                                                indexing="ij")[::-1], -1).reshape(-1, 2) for h, w in levels])
+    ref = ref[None, :, None, :].expand(B, Lq, L, 2).contiguous()
+    value = torch.randn(B, S, M, D, device="cuda", requires_grad=True)
+    assert not MSDA.fused_save_supported(value, shapes, lsi, Lq, 2)
+    proj = torch.cat([torch.randn(B, Lq, M * 32, device="cuda") * 3, torch.randn(B, Lq, M * 16, device="cuda")], -1).requires_grad_(True)
+    go = torch.randn(B, Lq, M * D, device="cuda")
+    out = MSDeformAttnFusedMergedFunction.apply(value, shapes, lsi, proj, ref)
+    out.backward(go)
+    got = [out.detach().clone(), value.grad.clone(), proj.grad.clone()]
+    value.grad = proj.grad = None
+    offsets, logits = proj[:, :, :M * 32].view(B, Lq, M, L, P, 2), proj[:, :, M * 32:].reshape(B, Lq, M, L * P)
+    aw = torch.softmax(logits, -1).view(B, Lq, M, L, P)
+    norm = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+    loc = ref[:, :, None, :, None, :] + offsets / norm[None, None, None, :, None, :]
+    out_u = MSDeformAttnFunction.apply(value, shapes, lsi, loc.contiguous(), aw.contiguous(), 64)
+    out_u.backward(go)
+    for name, a, b in zip(("out", "grad_value", "grad_proj"), got, [out_u.detach(), value.grad, proj.grad]):
+        assert (a - b).abs().max() <= 2e-5 * b.abs().max(), (name, ((a - b).abs().max() / b.abs().max()).item())
+
+
 def test_train_val_cli_runs_an_epoch_and_writes_kitti_results(tmp_path):
     """tools/train_val.py (the reference's CLI): one tiny epoch on synthetic data through Trainer -> checkpoint ->
     Tester.inference -> KITTI result files, then `-e` evaluation-only from the saved checkpoint."""
