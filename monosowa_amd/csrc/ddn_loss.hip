@@ -76,6 +76,14 @@ __global__ __launch_bounds__(256) void ddn_loss_fwd_kernel(const float *__restri
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// f'(p) p of the focal term f(p) = -alpha (1 - p)^gamma log p, with the factor p folded in analytically:
+//   f'(p) p = -alpha (-gamma (1 - p)^(gamma - 1) p log p + (1 - p)^gamma)
+// -- no division by p, so a bin whose softmax probability underflows to 0 (logit gap beyond ~103) contributes a finite
+// term (p log p -> 0) like the reference's autograd through (1 - p)^gamma * log_softmax, instead of inf * 0 = NaN.
+__device__ __forceinline__ float focal_dp_times_p(const DdnParams &p, float ls, float pc, float om) {
+  return -p.alpha * (-p.gamma * powf(om, p.gamma - 1.f) * (ls * pc) + powf(om, p.gamma));
+}
+
 // grad_logits = g_scale * weight * d(pixel loss) / d logits, g_scale = grad of the total / number of pixels (device scalar)
 __global__ __launch_bounds__(256) void ddn_loss_bwd_kernel(const float *__restrict__ logits, const float *__restrict__ boxes,
                                                            const float *__restrict__ depth, const unsigned char *__restrict__ valid,
@@ -97,14 +105,12 @@ __global__ __launch_bounds__(256) void ddn_loss_bwd_kernel(const float *__restri
   float T = 0.f;
   for (int c = 0; c < p.C; ++c) {
     const float ls = z[c * p.sc] - lse, pc = expf(ls), om = 1.f - pc;
-    const float dfdp = -p.alpha * (-p.gamma * powf(om, p.gamma - 1.f) * ls + powf(om, p.gamma) / pc);
-    T += ((c == bin ? 1.f : 0.f) + p.eps) * dfdp * pc;
+    T += ((c == bin ? 1.f : 0.f) + p.eps) * focal_dp_times_p(p, ls, pc, om);
   }
   const float scale = grad_total[0] * weight / (float)n_pix;
   for (int c = 0; c < p.C; ++c) {
     const float ls = z[c * p.sc] - lse, pc = expf(ls), om = 1.f - pc;
-    const float dfdp = -p.alpha * (-p.gamma * powf(om, p.gamma - 1.f) * ls + powf(om, p.gamma) / pc);
-    const float t = ((c == bin ? 1.f : 0.f) + p.eps) * dfdp * pc;
+    const float t = ((c == bin ? 1.f : 0.f) + p.eps) * focal_dp_times_p(p, ls, pc, om);
     gz[c * p.sc] = scale * (t - pc * T);
   }
 }

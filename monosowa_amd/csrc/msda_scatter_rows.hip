@@ -233,6 +233,10 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
       ROWS_STAMP(2);
       lds_barrier();
       ROWS_STAMP(3);
+      // read BETWEEN the round's two barriers: every `overflow = 1` of this round lies before the first one, and the next
+      // write to the flag (the reset below, or the next batch's appends) lies behind the second -- read after it, a fast wave's
+      // next-batch append could reach a slow wave's read of this batch (waves disagreeing on the number of barriers)
+      again = overflow != 0;
       if (r < n_rows) {
         const int n = min((int)count[r], cap);
         const uint2 *bk = bucket + r * bstride;
@@ -253,9 +257,7 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
       ROWS_STAMP(4);
       lds_barrier();                         // orders the gather before the next appends / grad_out rows
       ROWS_STAMP(5);
-      again = overflow != 0;                 // written before the first barrier of the round: the same value for everyone
-      if (again) {
-        lds_barrier();
+      if (again) {                           // everyone has read the flag (in front of the barrier above)
         if (tid == 0) overflow = 0;
         lds_barrier();
       }

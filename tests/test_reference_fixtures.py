@@ -381,6 +381,41 @@ def test_ddn_loss_kernels_at_the_training_shape_with_extreme_logits():
 
 
 @pytest.mark.gpu
+def test_ddn_loss_gradient_stays_finite_when_a_probability_underflows():
+    """Logit gaps beyond ~103 make a bin's float32 softmax probability exactly 0 (early or diverging training).  The
+    reference differentiates (1 - p)^gamma * log_softmax through autograd and stays finite there (ddn_loss.py:64-127,
+    focalloss.py); the fused backward must not form f'(p) = ... / p: gradients equal the float64 formulation's."""
+    from monosowa_amd.monodetr import losses as L
+    gen = torch.Generator().manual_seed(11)
+    B, C, H, W, N = 2, 81, 24, 80, 6
+    logits = torch.randn(B, C, H, W, generator=gen)
+    logits[:, 7] += 140.0 * (torch.rand(B, H, W, generator=gen) < 0.3)          # p of every other bin underflows there
+    logits[:, 20] -= 125.0
+    xy = torch.rand(B, N, 2, generator=gen) * torch.tensor([W - 20.0, H - 8.0])
+    boxes = torch.cat([xy, xy + torch.tensor([18.0, 7.0])], -1)
+    depth = torch.rand(B, N, generator=gen) * 55 + 2
+    valid = torch.ones(B, N, dtype=torch.bool)
+    crit = L.DDNLoss()
+    ref = logits.double().requires_grad_(True)
+    saved = L.FUSED_DDN
+    try:
+        L.FUSED_DDN = False
+        expect = crit.forward_padded(ref, boxes.double(), depth.double(), valid)
+        expect.backward()
+    finally:
+        L.FUSED_DDN = saved
+    z = logits.cuda().requires_grad_(True)
+    assert float(torch.softmax(z.detach(), 1).min()) == 0.0, "the case must make a float32 probability underflow"
+    got = crit.forward_padded(z, boxes.cuda(), depth.cuda(), valid.cuda())
+    assert "DDNLoss" in type(got.grad_fn).__name__, "the HIP kernel did not run"
+    got.backward()
+    assert torch.isfinite(z.grad).all(), "NaN / inf in the fused DDN gradient"
+    assert abs(got.item() - expect.item()) <= 2e-5 * abs(expect.item()), (got.item(), expect.item())
+    err = (z.grad.cpu().double() - ref.grad).abs().max().item()
+    assert err <= 1e-5 * ref.grad.abs().max().item(), err
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("channels_last", [False, True])
 def test_depth_expectation_kernels_equal_the_pytorch_expression(channels_last):
     """weighted_depth = sum_c softmax(logits)_c * bin_value_c (depth_predictor.py:90-91): the HIP kernels against float64
