@@ -10,6 +10,7 @@
 #include "msda_gather_rec.hip"
 #include "msda_gather_win.hip"
 #include "msda_scatter_rows.hip"
+#include "msda_plan.hip"
 #include <map>
 #include <mutex>
 #include <cstdlib>
@@ -59,6 +60,9 @@ struct Options {
   int window_persistent = 1;   // 1 (default): one workgroup per CU walks the items, inputs prefetched a unit ahead; 0: one per item
   int scatter_rows = 1;        // 1 (default): row-tile scatter (msda_scatter_rows.hip) with the window backward when Lq == S
   int scatter_reach = 6;       // its near-point reach in pixels (farther points: global atomics in the gather kernel)
+  int directional = 1;         // 1 (default): per-head directional bounds measured on the call's own offsets (msda_plan.h) size the
+                               // scatter's scan regions (and the windows); 0: isotropic reach / halo for every head
+  int plan_reach = 8;          // capacity of the directional scan: |footprint - centre| beyond this many pixels is "far" in any case
   Options() {                                               // the environment is read ONCE, at first use
     if (const char *e = std::getenv("MSDA_GATHER")) gather = std::atoi(e);
     if (const char *e = std::getenv("MSDA_SCATTER_FIXED")) scatter_fixed = std::atoi(e) != 0;
@@ -70,6 +74,8 @@ struct Options {
     if (const char *e = std::getenv("MSDA_SCATTER_ROWS")) scatter_rows = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSDA_SCATTER_REACH")) scatter_reach = std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("MSDA_WINDOW_HALO")) window_halo = std::min(32, std::max(0, std::atoi(e)));
+    if (const char *e = std::getenv("MSDA_DIRECTIONAL")) directional = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MSDA_PLAN_REACH")) plan_reach = std::min(16, std::max(1, std::atoi(e)));
   }
 };
 inline Options &options() {
@@ -223,7 +229,8 @@ template <bool BWD, bool FUSED, bool SAVED = false>
 void launch_gather(const float *value, const float *loc, const float *attw, const float *grad_out, float *out,
                    float *grad_loc, float *grad_attw, const float *ref, int ref_dim, const int64_t *shapes_host,
                    const int64_t *lsi_host, int B, int S, int M, int Lq, hipStream_t stream, int loc_rs = 0, int aw_rs = 0,
-                   float *grad_value = nullptr, int far_reach = -1, ValueView vv = ValueView()) {
+                   float *grad_value = nullptr, int far_reach = -1, ValueView vv = ValueView(),
+                   const msda::HeadPlan *plans = nullptr) {
   if (!loc_rs) loc_rs = M * 32;
   if (!aw_rs) aw_rs = M * 16;
   const int vts = vv.token_stride ? vv.token_stride : M * 32;
@@ -249,11 +256,11 @@ void launch_gather(const float *value, const float *loc, const float *attw, cons
       if (vv.mask)
         msda::gather_win_kernel<BWD, FUSED, SAVED, true><<<grid, threads, 0, stream>>>(
             value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, wt, B, S, M, loc_rs, aw_rs, grad_value, far_reach,
-            n_virtual, vts, vv.mask, qtab);
+            n_virtual, vts, vv.mask, qtab, plans);
       else
         msda::gather_win_kernel<BWD, FUSED, SAVED, false><<<grid, threads, 0, stream>>>(
             value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, wt, B, S, M, loc_rs, aw_rs, grad_value, far_reach,
-            n_virtual, vts, nullptr, qtab);
+            n_virtual, vts, nullptr, qtab, plans);
       return;
     }
   }
@@ -399,12 +406,46 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       const long long widest = std::max<long long>(std::max(loc_rs, aw_rs), std::max(M * 32, vv.token_stride));
       if (options().scatter_rows && window_applies(true, shapes_host, lsi_host, Lq, S, widest) && (!fused_ref || fused_ref_dim == 2)) {
         msda::RowPlan rp;
-        if (msda::make_row_plan(shapes_host, lsi_host, options().scatter_reach, rp) &&
-            msda::row_plan_table_bytes(rp) <= workspace_bytes) {
-          msda::RowCandidate *table = reinterpret_cast<msda::RowCandidate *>(workspace);
+        // directional plan (msda_plan.h): fused operator with 2-d reference points, or the forward's saved locations
+        bool directional = options().directional && (saved || fused_ref) && M <= msda::kPlanMaxHeads;
+        int reach = 0;
+        size_t plan_b = 0, stats_b = 0;
+        bool ok = false;
+        for (int attempt = 0; attempt < 2 && !ok; ++attempt) {        // a workspace too small for the per-head tables: isotropic plan
+          reach = directional ? std::max(options().scatter_reach, options().plan_reach) : options().scatter_reach;
+          plan_b = directional ? align256(msda::plan_bytes(M)) : 0;
+          stats_b = directional ? align256(msda::plan_stats_bytes(M) * msda::kStatsBlocks) : 0;
+          ok = msda::make_row_plan(shapes_host, lsi_host, reach, rp) &&
+               plan_b + stats_b + msda::row_plan_table_bytes(rp) * (directional ? M : 1) <= workspace_bytes;
+          if (!ok) { if (!directional) break; directional = false; }
+        }
+        if (ok) {
+          char *wsp = reinterpret_cast<char *>(workspace);
+          msda::HeadPlan *plans = directional ? reinterpret_cast<msda::HeadPlan *>(wsp) : nullptr;
+          msda::RowCandidate *table = reinterpret_cast<msda::RowCandidate *>(wsp + plan_b + stats_b);
           int n_tiles = 0;
           for (int l = 0; l < 4; ++l) n_tiles += rp.n_ty[l] * rp.n_tx[l];
-          msda::row_candidates_kernel<<<n_tiles, 256, 0, stream>>>(rp, table);
+          if (directional) {
+            msda::DirStats *partial = reinterpret_cast<msda::DirStats *>(wsp + plan_b);
+            msda::PlanGeom pg{};
+            msda::WinGeom wg;
+            window_tiling(shapes_host, lsi_host, options().window_halo, true, wg);      // (window_applies() above: it exists)
+            for (int l = 0; l < 4; ++l) { pg.H[l] = rp.H[l]; pg.W[l] = rp.W[l]; pg.start[l] = rp.start[l]; }
+            pg.S = S; pg.M = M;
+            pg.win_n_ty = wg.n_ty; pg.win_n_tx = wg.n_tx;
+            pg.win_budget_rows = msda::kWinMaxRowsBwd;
+            pg.win_max_queries = msda::kWinMaxQueries;
+            pg.default_halo = options().window_halo;
+            pg.reach = reach;
+            pg.want_rows = 1;
+            if (saved)
+              msda::dir_stats_kernel<1><<<msda::kStatsBlocks, msda::kStatsThreads, 0, stream>>>(loc, nullptr, pg, B, 0, partial);
+            else
+              msda::dir_stats_kernel<0><<<msda::kStatsBlocks, msda::kStatsThreads, 0, stream>>>(
+                  loc, fused_ref, pg, B, loc_rs ? loc_rs : M * 32, partial);
+            msda::dir_plan_kernel<<<M, 256, 0, stream>>>(partial, msda::kStatsBlocks, pg, rp, plans);
+          }
+          msda::row_candidates_kernel<<<n_tiles * (directional ? M : 1), 256, 0, stream>>>(rp, table, plans, n_tiles);
           for (int l = 0; l < L; ++l) {          // levels shared by several workgroups are accumulated with atomics
             if (rp.n_chunks[l] == 1) continue;
             hipError_t e = hipMemset2DAsync(grad_value + (size_t)rp.start[l] * M * 32, sizeof(float) * (size_t)S * M * 32, 0,
@@ -415,19 +456,19 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
           const int lrs = loc_rs ? loc_rs : M * 32, ars = aw_rs ? aw_rs : M * 16;
           if (fused_ref && !saved)
             msda::scatter_rows_kernel<true><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
-                loc, attw, grad_out, grad_value, fused_ref, fused_ref_dim, table, rp, B, S, M, lrs, ars, vv.mask);
+                loc, attw, grad_out, grad_value, fused_ref, fused_ref_dim, table, rp, B, S, M, lrs, ars, vv.mask, plans);
           else if (saved)
             msda::scatter_rows_kernel<false, true><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
-                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, 0, 0, vv.mask);
+                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, 0, 0, vv.mask, plans);
           else
             msda::scatter_rows_kernel<false><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
                 loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, lrs, ars);
           if (fused_ref && saved)
             launch_gather<true, true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
-                                            shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, rp.reach, vv);
+                                            shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, rp.reach, vv, plans);
           else if (fused_ref)
             launch_gather<true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
-                                      shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, rp.reach, vv);
+                                      shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, rp.reach, vv, plans);
           else
             launch_gather<true, false>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, nullptr, 0, shapes_host,
                                        lsi_host, B, S, M, Lq, stream, 0, 0, grad_value, rp.reach);
@@ -509,6 +550,8 @@ int msda_set_option(const char *name, int value) {
   if (n == "window_persistent" && (value == 0 || value == 1)) { options().window_persistent = value; return 0; }
   if (n == "scatter_rows" && (value == 0 || value == 1)) { options().scatter_rows = value; return 0; }
   if (n == "scatter_reach" && value >= 1 && value <= 16) { options().scatter_reach = value; return 0; }
+  if (n == "directional" && (value == 0 || value == 1)) { options().directional = value; return 0; }
+  if (n == "plan_reach" && value >= 1 && value <= 16) { options().plan_reach = value; return 0; }
   return MSDA_E_UNSUPPORTED;
 }
 

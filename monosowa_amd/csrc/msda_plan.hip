@@ -1,0 +1,304 @@
+// Directional launch plan of the self-attention kernels: sampling statistics -> per-head tables (msda_plan.h).
+#include "msda_common.h"
+#include "msda_plan.h"
+
+namespace msda {
+
+constexpr int kStatsBlocks = 64;         // workgroups of dir_stats_kernel = partial statistics per (head, level)
+constexpr int kStatsThreads = 256;
+
+__device__ __forceinline__ int plan_floor_div_dev(int a, int b) {        // b > 0
+  const int q = a / b, r = a - q * b;
+  return r < 0 ? q - 1 : q;
+}
+
+// ---- 1. statistics of d = (h_low - cf_y, w_low - cf_x) over a sample of the call's points ---------------------------------------
+// MODE 0: `loc` = raw sampling offsets [B, Lq, .] with row stride loc_rs (the fused operator's input), `ref` = 2-d reference
+//         points [B, Lq, 4, 2]; locations are evaluated exactly like the kernels do (msda_common.h: loc_from_offset).
+// MODE 1: `loc` = the forward's saved sampling locations, level-major [B, M, L, Lq, P, 2].
+// Every workgroup leaves ONE partial record per (head, level) in partial[blockIdx.x][M][4] (plain stores: no zero fill, no
+// same-address atomics -- 1000 workgroups adding into 32 records would serialise in L2).
+template <int MODE>
+__global__ __launch_bounds__(kStatsThreads) void dir_stats_kernel(const float *__restrict__ loc, const float *__restrict__ ref,
+                                                                  const PlanGeom g, int B, int loc_rs,
+                                                                  DirStats *__restrict__ partial) {
+  __shared__ int sh[kPlanMaxHeads * 4][10];       // n, up_y, dn_y, up_x, dn_x, sum_y, sum_x, sq_y, sq_x, -
+  const int M = g.M, S = g.S;
+  for (int i = threadIdx.x; i < M * 4 * 10; i += kStatsThreads) (&sh[0][0])[i] = 0;
+  __syncthreads();
+  const int ns = min(kPlanSamples, S);
+  const long long total = (long long)B * ns * M * 4;
+  for (long long t = (long long)blockIdx.x * kStatsThreads + threadIdx.x; t < total; t += (long long)gridDim.x * kStatsThreads) {
+    const int l = (int)(t & 3);
+    const long long u = t >> 2;
+    const int m = (int)(u % M);
+    const long long v = u / M;
+    const int i = (int)(v % ns), b = (int)(v / ns);
+    // a pseudo-random token of this batch element (a regular stride would alias with the image columns)
+    const unsigned q = (unsigned)((((unsigned long long)((unsigned)(i + b * ns) * 2654435761u)) * (unsigned long long)S) >> 32);
+    int lq = 0;
+    while (lq < 3 && (int)q >= g.start[lq + 1]) ++lq;
+    const int rel = (int)q - g.start[lq], yq = rel / g.W[lq], xq = rel - yq * g.W[lq];
+    const int H = g.H[l], W = g.W[l];
+    const int cy = centre_floor(yq, g.H[lq], H), cx = centre_floor(xq, g.W[lq], W);
+    float xy[8];
+    if (MODE == 0) {
+      const float *op = loc + ((long long)b * S + q) * loc_rs + (m * 4 + l) * 8;
+      const float4 a = ld4(op), c = ld4(op + 4);
+      const float2 r = *reinterpret_cast<const float2 *>(ref + (((long long)b * S + q) * 4 + l) * 2);
+      const float o[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        xy[2 * k] = add_rn(r.x, __fdiv_rn(o[2 * k], (float)W));
+        xy[2 * k + 1] = add_rn(r.y, __fdiv_rn(o[2 * k + 1], (float)H));
+      }
+    } else {
+      const float *lp = loc + ((((long long)(b * M + m) * 4 + l) * S + q) * 4) * 2;
+      const float4 a = ld4(lp), c = ld4(lp + 4);
+      xy[0] = a.x; xy[1] = a.y; xy[2] = a.z; xy[3] = a.w; xy[4] = c.x; xy[5] = c.y; xy[6] = c.z; xy[7] = c.w;
+    }
+    int n = 0, up_y = 0, dn_y = 0, up_x = 0, dn_x = 0, sy = 0, sx = 0, qy = 0, qx = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const Tap<float> tp = make_tap<float>(xy[2 * k], xy[2 * k + 1], H, W);
+      if (!tp.valid) continue;
+      const int dy = max(-kPlanClip, min(kPlanClip, tp.h_low - cy)), dx = max(-kPlanClip, min(kPlanClip, tp.w_low - cx));
+      ++n;
+      up_y = max(up_y, dy + kPlanClip); dn_y = max(dn_y, kPlanClip - dy);
+      up_x = max(up_x, dx + kPlanClip); dn_x = max(dn_x, kPlanClip - dx);
+      sy += dy; sx += dx; qy += dy * dy; qx += dx * dx;
+    }
+    if (n) {
+      int *rec = sh[m * 4 + l];
+      atomicAdd(&rec[0], n);
+      atomicMax(&rec[1], up_y); atomicMax(&rec[2], dn_y); atomicMax(&rec[3], up_x); atomicMax(&rec[4], dn_x);
+      atomicAdd(&rec[5], sy); atomicAdd(&rec[6], sx); atomicAdd(&rec[7], qy); atomicAdd(&rec[8], qx);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < M * 4; i += kStatsThreads) {
+    DirStats s;
+    s.n = sh[i][0]; s.up_y = sh[i][1]; s.dn_y = sh[i][2]; s.up_x = sh[i][3]; s.dn_x = sh[i][4];
+    s.sum_y = sh[i][5]; s.sum_x = sh[i][6]; s.pad = 0;
+    s.sq_y = (unsigned long long)(unsigned)sh[i][7]; s.sq_x = (unsigned long long)(unsigned)sh[i][8];
+    partial[(long long)blockIdx.x * M * 4 + i] = s;
+  }
+}
+
+// ---- 2. per-head tables ----------------------------------------------------------------------------------------------------------
+// window extent of one axis tile at sampled level lv for bounds [dlo, dhi] of the footprint's top-left pixel
+__device__ __forceinline__ AxisSpec axis_spec_dir(const int *N, int n_t, int t0, int t1, int lv, int dlo, int dhi) {
+  // queries of tiles [t0, t1) of n_t along this axis
+  AxisSpec a;
+  a.q0 = (short)(t0 * N[lv] / n_t);
+  a.qn = (short)(t1 * N[lv] / n_t - a.q0);
+  int lo = 1 << 30, hi = -(1 << 30);
+#pragma unroll
+  for (int l = 0; l < kWinLevels; ++l) {
+    const int q0 = t0 * N[l] / n_t, q1 = t1 * N[l] / n_t;
+    if (q1 <= q0) continue;
+    lo = min(lo, plan_floor_div_dev((2 * q0 + 1) * N[lv] - N[l], 2 * N[l]));
+    hi = max(hi, plan_floor_div_dev((2 * (q1 - 1) + 1) * N[lv] - N[l], 2 * N[l]));
+  }
+  a.w0 = 0; a.wn = 0;
+  if (hi < lo) return a;
+  const int w0 = max(0, lo + dlo), w1 = min(N[lv] - 1, hi + dhi + 1);        // the footprint spans h_low, h_low + 1
+  if (w1 < w0) return a;
+  a.w0 = (short)w0;
+  a.wn = (short)(w1 - w0 + 1);
+  return a;
+}
+
+// run of query pixels c in [0, Nq) whose centre floor (in pixels of the extent-N level) lies in [lo, hi]
+__device__ __forceinline__ void scan_run_dev(int Nq, int N, int lo, int hi, short &q0, short &qn) {
+  // centre floor(c) = floor(((2 c + 1) N - Nq) / (2 Nq)) is monotone in c:
+  //   >= lo  <=>  (2 c + 1) N >= Nq (2 lo + 1)      <= hi  <=>  (2 c + 1) N < Nq (2 hi + 3)
+  int first = plan_floor_div_dev(Nq * (2 * lo + 1) - N + 2 * N - 1, 2 * N);           // ceil((Nq (2 lo + 1) - N) / (2 N))
+  int last = plan_floor_div_dev(Nq * (2 * hi + 3) - N + 2 * N - 1, 2 * N) - 1;
+  first = max(first, 0);
+  last = min(last, Nq - 1);
+  q0 = (short)(last < first ? 0 : first);
+  qn = (short)(last < first ? 0 : last - first + 1);
+}
+
+__global__ __launch_bounds__(256) void dir_plan_kernel(const DirStats *__restrict__ partial, int n_partial, const PlanGeom g,
+                                                       const RowPlan rp, HeadPlan *__restrict__ plans) {
+  const int m = blockIdx.x, tid = threadIdx.x;
+  __shared__ DirBounds s_win[4], s_near[4];
+  __shared__ float s_mean[4][2];
+  __shared__ AxisSpec s_wax[kWinMaxAxisTiles][kWinLevels];
+  __shared__ RowAxis s_rax[kRowMaxAxisTiles];
+  __shared__ int s_rows_max, s_cand_max[4], s_q_max;
+  HeadPlan &hp = plans[m];
+
+  // ---- A. bounds: [min, max] of the sample, cut at mean +- 4 sigma (one stray point must not size every window) ----------------
+  if (tid < 4) {
+    const int l = tid;
+    long long n = 0, sy = 0, sx = 0;
+    unsigned long long qy = 0, qx = 0;
+    int up_y = 0, dn_y = 0, up_x = 0, dn_x = 0;
+    for (int i = 0; i < n_partial; ++i) {
+      const DirStats s = partial[((long long)i * g.M + m) * 4 + l];
+      n += s.n; sy += s.sum_y; sx += s.sum_x; qy += s.sq_y; qx += s.sq_x;
+      up_y = max(up_y, s.up_y); dn_y = max(dn_y, s.dn_y); up_x = max(up_x, s.up_x); dn_x = max(dn_x, s.dn_x);
+    }
+    DirBounds b;
+    float my = 0.f, mx = 0.f;
+    if (n == 0) {
+      b.ylo = b.xlo = (short)-g.default_halo;
+      b.yhi = b.xhi = (short)(g.default_halo - 1);
+    } else {
+      my = (float)sy / (float)n; mx = (float)sx / (float)n;
+      const float vy = fmaxf((float)qy / (float)n - my * my, 0.f), vx = fmaxf((float)qx / (float)n - mx * mx, 0.f);
+      const float dy = 4.f * sqrtf(vy) + 0.5f, dx = 4.f * sqrtf(vx) + 0.5f;
+      b.ylo = (short)max(kPlanClip - dn_y, (int)floorf(my - dy)); b.yhi = (short)min(up_y - kPlanClip, (int)ceilf(my + dy));
+      b.xlo = (short)max(kPlanClip - dn_x, (int)floorf(mx - dx)); b.xhi = (short)min(up_x - kPlanClip, (int)ceilf(mx + dx));
+    }
+    s_mean[l][0] = my; s_mean[l][1] = mx;
+    DirBounds nb;                         // scatter: the candidate tables hold |d| <= reach (both ends clamped into that range)
+    const int R = g.reach;
+    nb.ylo = (short)min(max((int)b.ylo, -R), R); nb.yhi = (short)max(min((int)b.yhi, R), -R);
+    nb.xlo = (short)min(max((int)b.xlo, -R), R); nb.xhi = (short)max(min((int)b.xhi, R), -R);
+    s_near[l] = nb;
+    // windows: no extent beyond 32 pixels around the mean enters the fit below (nothing that wide fits the LDS budget)
+    const int cy = (int)floorf(my), cx = (int)floorf(mx);
+    b.ylo = (short)max((int)b.ylo, cy - 16); b.yhi = (short)min((int)b.yhi, cy + 16);
+    b.xlo = (short)max((int)b.xlo, cx - 16); b.xhi = (short)min((int)b.xhi, cx + 16);
+    if (b.yhi < b.ylo) b.yhi = b.ylo;
+    if (b.xhi < b.xlo) b.xhi = b.xlo;
+    s_win[l] = b;
+  }
+  __syncthreads();
+
+  // ---- B. windows: fit the LDS budget (shrink the longest extent towards the mean until every tile fits) ---------------------------
+  const int n_ty = g.win_n_ty, n_tx = g.win_n_tx, n_ax = n_ty + n_tx;
+  // (the last trip, reached only when 80 cuts did not fit the windows, takes the isotropic default the host's tiling was
+  // chosen for: the gather kernels trust this table with their LDS addressing)
+  for (int iter = 0; iter <= 80; ++iter) {
+    if (tid == 0) s_rows_max = 0;
+    if (iter == 80 && tid < 4) {
+      s_win[tid].ylo = s_win[tid].xlo = (short)-g.default_halo;
+      s_win[tid].yhi = s_win[tid].xhi = (short)(g.default_halo - 1);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n_ax * 4; idx += 256) {
+      const int t = idx >> 2, lv = idx & 3;
+      const DirBounds b = s_win[lv];
+      s_wax[t][lv] = t < n_ty ? axis_spec_dir(g.H, n_ty, t, t + 1, lv, b.ylo, b.yhi) : axis_spec_dir(g.W, n_tx, t - n_ty, t - n_ty + 1, lv, b.xlo, b.xhi);
+    }
+    __syncthreads();
+    for (int tile = tid; tile < n_ty * n_tx; tile += 256) {
+      const int ty = tile / n_tx, tx = tile - ty * n_tx;
+      int rows = 0;
+#pragma unroll
+      for (int lv = 0; lv < 4; ++lv) rows += ((int)s_wax[ty][lv].wn * (int)s_wax[n_ty + tx][lv].wn + 7) & ~7;
+      atomicMax(&s_rows_max, rows);
+    }
+    __syncthreads();
+    if (s_rows_max <= g.win_budget_rows) break;
+    if (tid == 0) {
+      // the longest extent over levels and axes loses a quarter (at least one pixel) on the side farther from the mean
+      int bl = 0, ba = 0, be = -1;
+      for (int lv = 0; lv < 4; ++lv) {
+        const int ey = s_win[lv].yhi - s_win[lv].ylo, ex = s_win[lv].xhi - s_win[lv].xlo;
+        if (ey > be) { be = ey; bl = lv; ba = 0; }
+        if (ex > be) { be = ex; bl = lv; ba = 1; }
+      }
+      if (be > 0) {
+        const int cut = max(1, be / 4);
+        short &lo = ba ? s_win[bl].xlo : s_win[bl].ylo, &hi = ba ? s_win[bl].xhi : s_win[bl].yhi;
+        for (int c = 0; c < cut && hi > lo; ++c) {
+          if ((float)hi - s_mean[bl][ba] >= s_mean[bl][ba] - (float)lo) --hi; else ++lo;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (s_rows_max > g.win_budget_rows) {            // cannot happen with a tiling the host chose for default_halo; never overrun the LDS
+    for (int idx = tid; idx < n_ax * 4; idx += 256) s_wax[idx >> 2][idx & 3].wn = 0;
+    __syncthreads();
+  }
+  // merged column pairs: every pair's windows and queries must fit
+  if (tid == 0) { s_rows_max = 0; s_q_max = 0; }
+  __syncthreads();
+  const int n_px = n_tx / 2;
+  for (int idx = tid; idx < n_px * 4; idx += 256) {
+    const int t = idx >> 2, lv = idx & 3;
+    hp.wax2[t][lv] = axis_spec_dir(g.W, n_tx, 2 * t, 2 * t + 2, lv, s_win[lv].xlo, s_win[lv].xhi);
+  }
+  for (int tile = tid; tile < n_ty * n_px; tile += 256) {
+    const int ty = tile / n_px, tp = tile - ty * n_px;
+    int rows = 0, queries = 0;
+#pragma unroll
+    for (int lv = 0; lv < 4; ++lv) {
+      const AxisSpec a2 = axis_spec_dir(g.W, n_tx, 2 * tp, 2 * tp + 2, lv, s_win[lv].xlo, s_win[lv].xhi);
+      rows += ((int)s_wax[ty][lv].wn * (int)a2.wn + 7) & ~7;
+      queries += (int)s_wax[ty][lv].qn * (int)a2.qn;
+    }
+    atomicMax(&s_rows_max, rows);
+    atomicMax(&s_q_max, queries);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < n_ax * 4; idx += 256) hp.wax[idx >> 2][idx & 3] = s_wax[idx >> 2][idx & 3];
+  if (tid < 4) { hp.win[tid] = s_win[tid]; hp.near[tid] = s_near[tid]; }
+  if (tid == 0) {
+    hp.merged = (n_px > 0 && s_rows_max <= g.win_budget_rows && s_q_max <= g.win_max_queries) ? 1 : 0;
+    hp.win_rows_max = s_rows_max;
+  }
+  if (!g.want_rows) return;
+
+  // ---- C. row-tile scatter: per (level, axis tile) the runs of query pixels whose points can reach it ---------------------------
+  int n_axis_total = 0;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) n_axis_total += rp.n_ty[l] + rp.n_tx[l];
+  for (int a = tid; a < n_axis_total; a += 256) {
+    int l = 0;
+    while (l < 3 && a >= rp.axis0[l + 1]) ++l;
+    const bool is_y = a - rp.axis0[l] < rp.n_ty[l];
+    RowAxis ra = rp.ax[a];                       // r0 / rn: the static tiling
+    const DirBounds b = s_near[l];
+    // a point with top-left pixel t = cf + d touches pixels t, t + 1: it reaches [r0, r0 + rn) iff t in [r0 - 1, r0 + rn - 1]
+    const int dlo = is_y ? b.ylo : b.xlo, dhi = is_y ? b.yhi : b.xhi;
+    const int lo = ra.r0 - 1 - dhi, hi = ra.r0 + ra.rn - 1 - dlo;
+#pragma unroll
+    for (int lq = 0; lq < 4; ++lq) scan_run_dev(is_y ? rp.H[lq] : rp.W[lq], is_y ? rp.H[l] : rp.W[l], lo, hi, ra.q0[lq], ra.qn[lq]);
+    s_rax[a] = ra;
+    hp.rax[a] = ra;
+  }
+  if (tid < 4) s_cand_max[tid] = 0;
+  __syncthreads();
+  int n_tiles_total = 0;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) n_tiles_total += rp.n_ty[l] * rp.n_tx[l];
+  for (int t = tid; t < n_tiles_total; t += 256) {
+    int l = 0, tl = t;
+    while (l < 3 && tl >= rp.n_ty[l] * rp.n_tx[l]) { tl -= rp.n_ty[l] * rp.n_tx[l]; ++l; }
+    const int ty = tl / rp.n_tx[l], tx = tl - ty * rp.n_tx[l];
+    const RowAxis ay = s_rax[rp.axis0[l] + ty], ax = s_rax[rp.axis0[l] + rp.n_ty[l] + tx];
+    int c = 0;
+#pragma unroll
+    for (int lq = 0; lq < 4; ++lq) c += (int)ay.qn[lq] * (int)ax.qn[lq];
+    atomicMax(&s_cand_max[l], c);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float work[4];
+    for (int l = 0; l < 4; ++l) {
+      const int nc = max(1, min(rp.n_chunks[l], (s_cand_max[l] + kRowChunkQueries - 1) / kRowChunkQueries));
+      hp.n_chunks[l] = nc;
+      work[l] = (float)s_cand_max[l] / (float)nc;
+      hp.order[l] = l;
+    }
+    for (int i = 0; i < 4; ++i)                    // levels by work per item, heaviest first
+      for (int j = i + 1; j < 4; ++j)
+        if (work[hp.order[j]] > work[hp.order[i]]) { const int t = hp.order[i]; hp.order[i] = hp.order[j]; hp.order[j] = t; }
+    hp.first_item[0] = 0;
+    for (int i = 0; i < 4; ++i) {
+      const int l = hp.order[i];
+      hp.first_item[i + 1] = hp.first_item[i] + rp.n_ty[l] * rp.n_tx[l] * hp.n_chunks[l];
+    }
+    hp.n_items = hp.first_item[4];
+  }
+}
+
+}  // namespace msda

@@ -13,7 +13,9 @@
 
 namespace msda {
 
-constexpr int kRowTileRows = 256;          // value rows per tile: 512 threads = 256 rows x 2 lanes (16 channels each)
+constexpr int kRowTileRows = 128;          // bilinear cells per tile: 512 threads = 128 cells x 4 lanes (8 channels x 4 corner sums each);
+                                           // a tile of th x tw output rows has (th + 1) x (tw + 1) cells
+constexpr int kRowCellCap = 32;            // points one cell's bucket holds per batch and round
 constexpr int kRowThreads = 512;
 #ifndef MSDA_ROW_SUB
 #define MSDA_ROW_SUB 2
@@ -21,7 +23,6 @@ constexpr int kRowThreads = 512;
 constexpr int kRowSub = MSDA_ROW_SUB;                 // candidate points per thread and batch
 constexpr int kRowBatchQueries = kRowThreads / 4 * kRowSub;   // candidates x the level's 4 points per batch
 constexpr int kRowMaxAxisTiles = 96;       // sum over levels of (n_ty + n_tx)
-constexpr int kRowBucketEntries = kRowSub == 1 ? 4096 : 5632;    // hit records per batch (32 / 44 KB), shared equally by the tile's rows
 constexpr int kRowChunkQueries = 3584;     // candidates per workgroup (14 batches); longer scan lists are split
 
 struct RowAxis {
@@ -74,9 +75,20 @@ inline bool make_row_plan(const int64_t *shapes_host, const int64_t *lsi_host, i
   }
   for (int l = 0; l < 4; ++l) {
     const int H = p.H[l], W = p.W[l];
-    // tiles of <= kRowTileRows rows, wide rather than tall (rows of a level are contiguous along x)
-    int tw = std::min(W, 16), th = std::min(H, kRowTileRows / tw);
-    if (H * W <= kRowTileRows) { th = H; tw = W; }
+    // tiles whose cells -- (th + 1) x (tw + 1): one apron row above, one apron column to the left -- fit kRowTileRows: the
+    // split that scans the fewest candidates, i.e. minimises the summed area of the tiles grown by a typical scan margin
+    int tw = W, th = H;
+    if ((H + 1) * (W + 1) > kRowTileRows) {
+      const int mg = 8;
+      long long best = -1;
+      for (int nty = 1; nty <= H; ++nty) {
+        const int h = (H + nty - 1) / nty, w_max = kRowTileRows / (h + 1) - 1;
+        if (w_max < 1) continue;
+        const int ntx = (W + w_max - 1) / w_max, w = (W + ntx - 1) / ntx;
+        const long long cost = (long long)nty * ntx * (h + mg) * (w + mg);
+        if (best < 0 || cost < best) { best = cost; th = h; tw = w; }
+      }
+    }
     p.n_tx[l] = (W + tw - 1) / tw; p.tw[l] = (W + p.n_tx[l] - 1) / p.n_tx[l];
     p.n_ty[l] = (H + th - 1) / th; p.th[l] = (H + p.n_ty[l] - 1) / p.n_ty[l];
     p.axis0[l] = n_axis;

@@ -1,23 +1,27 @@
-// grad_value of the self-attention shape (Lq == S), d32 path: exclusive ROW TILES accumulated in registers.
-// Plan and geometry: msda_scatter_plan.h.
+// grad_value of the self-attention shape (Lq == S), d32 path: exclusive tiles of bilinear CELLS accumulated in registers.
+// Plan and geometry: msda_scatter_plan.h (static tiling), msda_plan.h (per-head directional scan runs).
 //
-// The tile-owner generation (msda_backward_tiled.hip) is bound by LDS atomics: one ds_add_u64 per (point, corner, channel)
-// = 2.7 G of them per launch at B = 16, behind a transposing pre-pass (K1: 0.8 GB of traffic) and with grad_out rows
-// fetched per hit from L2.  Here a workgroup owns <= 256 value rows of one level of one (batch, head); each row belongs to 2
-// lanes (16 channels = four float4 accumulators each).  The points that can reach the tile come from a per-tile scan list of
-// candidate queries (the queries whose pixel centre lies within reach + 1 pixels of the tile; built once per call by
-// row_candidates_kernel and shared by all batch x head planes).  Per batch of 128 candidates:
-//   1. thread = (candidate, one of the level's 4 points): loads the point straight from loc / attn_w (fused: offsets /
-//      logits / reference points -- no transposed copy), resolves its tap; the batch's grad_out rows go to LDS (16 KB);
-//   2. every corner that lands in the tile takes a slot in its ROW's bucket (one ds_add_rtn_u32 per corner -- 1/32 of the
-//      atomics of the per-channel scheme) and leaves {weight, candidate};
-//   3. the row's 2 lanes walk the bucket: 4 x ds_read_b128 of grad_out + 16 FMAs per hit, sums stay in registers.
-// The inputs of a batch are fetched one batch ahead (candidate entries two ahead).
+// A sampling point adds w_corner * attn_w * grad_out[q, m, :] to the four value rows of its bilinear footprint (cuh:125-152).
+// Round 2 made every footprint CORNER a "hit" in its value row's bucket and let the row's lanes sum their hits: per corner one
+// LDS slot reservation, one record, 128 bytes of grad_out re-read from LDS -- counters: LDS 47 % busy (44 % of it bank
+// conflicts), waves parked 56 % of the time; the cost follows the 83.6 M corner hits of a launch, not the candidates scanned.
+// Here the unit is the POINT: a workgroup owns a tile of output rows [y0, y0 + th) x [x0, x0 + tw) of one level of one
+// (batch, head) and accumulates, per CELL (the top-left pixel of a footprint; cells [y0 - 1, y0 + th) x [x0 - 1, x0 + tw)),
+// the four corner-weighted sums  S00, S01, S10, S11 = sum over the cell's points of w_corner * attn_w * grad_out  in registers
+// (4 lanes per cell x 8 channels x 4 sums = 32 accumulator registers; 2 lanes x 16 channels would need 64 and spilled the scan).  One reservation, one 2-byte record and ONE read of the grad_out row per point;
+// at the end  grad_value[y, x] = S00[y, x] + S01[y, x - 1] + S10[y - 1, x] + S11[y - 1, x - 1]  (three shifted adds through
+// LDS, once per workgroup).  Cells on the tile's top / left apron are accumulated by two neighbouring tiles each (the
+// candidate scan already covers them: a point reaches a tile's outputs iff its cell lies in the tile's cell range).
+// Per batch of 256 candidates (the queries around the tile, msda_plan.h):
+//   1. thread = (candidate, one of the level's 4 points): resolves its tap, leaves the four corner coefficients in a per-batch
+//      table and -- when the cell is the tile's -- the point's index in the cell's bucket; the batch's grad_out rows go to LDS;
+//   2. the cell's 4 lanes walk the bucket: per point 1 + 1 + 2 LDS reads and 16 packed FMAs per lane.
 // Single-workgroup tiles are written with plain 128-byte rows (no zero fill, no global atomics); levels whose scan lists
 // are split over workgroups add full rows atomically into a zeroed region.
-// Only NEAR points are scanned (near_point(), msda_common.h); the rest is added by the gather kernel (msda_gather_win.hip).
+// Only NEAR points are scanned (inside the head's bounds, msda_plan.h); the rest is added by the gather kernel.
 #include "msda_common.h"
 #include "msda_scatter_plan.h"
+#include "msda_plan.h"
 
 #ifndef MSDA_ROWS_STAMP
 #define MSDA_ROWS_STAMP 0        // measurement builds only: per-phase shader-clock totals (tools/debug/win_stamps.py)
@@ -40,13 +44,16 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// scan lists: one workgroup per (level, tile)
-__global__ __launch_bounds__(256) void row_candidates_kernel(const RowPlan p, RowCandidate *__restrict__ table) {
-  int l = 0, t = blockIdx.x;
+// scan lists: one workgroup per (level, tile) -- and per head when the directional plan (msda_plan.h) supplies the runs
+__global__ __launch_bounds__(256) void row_candidates_kernel(const RowPlan p, RowCandidate *__restrict__ table,
+                                                             const HeadPlan *__restrict__ plans, int n_tiles) {
+  const int head = blockIdx.x / n_tiles;                   // 0 without a directional plan (one table for all heads)
+  int l = 0, t = blockIdx.x - head * n_tiles;
   while (l < 3 && t >= p.n_ty[l] * p.n_tx[l]) { t -= p.n_ty[l] * p.n_tx[l]; ++l; }
   const int ty = t / p.n_tx[l], tx = t - ty * p.n_tx[l];
-  const RowAxis ay = p.ax[p.axis0[l] + ty], ax = p.ax[p.axis0[l] + p.n_ty[l] + tx];
-  RowCandidate *out = table + p.cand_base[l] + (long long)t * p.cand_stride[l];
+  const RowAxis *axes = plans ? plans[head].rax : p.ax;
+  const RowAxis ay = axes[p.axis0[l] + ty], ax = axes[p.axis0[l] + p.n_ty[l] + tx];
+  RowCandidate *out = table + (long long)head * p.cand_total + p.cand_base[l] + (long long)t * p.cand_stride[l];
   int first = 0;
   for (int lq = 0; lq < 4; ++lq) {
     const int n = (int)ay.qn[lq] * (int)ax.qn[lq], w = ax.qn[lq];
@@ -66,13 +73,17 @@ __global__ __launch_bounds__(256) void row_candidates_kernel(const RowPlan p, Ro
 // FUSED: `loc` / `attw` carry raw sampling offsets / attention logits, `ref` the reference points [B, Lq, 4, ref_dim].
 // LEVEL_MAJOR (not FUSED): `loc` / `attw` are the fused forward's saved tensors, [B, M, L, Lq, P(, 2)].
 template <bool FUSED, bool LEVEL_MAJOR = false>
-__global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_rows_kernel(
+__global__ __launch_bounds__(kRowThreads, 4) void scatter_rows_kernel(
     const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out,
     float *__restrict__ grad_value, const float *__restrict__ ref, int ref_dim, const RowCandidate *__restrict__ table,
-    const RowPlan p, int B, int S, int M, int loc_rs, int aw_rs, const unsigned char *__restrict__ vmask = nullptr) {
+    const RowPlan p, int B, int S, int M, int loc_rs, int aw_rs, const unsigned char *__restrict__ vmask = nullptr,
+    const HeadPlan *__restrict__ plans = nullptr) {
+  // plans (optional): the directional plan (msda_plan.h) -- per head the scan runs, chunking and near-bounds; `p` then only
+  // supplies the static tiling and the table capacities (the grid is sized for its isotropic worst case: surplus items exit)
   // vmask [B, S] (optional): padded value tokens -- their grad_value rows come out as zero (ms_deform_attn.py:139-140)
-  __shared__ float4 go_lds[kRowBatchQueries * 8];          // grad_out rows of the batch's candidates (this head), 16 KB
-  __shared__ uint2 bucket[kRowBucketEntries];              // per row: {weight bits, candidate slot}, 32 KB
+  __shared__ float4 go_lds[kRowBatchQueries * 8];          // grad_out rows of the batch's candidates (this head), 32 KB
+  __shared__ float4 coef_tab[kRowBatchQueries * 4];        // per (candidate slot, point): the four corner coefficients, 16 KB
+  __shared__ unsigned short bucket[kRowTileRows * (kRowCellCap + 1)];   // per cell: point indices (slot * 4 + point), 16.5 KB
   __shared__ unsigned count[kRowTileRows];
   __shared__ int overflow;                                 // some bucket was full: the batch needs another round
 
@@ -81,60 +92,63 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
   if (bm >= B * M) return;
   const int it = (int)((blockIdx.x / 8) % p.n_items);
   const int b = bm / M, m = bm - b * M;
+  const HeadPlan *hp = plans ? plans + m : nullptr;
+  if (hp && it >= hp->n_items) return;
+  const int *first_item = hp ? hp->first_item : p.first_item;
   int oi = 0;
-  while (oi < 3 && it >= p.first_item[oi + 1]) ++oi;
-  const int l = p.order[oi];
-  const int local = it - p.first_item[oi];
-  const int n_chunks = p.n_chunks[l];
+  while (oi < 3 && it >= first_item[oi + 1]) ++oi;
+  const int l = hp ? hp->order[oi] : p.order[oi];
+  const int local = it - first_item[oi];
+  const int n_chunks = hp ? hp->n_chunks[l] : p.n_chunks[l];
   const int chunk = local % n_chunks, tile = local / n_chunks;
   const int ty = tile / p.n_tx[l], tx = tile - ty * p.n_tx[l];
-  const RowAxis ay = p.ax[p.axis0[l] + ty], ax = p.ax[p.axis0[l] + p.n_ty[l] + tx];
+  const RowAxis *axes = hp ? hp->rax : p.ax;
+  const RowAxis ay = axes[p.axis0[l] + ty], ax = axes[p.axis0[l] + p.n_ty[l] + tx];
+  // near <=> the footprint's top-left pixel lies inside the head's bounds around the query's centre floor
+  DirBounds nb;
+  if (hp) nb = hp->near[l]; else { nb.ylo = nb.xlo = (short)-p.reach; nb.yhi = nb.xhi = (short)p.reach; }
   const int H = p.H[l], W = p.W[l];
-  const int y0 = ay.r0, x0 = ax.r0, th = ay.rn, tw = ax.rn, n_rows = th * tw;
-  // bucket slots per row and round (>= 15); rows are cap + 1 entries apart: with a power-of-two stride every row's bucket
-  // would start on the same LDS bank (counters: 58 % of the LDS cycles were bank conflicts)
-  const int cap = kRowBucketEntries / n_rows - 1, bstride = cap + 1;
+  const int y0 = ay.r0, x0 = ax.r0, th = ay.rn, tw = ax.rn;          // the tile's output rows
+  const int cw = tw + 1, n_cells = (th + 1) * cw;                    // its cells: one more row above, one more column to the left
+  constexpr int cap = kRowCellCap, bstride = kRowCellCap + 1;        // (odd stride in 2-byte units: the buckets start on different banks)
   int n_cand = 0;
 #pragma unroll
   for (int lq = 0; lq < 4; ++lq) n_cand += (int)ay.qn[lq] * (int)ax.qn[lq];
   const int c_begin = (int)((long long)n_cand * chunk / n_chunks), c_end = (int)((long long)n_cand * (chunk + 1) / n_chunks);
-  const RowCandidate *cands = table + p.cand_base[l] + (long long)tile * p.cand_stride[l];
+  const RowCandidate *cands = table + (hp ? (long long)m * p.cand_total : 0) + p.cand_base[l] + (long long)tile * p.cand_stride[l];
 
   const int tid = threadIdx.x;
   const int slot0 = tid >> 2, pt = tid & 3;                // scan role: candidate slots slot0, slot0 + 128 of the batch; point
-  const int r = tid >> 1, half = tid & 1;                  // gather role: row of the tile, half of its 32 channels
+  const int cell = tid >> 2, quarter = tid & 3;            // walk role: cell of the tile, quarter of its 32 channels
   if (tid < kRowTileRows) count[tid] = 0;
   if (tid == 0) overflow = 0;
-  // this lane's 16 channel sums as 8 packed pairs: a hit costs 8 v_pk_fma_f32 instead of 16 v_fmac_f32 (the bucket walk is
-  // bound by instruction issue and LDS latency, not by arithmetic)
-  rows_v2f ap[8];
+  // this lane's 4 x 8 channel sums as packed pairs (v_pk_fma_f32): sums[j][2 k], [2 k + 1] = channels 4 k .. 4 k + 3 (of the
+  // lane's 8) of corner j
+  rows_v2f sums[4][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) ap[i] = (rows_v2f){0.f, 0.f};
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sums[j][i] = (rows_v2f){0.f, 0.f};
 
-  // The scan is a chain of two dependent memory round trips per batch (candidate -> point).  Candidate entries are read two
-  // batches ahead; a batch's points are requested as soon as the previous batch's inputs have been turned into taps, so the
-  // loads are in flight during that batch's bucket / gather phases (lds_barrier keeps them in flight).
+  // Candidate entries are read two batches ahead, a batch's POINTS one batch ahead (in flight during the previous batch's
+  // bucket / walk phases: lds_barrier keeps them in flight); its grad_out rows are requested at the top of the batch and
+  // written to LDS behind the taps -- not live across the walk.
   // Batch k takes candidates k, k + n_batches, k + 2 n_batches, ... of the chunk: a batch then samples the whole scan
-  // region.  Neighbouring queries sample alike (the model's offsets are a per-head pattern), so a batch of NEIGHBOURS
-  // lands on a handful of rows of a coarse level -- hundreds of hits per row against a bucket of a few dozen (many overflow
-  // rounds with most lanes idle: measured 1.95 ms per backward in the train step against 1.45 ms on random offsets).
-  struct Inputs { float4 g0, g1, lg; float2 xy; float wt; RefScale rs; };
+  // region (a batch of NEIGHBOURS lands on a handful of cells of a coarse level and overflows their buckets).
+  struct Points { float4 lg; float2 xy; float wt; RefScale rs; };
   const int n_batches = (c_end - c_begin + kRowBatchQueries - 1) / kRowBatchQueries;
   auto cand_index = [&](const int k, const int u) {
     return k < n_batches ? c_begin + k + (slot0 + u * (kRowThreads / 4)) * n_batches : c_end;
   };
   auto candidate = [&](const int j) {
-    RowCandidate c{0, 0, 0};
+    RowCandidate c{-1, 0, 0};
     if (j < c_end) c = cands[j];
     return c;
   };
-  auto fetch = [&](const int j, const RowCandidate c) {
-    Inputs in{};
-    if (j < c_end) {
+  auto fetch = [&](const RowCandidate c) {
+    Points in{};
+    if (c.token >= 0) {
       const long long q_lin = (long long)b * S + c.token;                          // Lq == S
-      const float *gp = grad_out + (q_lin * M + m) * 32 + pt * 8;
-      in.g0 = ld4(gp);
-      in.g1 = ld4(gp + 4);
       const long long pl = (((long long)(b * M + m) * 4 + l) * S + c.token) * 4 + pt;          // level-major point index
       in.xy = LEVEL_MAJOR ? *reinterpret_cast<const float2 *>(loc + pl * 2)
                           : *reinterpret_cast<const float2 *>(loc + q_lin * loc_rs + ((m * 4 + l) * 4 + pt) * 2);
@@ -150,11 +164,11 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
     return in;
   };
   RowCandidate cur[kRowSub], c_next[kRowSub];
-  Inputs in[kRowSub];
+  Points in[kRowSub];
 #pragma unroll
   for (int u = 0; u < kRowSub; ++u) {
     cur[u] = candidate(cand_index(0, u));
-    in[u] = fetch(cand_index(0, u), cur[u]);
+    in[u] = fetch(cur[u]);
     c_next[u] = candidate(cand_index(1, u));
   }
   lds_barrier();
@@ -164,14 +178,20 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
 
   for (int k = 0; k < n_batches; ++k) {
     ROWS_STAMP(0);
-#if MSDA_ROWS_STAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ROWS_STAMP(7);
-#endif
+    // ---- 0. the batch's grad_out rows: this thread's 32 bytes of its candidates' rows ---------------------------------------
+    float4 g0[kRowSub], g1[kRowSub];
+#pragma unroll
+    for (int u = 0; u < kRowSub; ++u) {
+      g0[u] = g1[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cur[u].token >= 0) {
+        const float *gp = grad_out + (((long long)b * S + cur[u].token) * M + m) * 32 + pt * 8;
+        g0[u] = ld4(gp);
+        g1[u] = ld4(gp + 4);
+      }
+    }
     // ---- 1. this thread's two points -------------------------------------------------------------------------------
-    unsigned pend = 0;                                     // bit 4 u + c: corner c of sub-slot u still has to be placed
-    int rows[kRowSub][4];
-    float coef[kRowSub][4];
+    unsigned pend = 0;                                     // bit u: the point of sub-slot u still has to be placed
+    int cells[kRowSub];
 #pragma unroll
     for (int u = 0; u < kRowSub; ++u) {
       const int slot = slot0 + u * (kRowThreads / 4);
@@ -187,75 +207,91 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
         lx = loc_from_offset<4>(in[u].rs.rx, lx, in[u].rs.sx, ref_dim);
         ly = loc_from_offset<4>(in[u].rs.ry, ly, in[u].rs.sy, ref_dim);
       }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { rows[u][c] = 0; coef[u][c] = 0.f; }
-      if (cand_index(k, u) < c_end) {
-        go_lds[slot * 8 + ((pt * 2) ^ (slot & 7))] = in[u].g0;          // chunk c of slot s at c ^ (s & 7): the gather's lanes
-        go_lds[slot * 8 + ((pt * 2 + 1) ^ (slot & 7))] = in[u].g1;      // read one chunk of different rows -> different banks
+      cells[u] = 0;
+      if (cur[u].token >= 0) {
         const Tap<float> tp = make_tap<float>(lx, ly, H, W);
-        if (tp.valid && near_point(tp.h_low, tp.w_low, cur[u].cy, cur[u].cx, p.reach)) {
-          const int ry0 = tp.y0 - y0, ry1 = tp.y1 - y0, rx0 = tp.x0 - x0, rx1 = tp.x1 - x0;
-          const bool iy0 = tp.t && (unsigned)ry0 < (unsigned)th, iy1 = tp.b && (unsigned)ry1 < (unsigned)th;
-          const bool ix0 = tp.l && (unsigned)rx0 < (unsigned)tw, ix1 = tp.r && (unsigned)rx1 < (unsigned)tw;
-          rows[u][0] = ry0 * tw + rx0; rows[u][1] = ry0 * tw + rx1; rows[u][2] = ry1 * tw + rx0; rows[u][3] = ry1 * tw + rx1;
-          coef[u][0] = tp.w1 * wt; coef[u][1] = tp.w2 * wt; coef[u][2] = tp.w3 * wt; coef[u][3] = tp.w4 * wt;
-          pend |= ((iy0 && ix0 ? 1u : 0u) | (iy0 && ix1 ? 2u : 0u) | (iy1 && ix0 ? 4u : 0u) | (iy1 && ix1 ? 8u : 0u)) << (4 * u);
+        // corner coefficients (a corner outside the level has weight 0, msda_common.h): read by the walk through the
+        // point's index, so every thread writes its entry
+        coef_tab[slot * 4 + pt] = make_float4(tp.w1 * wt, tp.w2 * wt, tp.w3 * wt, tp.w4 * wt);
+        if (tp.valid && inside_bounds(tp.h_low - cur[u].cy, tp.w_low - cur[u].cx, nb)) {
+          const int cy = tp.h_low - (y0 - 1), cx = tp.w_low - (x0 - 1);
+          if ((unsigned)cy <= (unsigned)th && (unsigned)cx <= (unsigned)tw) {
+            cells[u] = cy * cw + cx;
+            pend |= 1u << u;
+          }
         }
       }
-      // the next batch's points: requested now, consumed in the next iteration
+    }
+    // the batch's grad_out rows (requested at the top: the taps ran under their latency), then the next batch's points:
+    // requested now, consumed in the next iteration
+#pragma unroll
+    for (int u = 0; u < kRowSub; ++u) {
+      if (cur[u].token >= 0) {
+        const int slot = slot0 + u * (kRowThreads / 4);
+        go_lds[slot * 8 + ((pt * 2) ^ (slot & 7))] = g0[u];          // chunk c of slot s at c ^ (s & 7): the walk's lanes
+        go_lds[slot * 8 + ((pt * 2 + 1) ^ (slot & 7))] = g1[u];      // read one chunk of different rows -> different banks
+      }
       cur[u] = c_next[u];
-      in[u] = fetch(cand_index(k + 1, u), cur[u]);
+      in[u] = fetch(cur[u]);
       c_next[u] = candidate(cand_index(k + 2, u));
     }
     ROWS_STAMP(1);
-    // ---- 2./3. buckets and row sums; a row whose bucket overflows (many points on one pixel) takes more rounds -----------
+    // ---- 2./3. buckets and cell sums; a cell whose bucket overflows (many points on one pixel) takes more rounds -----------
     bool again;
     do {
-      // all slot reservations first (independent LDS atomics with return: in flight together), then the entries -- one atomic,
-      // its wait and its store per corner in turn cost eight LDS round trips per thread and batch
-      unsigned rank[kRowSub][4];
+      unsigned rank[kRowSub];
+#pragma unroll
+      for (int u = 0; u < kRowSub; ++u) {
+        rank[u] = 0xFFFFFFFFu;
+        if (pend & (1u << u)) rank[u] = atomicAdd(&count[cells[u]], 1u);
+      }
 #pragma unroll
       for (int u = 0; u < kRowSub; ++u)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          rank[u][c] = 0xFFFFFFFFu;
-          if (pend & (1u << (4 * u + c))) rank[u][c] = atomicAdd(&count[rows[u][c]], 1u);
+        if (rank[u] < (unsigned)cap) {
+          bucket[cells[u] * bstride + rank[u]] = (unsigned short)((slot0 + u * (kRowThreads / 4)) * 4 + pt);
+          pend &= ~(1u << u);
         }
-#pragma unroll
-      for (int u = 0; u < kRowSub; ++u)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (rank[u][c] < (unsigned)cap) {
-            bucket[rows[u][c] * bstride + rank[u][c]] = make_uint2(__float_as_uint(coef[u][c]), (unsigned)(slot0 + u * (kRowThreads / 4)));
-            pend &= ~(1u << (4 * u + c));
-          }
       if (pend) overflow = 1;                // rare
       ROWS_STAMP(2);
       lds_barrier();
       ROWS_STAMP(3);
-      // read BETWEEN the round's two barriers: every `overflow = 1` of this round lies before the first one, and the next
-      // write to the flag (the reset below, or the next batch's appends) lies behind the second -- read after it, a fast wave's
-      // next-batch append could reach a slow wave's read of this batch (waves disagreeing on the number of barriers)
+      // read BETWEEN the round's two barriers: every `overflow = 1` of this round lies before the first one, the next write
+      // to the flag (the reset below, or the next batch's appends) behind the second
       again = overflow != 0;
-      if (r < n_rows) {
-        const int n = min((int)count[r], cap);
-        const uint2 *bk = bucket + r * bstride;
+      if (cell < n_cells) {
+        const int n = min((int)count[cell], cap);
+        const unsigned short *bk = bucket + cell * bstride;
+        const char *go_b = reinterpret_cast<const char *>(go_lds);
+        const int hs = quarter << 5;
+        // index i + 1 is requested before point i's rows (bk[n] is at worst the cell's pad slot)
+        unsigned idx_next = bk[0];
         for (int i = 0; i < n; ++i) {
-          const uint2 e = bk[i];
-          const float w = __uint_as_float(e.x);
-          const float4 *g4 = go_lds + e.y * 8;
-          const int sw = (half * 4) ^ (e.y & 7);     // grad_out rows are stored with their 16-byte chunks XOR-swizzled by the slot
+          const unsigned idx = idx_next;
+          idx_next = bk[i + 1];
+          const float4 c4 = coef_tab[idx];
+          // the row's 16-byte chunks are stored XOR-swizzled by the slot: chunk c of slot s at (c ^ (s & 7)); this lane's
+          // chunks are 2 quarter + kk  ->  byte (s * 128 + (s & 7) * 16) ^ (quarter * 32) ^ (kk * 16)
+          const unsigned s4 = idx >> 2, a0 = ((s4 << 7) | ((s4 & 7) << 4)) ^ hs;
+          float4 a[2];
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const float4 a = g4[kk ^ sw];
-            ap[2 * kk] = __builtin_elementwise_fma((rows_v2f){w, w}, (rows_v2f){a.x, a.y}, ap[2 * kk]);
-            ap[2 * kk + 1] = __builtin_elementwise_fma((rows_v2f){w, w}, (rows_v2f){a.z, a.w}, ap[2 * kk + 1]);
+          for (int kk = 0; kk < 2; ++kk) a[kk] = *reinterpret_cast<const float4 *>(go_b + (a0 ^ (kk << 4)));
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const rows_v2f lo = (rows_v2f){a[kk].x, a[kk].y}, hi = (rows_v2f){a[kk].z, a[kk].w};
+            sums[0][2 * kk] = __builtin_elementwise_fma((rows_v2f){c4.x, c4.x}, lo, sums[0][2 * kk]);
+            sums[0][2 * kk + 1] = __builtin_elementwise_fma((rows_v2f){c4.x, c4.x}, hi, sums[0][2 * kk + 1]);
+            sums[1][2 * kk] = __builtin_elementwise_fma((rows_v2f){c4.y, c4.y}, lo, sums[1][2 * kk]);
+            sums[1][2 * kk + 1] = __builtin_elementwise_fma((rows_v2f){c4.y, c4.y}, hi, sums[1][2 * kk + 1]);
+            sums[2][2 * kk] = __builtin_elementwise_fma((rows_v2f){c4.z, c4.z}, lo, sums[2][2 * kk]);
+            sums[2][2 * kk + 1] = __builtin_elementwise_fma((rows_v2f){c4.z, c4.z}, hi, sums[2][2 * kk + 1]);
+            sums[3][2 * kk] = __builtin_elementwise_fma((rows_v2f){c4.w, c4.w}, lo, sums[3][2 * kk]);
+            sums[3][2 * kk + 1] = __builtin_elementwise_fma((rows_v2f){c4.w, c4.w}, hi, sums[3][2 * kk + 1]);
           }
         }
-        if (half == 0) count[r] = 0;         // the row's two lanes sit in one wave: both have read it
+        if (quarter == 0) count[cell] = 0;   // the cell's four lanes sit in one wave: all have read it
       }
       ROWS_STAMP(4);
-      lds_barrier();                         // orders the gather before the next appends / grad_out rows
+      lds_barrier();                         // orders the walk before the next appends / coefficients / grad_out rows
       ROWS_STAMP(5);
       if (again) {                           // everyone has read the flag (in front of the barrier above)
         if (tid == 0) overflow = 0;
@@ -269,33 +305,56 @@ __global__ __launch_bounds__(kRowThreads, kRowSub == 1 ? 6 : 4) void scatter_row
   if ((threadIdx.x & 63) == 0)
     for (int i = 0; i < 8; ++i) atomicAdd(&g_rows_stamp[i], (unsigned long long)st_acc[i]);
 #endif
-  // ---- write the tile -------------------------------------------------------------------------------------------------
-  float4 acc[4];
+  // ---- corner sums -> rows: out[y, x] = S00[y, x] + S01[y, x - 1] + S10[y - 1, x] + S11[y - 1, x - 1] ---------------------------
+  // three shifted adds through LDS (the grad_out buffer: every wave is past its last walk), 32 bytes per lane and round
+  const int cy = cell / cw, cx = cell - cy * cw;
+  auto shifted_add = [&](const int j, const int src, const bool take) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) acc[k] = make_float4(ap[2 * k].x, ap[2 * k].y, ap[2 * k + 1].x, ap[2 * k + 1].y);
+    for (int kk = 0; kk < 2; ++kk)
+      go_lds[(cell * 4 + quarter) * 2 + kk] = make_float4(sums[j][2 * kk].x, sums[j][2 * kk].y, sums[j][2 * kk + 1].x, sums[j][2 * kk + 1].y);
+    lds_barrier();
+    if (take) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const float4 v = go_lds[(src * 4 + quarter) * 2 + kk];
+        sums[0][2 * kk] += (rows_v2f){v.x, v.y};
+        sums[0][2 * kk + 1] += (rows_v2f){v.z, v.w};
+      }
+    }
+    lds_barrier();
+  };
+  const bool is_out = cell < n_cells && cy >= 1 && cx >= 1;
+  shifted_add(1, cell - 1, is_out);
+  shifted_add(2, cell - cw, is_out);
+  shifted_add(3, cell - cw - 1, is_out);
+
+  // ---- write the tile -------------------------------------------------------------------------------------------------
+  float4 acc[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) acc[k] = make_float4(sums[0][2 * k].x, sums[0][2 * k].y, sums[0][2 * k + 1].x, sums[0][2 * k + 1].y);
   const long long tok0 = (long long)b * S + p.start[l];
   if (n_chunks == 1) {
-    if (r < n_rows) {
-      const int ry = r / tw, rx = r - ry * tw;
-      const long long token = tok0 + (long long)(y0 + ry) * W + (x0 + rx);
-      float *dst = grad_value + (token * M + m) * 32 + half * 16;
+    if (is_out) {
+      const long long token = tok0 + (long long)(y0 + cy - 1) * W + (x0 + cx - 1);
+      float *dst = grad_value + (token * M + m) * 32 + quarter * 8;
       const bool padded = vmask && vmask[token];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) st4(dst + 4 * k, padded ? make_float4(0.f, 0.f, 0.f, 0.f) : acc[k]);
+      for (int k = 0; k < 2; ++k) st4(dst + 4 * k, padded ? make_float4(0.f, 0.f, 0.f, 0.f) : acc[k]);
     }
   } else {
     // several workgroups share the tile: full 128-byte rows of atomics (lane = channel), through LDS
-    float *rows_lds = reinterpret_cast<float *>(bucket);
-    if (r < n_rows) {
+    float *rows_lds = reinterpret_cast<float *>(go_lds);
+    if (is_out) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) *reinterpret_cast<float4 *>(rows_lds + r * 32 + half * 16 + 4 * k) = acc[k];
+      for (int k = 0; k < 2; ++k) *reinterpret_cast<float4 *>(rows_lds + cell * 32 + quarter * 8 + 4 * k) = acc[k];
     }
     __syncthreads();
     const int ch = tid & 31;
-    for (int rr = tid >> 5; rr < n_rows; rr += kRowThreads / 32) {
+    for (int rr = tid >> 5; rr < n_cells; rr += kRowThreads / 32) {
+      const int ry = rr / cw, rx = rr - ry * cw;
+      if (ry < 1 || rx < 1) continue;
       const float v = rows_lds[rr * 32 + ch];
-      const int ry = rr / tw, rx = rr - ry * tw;
-      const long long token = tok0 + (long long)(y0 + ry) * W + (x0 + rx);
+      const long long token = tok0 + (long long)(y0 + ry - 1) * W + (x0 + rx - 1);
       if (v != 0.f && !(vmask && vmask[token])) atomicAdd(grad_value + (token * M + m) * 32 + ch, v);
     }
   }
