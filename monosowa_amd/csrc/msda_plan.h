@@ -22,7 +22,7 @@ namespace msda {
 
 constexpr int kPlanMaxHeads = 32;        // M * L * 8 <= 1024 threads in the d32 kernels
 constexpr int kPlanClip = 64;            // |d| is clipped here before it enters the statistics
-constexpr int kPlanSamples = 640;        // sampled queries per batch element (of Lq)
+constexpr int kPlanSamples = 256;        // sampled queries per batch element (of Lq): >= 16 k points per (head, level) at B = 16
 
 struct DirBounds { short ylo, yhi, xlo, xhi; };      // inclusive bounds of d
 #if defined(__HIPCC__)

@@ -4,7 +4,7 @@
 
 namespace msda {
 
-constexpr int kStatsBlocks = 64;         // workgroups of dir_stats_kernel = partial statistics per (head, level)
+constexpr int kStatsBlocks = 256;        // workgroups of dir_stats_kernel = partial statistics per (head, level)
 constexpr int kStatsThreads = 256;
 
 __device__ __forceinline__ int plan_floor_div_dev(int a, int b) {        // b > 0
@@ -132,16 +132,28 @@ __global__ __launch_bounds__(256) void dir_plan_kernel(const DirStats *__restric
   HeadPlan &hp = plans[m];
 
   // ---- A. bounds: [min, max] of the sample, cut at mean +- 4 sigma (one stray point must not size every window) ----------------
+  // (the partial records are summed by all threads: one dependent global load per thread instead of n_partial per level)
+  __shared__ int s_acc[4][8];                    // n, up_y, dn_y, up_x, dn_x, sum_y, sum_x, -
+  __shared__ unsigned long long s_sq[4][2];
+  if (tid < 32) (&s_acc[0][0])[tid] = 0;
+  if (tid < 8) (&s_sq[0][0])[tid] = 0ull;
+  __syncthreads();
+  for (int i = tid; i < n_partial * 4; i += 256) {
+    const int l = i & 3;
+    const DirStats s = partial[((long long)(i >> 2) * g.M + m) * 4 + l];
+    if (s.n) {
+      atomicAdd(&s_acc[l][0], s.n);
+      atomicMax(&s_acc[l][1], s.up_y); atomicMax(&s_acc[l][2], s.dn_y); atomicMax(&s_acc[l][3], s.up_x); atomicMax(&s_acc[l][4], s.dn_x);
+      atomicAdd(&s_acc[l][5], s.sum_y); atomicAdd(&s_acc[l][6], s.sum_x);
+      atomicAdd(&s_sq[l][0], s.sq_y); atomicAdd(&s_sq[l][1], s.sq_x);
+    }
+  }
+  __syncthreads();
   if (tid < 4) {
     const int l = tid;
-    long long n = 0, sy = 0, sx = 0;
-    unsigned long long qy = 0, qx = 0;
-    int up_y = 0, dn_y = 0, up_x = 0, dn_x = 0;
-    for (int i = 0; i < n_partial; ++i) {
-      const DirStats s = partial[((long long)i * g.M + m) * 4 + l];
-      n += s.n; sy += s.sum_y; sx += s.sum_x; qy += s.sq_y; qx += s.sq_x;
-      up_y = max(up_y, s.up_y); dn_y = max(dn_y, s.dn_y); up_x = max(up_x, s.up_x); dn_x = max(dn_x, s.dn_x);
-    }
+    const long long n = s_acc[l][0], sy = s_acc[l][5], sx = s_acc[l][6];
+    const unsigned long long qy = s_sq[l][0], qx = s_sq[l][1];
+    const int up_y = s_acc[l][1], dn_y = s_acc[l][2], up_x = s_acc[l][3], dn_x = s_acc[l][4];
     DirBounds b;
     float my = 0.f, mx = 0.f;
     if (n == 0) {
