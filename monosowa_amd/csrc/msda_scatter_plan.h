@@ -13,10 +13,16 @@
 
 namespace msda {
 
-constexpr int kRowTileRows = 128;          // bilinear cells per tile: 512 threads = 128 cells x 4 lanes (8 channels x 4 corner sums each);
+#ifndef MSDA_ROW_CELLS
+#define MSDA_ROW_CELLS 128
+#endif
+#ifndef MSDA_ROW_THREADS
+#define MSDA_ROW_THREADS 512
+#endif
+constexpr int kRowTileRows = MSDA_ROW_CELLS;   // bilinear cells per tile: 512 threads = 128 cells x 4 lanes (8 channels x 4 corner sums each);
                                            // a tile of th x tw output rows has (th + 1) x (tw + 1) cells
 constexpr int kRowCellCap = 32;            // points one cell's bucket holds per batch and round
-constexpr int kRowThreads = 512;
+constexpr int kRowThreads = MSDA_ROW_THREADS;
 #ifndef MSDA_ROW_SUB
 #define MSDA_ROW_SUB 2
 #endif

@@ -23,6 +23,9 @@
 #include "msda_scatter_plan.h"
 #include "msda_plan.h"
 
+#ifndef MSDA_ROWS_SKIP
+#define MSDA_ROWS_SKIP 0         // measurement builds only: 1 no bucket walk, 2 no appends (scan only)
+#endif
 #ifndef MSDA_ROWS_STAMP
 #define MSDA_ROWS_STAMP 0        // measurement builds only: per-phase shader-clock totals (tools/debug/win_stamps.py)
 #endif
@@ -210,14 +213,14 @@ __global__ __launch_bounds__(kRowThreads, 4) void scatter_rows_kernel(
       cells[u] = 0;
       if (cur[u].token >= 0) {
         const Tap<float> tp = make_tap<float>(lx, ly, H, W);
-        // corner coefficients (a corner outside the level has weight 0, msda_common.h): read by the walk through the
-        // point's index, so every thread writes its entry
-        coef_tab[slot * 4 + pt] = make_float4(tp.w1 * wt, tp.w2 * wt, tp.w3 * wt, tp.w4 * wt);
         if (tp.valid && inside_bounds(tp.h_low - cur[u].cy, tp.w_low - cur[u].cx, nb)) {
           const int cy = tp.h_low - (y0 - 1), cx = tp.w_low - (x0 - 1);
           if ((unsigned)cy <= (unsigned)th && (unsigned)cx <= (unsigned)tw) {
             cells[u] = cy * cw + cx;
-            pend |= 1u << u;
+            // corner coefficients (a corner outside the level has weight 0, msda_common.h): read by the walk through the
+            // point's index -- only a point of this tile is ever looked up
+            coef_tab[slot * 4 + pt] = make_float4(tp.w1 * wt, tp.w2 * wt, tp.w3 * wt, tp.w4 * wt);
+            if (!(MSDA_ROWS_SKIP & 2)) pend |= 1u << u;
           }
         }
       }
@@ -226,7 +229,11 @@ __global__ __launch_bounds__(kRowThreads, 4) void scatter_rows_kernel(
     // requested now, consumed in the next iteration
 #pragma unroll
     for (int u = 0; u < kRowSub; ++u) {
-      if (cur[u].token >= 0) {
+      // (only for a candidate with a point in this tile: the quad's four threads hold its four points)
+      unsigned any = (pend >> u) & 1u;
+      any |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)any, 0xB1, 0xF, 0xF, false);
+      any |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)any, 0x4E, 0xF, 0xF, false);
+      if (any) {
         const int slot = slot0 + u * (kRowThreads / 4);
         go_lds[slot * 8 + ((pt * 2) ^ (slot & 7))] = g0[u];          // chunk c of slot s at c ^ (s & 7): the walk's lanes
         go_lds[slot * 8 + ((pt * 2 + 1) ^ (slot & 7))] = g1[u];      // read one chunk of different rows -> different banks
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(kRowThreads, 4) void scatter_rows_kernel(
         const int hs = quarter << 5;
         // index i + 1 is requested before point i's rows (bk[n] is at worst the cell's pad slot)
         unsigned idx_next = bk[0];
-        for (int i = 0; i < n; ++i) {
+        for (int i = 0; i < ((MSDA_ROWS_SKIP & 1) ? 0 : n); ++i) {
           const unsigned idx = idx_next;
           idx_next = bk[i + 1];
           const float4 c4 = coef_tab[idx];
