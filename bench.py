@@ -56,6 +56,15 @@ def parse():
     ap.add_argument("--preheat-seconds", type=float, default=3.0,
                     help="untimed steps run for this long before the W warm-up steps: on a fresh box the first ~2 s of "
                          "sustained load run 5 %% slower (clock / power ramp), which 3 warm-up steps (0.3 s) do not cover")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="fixed GLOBAL batch per optimizer step (SURVEY 8d config 3, second definition): every rank runs "
+                         "global_batch / (gpus * batch) micro-steps of --batch images with gradient accumulation, one AdamW "
+                         "update per step; the line then says \"scaling\": \"strong\" (total work fixed as N grows).  0 (default): "
+                         "per-GPU batch fixed, \"weak\"")
+    ap.add_argument("--mixed-cameras", action="store_true",
+                    help="config 5: the batch mixes fu in {721.5, 552.6, 2055} (per-sample Canonical Object Space scale)")
+    ap.add_argument("--no-inference-leg", action="store_true", help="skip the eval-mode leg of the train line")
+    ap.add_argument("--inference-steps", type=int, default=20)
     ap.add_argument("--no-miopen-db", action="store_true",
                     help="ignore the shipped MIOpen find results (monosowa_amd/miopen_db) and use MIOpen's heuristics")
     return ap.parse_args()
@@ -104,20 +113,29 @@ def build_everything(args, device):
 _PROBE_SLEEP = float(os.environ.get("MONOSOWA_PROBE_SLEEP_MS", "0")) * 1e-3     # host-slack probe (tools only)
 
 
-def train_step_fn(model, criterion, optimizer):
+def train_step_fn(model, criterion, optimizer, accum=1):
+    """One optimizer step.  accum > 1: that many micro-steps over the same resident batch with gradient accumulation (each
+    micro-batch's losses scaled by 1 / accum; under DDP the all-reduce runs once, with the last micro-step) -- the
+    fixed-global-batch definition of a step.  The criterion normalises every micro-batch by its own box count, as the reference
+    loop would when it accumulates (trainer_helper.py:123-150 has no accumulation of its own)."""
+    import contextlib
     from monosowa_amd.monodetr.criterion import weighted_total
     from monosowa_amd.synthetic import prepare_targets
 
     def step(batch):
         inputs, calibs, targets, info = batch
-        tl = prepare_targets(targets, inputs.shape[0])
         optimizer.zero_grad(set_to_none=True)
-        outputs = model(inputs, calibs, tl, targets["img_size"])
-        loss_dict = criterion(outputs, tl)
-        total = weighted_total(loss_dict, criterion.weight_dict)
-        if _PROBE_SLEEP:
-            time.sleep(_PROBE_SLEEP)
-        total.backward()
+        total = None
+        for i in range(accum):
+            tl = prepare_targets(targets, inputs.shape[0])
+            sync_now = i == accum - 1 or not hasattr(model, "no_sync")
+            with (contextlib.nullcontext() if sync_now else model.no_sync()):
+                outputs = model(inputs, calibs, tl, targets["img_size"])
+                loss_dict = criterion(outputs, tl)
+                total = weighted_total(loss_dict, criterion.weight_dict)
+                if _PROBE_SLEEP:
+                    time.sleep(_PROBE_SLEEP)
+                (total if accum == 1 else total / accum).backward()
         optimizer.step()
         return total
     return step
@@ -240,11 +258,15 @@ def main():
     model.train(train)
     criterion.train(train)
     model = wrap_ddp(model, device)
-    batch = make_batch(args.batch, device, seed=444 + rank, resolution=(W, H))
+    batch = make_batch(args.batch, device, seed=444 + rank, resolution=(W, H), mixed_cameras=args.mixed_cameras)
     batch = (batch[0].contiguous(memory_format=torch.channels_last),) + batch[1:]
+    accum = 1
+    if args.global_batch:
+        assert train and args.global_batch % (args.batch * world) == 0, "--global-batch must be a multiple of gpus * batch"
+        accum = args.global_batch // (args.batch * world)
 
     if train:
-        step = train_step_fn(model, criterion, optimizer)
+        step = train_step_fn(model, criterion, optimizer, accum)
     elif not args.graph:
         def step(b):
             with torch.no_grad():
@@ -290,8 +312,44 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    global_batch = args.batch * world
+    global_batch = args.batch * world * accum
     value = global_batch * args.steps / elapsed
+
+    # ---- inference leg of the train line (north_star: "training/inference throughput ... reported"): eval-mode forward of
+    # the same model on the same resident batch, every rank its own images, timed like the train leg -----------------------
+    inference = None
+    if train and not args.no_inference_leg:
+        net = model.module if hasattr(model, "module") else model
+        net.eval()
+
+        def infer(b):
+            with torch.no_grad():
+                return net(b[0], b[1], None, b[2]["img_size"])["pred_logits"]
+        for _ in range(3):
+            infer(batch)
+        sync()
+        with MSDA.LaunchTimer() as itimer:
+            t1 = time.perf_counter()
+            for _ in range(args.inference_steps):
+                infer(batch)
+            sync()
+            i_elapsed = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([i_elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            i_elapsed = t.item()
+        enc = [(dims, d) for (kind, dims), d in itimer.summary().items() if kind == "fwd" and dims[5] == dims[1]]
+        inference = {"value": args.batch * world * args.inference_steps / i_elapsed, "unit": "img/s", "steps": args.inference_steps,
+                     "ms_per_step": i_elapsed / args.inference_steps * 1e3, "queries": 50,
+                     "workload": "eval forward (50 queries), per-GPU batch %d" % args.batch}
+        if enc:
+            dims, d = enc[0]
+            ab = msda_alg_bytes("fwd", dims)
+            inference["msda_fwd"] = {"Lq": dims[5], "avg_launch_ms": d["avg_ms"], "alg_bytes_per_launch": ab,
+                                     "frac": ab / (d["avg_ms"] * 1e-3) / HBM_PEAK_BYTES_PER_S}
+        net.train()
+        log("inference leg: %d eval steps in %.3f s" % (args.inference_steps, i_elapsed))
+
     kernels = []
     for (kind, dims), d in sorted(timer.summary().items(), key=lambda kv: -kv[1]["total_ms"]):
         ab = msda_alg_bytes(kind, dims)
@@ -330,14 +388,19 @@ def main():
         line = {
             "metric": "MonoDETR %s img/s (KITTI %dx%d)" % ("training" if train else "inference", W, H),
             "value": value, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            # weak: per-GPU batch fixed as N grows; strong: --global-batch fixed (gradient accumulation fills the difference)
+            "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "MonoDETR %s KITTI %dx%d, %s step, per-GPU batch %d, synthetic images + random pseudo-labels"
                                    % (args.backbone, W, H, "fwd+criterion+bwd+AdamW" if train else "eval fwd (50 queries)", args.batch),
                        "global_batch": global_batch, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
+                       "accumulation_micro_steps": accum, "mixed_cameras": bool(args.mixed_cameras),
                        "queries": 550 if train else 50},
             "roofline": roofline,
         }
+        if inference is not None:
+            line["inference"] = inference
         if dist.is_initialized():          # the CPU leg below must not meet an RCCL-only process group
             dist.barrier()
             dist.destroy_process_group()

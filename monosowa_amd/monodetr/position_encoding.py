@@ -35,20 +35,26 @@ class PositionEmbeddingSine(nn.Module):
         return self._encode(x, mask)
 
     def _encode(self, x, mask):
-        not_mask = ~mask
-        y_embed = not_mask.cumsum(1, dtype=torch.float32)
-        x_embed = not_mask.cumsum(2, dtype=torch.float32)
-        if self.normalize:
-            eps = 1e-6
-            y_embed = y_embed / (y_embed[:, -1:, :] + eps) * self.scale
-            x_embed = x_embed / (x_embed[:, :, -1:] + eps) * self.scale
-        dim_t = torch.arange(self.num_pos_feats, dtype=torch.float32, device=x.device)
-        dim_t = self.temperature ** (2 * (dim_t // 2) / self.num_pos_feats)
-        pos_x = x_embed[:, :, :, None] / dim_t
-        pos_y = y_embed[:, :, :, None] / dim_t
-        pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
-        pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
-        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+        """Channel c of each half is a sinusoid of the (normalised) count of valid pixels up to and including this one, along
+        y for the first half and along x for the second: frequency temperature ** (-2 (c // 2) / F), even channels the sine,
+        odd channels the cosine of the SAME angle as their even neighbour (position_encoding.py:40-56).  Both functions are
+        evaluated for every channel and the parity picks one -- the picked values are the reference's bit for bit (same
+        quotient, same function), the layout falls out of a single concatenation instead of interleaving two half-width
+        tensors."""
+        valid = (~mask).to(torch.float32)
+        F = self.num_pos_feats
+        channel = torch.arange(F, device=x.device)
+        period = self.temperature ** (2 * torch.div(channel, 2, rounding_mode="floor").to(torch.float32) / F)
+        take_sin = (channel % 2 == 0)
+        halves = []
+        for axis in (1, 2):                                        # y (rows), then x (columns)
+            count = torch.cumsum(valid, dim=axis)
+            if self.normalize:
+                last = count.narrow(axis, count.shape[axis] - 1, 1)
+                count = count / (last + 1e-6) * self.scale
+            angle = count.unsqueeze(-1) / period                   # [B, H, W, F]
+            halves.append(torch.where(take_sin, angle.sin(), angle.cos()))
+        return torch.cat(halves, dim=3).permute(0, 3, 1, 2)
 
 
 def build_position_encoding(cfg):

@@ -16,10 +16,16 @@ from torch.utils.data import Dataset
 MAX_OBJS = 50
 
 
-def synthetic_sample(rng, resolution=(1280, 384), canonical_focal_length=500.0):
+MIXED_CAMERA_FU = (721.5, 552.6, 2055.0)      # KITTI, KITTI-360, Waymo front camera: typical values picked for the synthetic
+                                              # mixed-dataset batch of SURVEY.md 8d config 5 (the reference reads fu per calib file)
+
+
+def synthetic_sample(rng, resolution=(1280, 384), canonical_focal_length=500.0, fu=None):
+    """``fu``: focal length of this sample's camera in pixels (default: the KITTI-like value scaled to the resolution).  The
+    depth labels live in Canonical Object Space: scaled by canonical_focal_length / fu PER SAMPLE (kitti_dataset.py:232-237)."""
     W, H = resolution
     img = rng.standard_normal((3, H, W), dtype=np.float32)
-    fu = 707.05 * (W / 1242.0)
+    fu = 707.05 * (W / 1242.0) if fu is None else float(fu)
     calib = np.array([[fu, 0, W / 2.0, 0], [0, fu, H / 2.0, 0], [0, 0, 1, 0]], dtype=np.float32)
     n = int(rng.integers(1, 11))
     t = {
@@ -84,10 +90,13 @@ class SyntheticKITTI(Dataset):
         return img, calib, t, info
 
 
-def make_batch(batch_size, device, seed=444, resolution=(1280, 384)):
-    """One pre-collated batch resident on ``device``: (inputs, calibs, targets dict of [B,50,...], info)."""
+def make_batch(batch_size, device, seed=444, resolution=(1280, 384), mixed_cameras=False):
+    """One pre-collated batch resident on ``device``: (inputs, calibs, targets dict of [B,50,...], info).
+    ``mixed_cameras``: the samples cycle through MIXED_CAMERA_FU (a mixed-dataset batch: every sample has its own
+    canonical_scale and its own fu in ``calibs``, which the depth head reads per sample, monodetr.py:248)."""
     rng = np.random.default_rng(seed)
-    samples = [synthetic_sample(rng, resolution) for _ in range(batch_size)]
+    samples = [synthetic_sample(rng, resolution, fu=MIXED_CAMERA_FU[i % len(MIXED_CAMERA_FU)] if mixed_cameras else None)
+               for i in range(batch_size)]
     inputs = torch.from_numpy(np.stack([s[0] for s in samples])).to(device)
     calibs = torch.from_numpy(np.stack([s[1] for s in samples])).to(device)
     targets = {k: torch.from_numpy(np.stack([s[2][k] for s in samples])).to(device) for k in samples[0][2]}

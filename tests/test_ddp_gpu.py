@@ -220,3 +220,26 @@ def test_two_ranks_on_one_gpu_allreduce_the_fused_steps_gradients(tmp_path):
     if any(p.returncode != 0 for p in procs) or "ddp-ws2 ok" not in outs[0][0]:
         pytest.fail("DDP world-size-2 worker failed\n" + "\n".join("--- rank %d (rc %s) ---\n%s\n%s" % (i, procs[i].returncode, o[-1500:], e[-5000:])
                                                                      for i, (o, e) in enumerate(outs)), pytrace=False)
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_relays_the_same_line_as_the_plain_run():
+    """bench.py started plainly with MONOSOWA_BENCH_FORCE_LAUNCH=1 (the path ``--gpus N`` takes for N > 1: a fresh
+    torch.distributed.run child over RCCL, its stdout relayed) prints the ONE JSON line of the contract, and its value agrees
+    with the plain single-process run (same workload; DDP at world size 1) within the run-to-run spread."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2", "--no-cpu-baseline",
+           "--no-inference-leg", "--preheat-seconds", "2"]
+    lines = []
+    for force in ("0", "1"):
+        r = subprocess.run(cmd, env=dict(env, MONOSOWA_BENCH_FORCE_LAUNCH=force), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(out) == 1, r.stdout[-2000:]
+        lines.append(json.loads(out[0]))
+    plain, relayed = lines
+    assert relayed["n_gpus"] == 1 and relayed["metric"] == plain["metric"] and relayed["config"] == plain["config"]
+    assert abs(relayed["value"] - plain["value"]) <= 0.05 * plain["value"], (plain["value"], relayed["value"])

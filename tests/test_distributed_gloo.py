@@ -136,3 +136,23 @@ def test_two_rank_ddp_gradient_allreduce_and_num_boxes():
         p.join(240)
         assert p.exitcode == 0
     assert q.get() == "ok"
+
+
+def test_bench_self_launch_spawns_a_child_and_returns_its_code():
+    """``python bench.py --gpus N`` started plainly (no RANK in the environment) must start its ranks as a FRESH child
+    (torch.distributed.run) before touching the GPU and exit with the child's code (bench.py: launch_ranks).  Here there is
+    no GPU: the single rank stops with bench.py's own "needs an MI355X" message -- what matters is that it is the CHILD that
+    says so, under a launcher, and that the parent relays the failure code instead of running the benchmark itself."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MONOSOWA_BENCH_FORCE_LAUNCH="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert "starting 1 ranks" in r.stderr and "torch.distributed.run" in r.stderr, r.stderr[-2000:]
+    if not torch.cuda.is_available():
+        assert "needs an MI355X" in r.stderr, r.stderr[-2000:]              # said by the rank, not by the parent
+        assert r.returncode != 0                                            # ... and its failure is the parent's exit code
+        assert r.stdout.strip() == ""                                       # no JSON line was invented

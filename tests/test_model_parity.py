@@ -200,12 +200,26 @@ def test_matcher_indices_gpu(golden_dir):
     _matcher_case(_load(golden_dir, "matcher"), "cuda")
 
 
-def test_position_encoding(golden_dir):
+def _position_case(golden_dir, device):
     from monosowa_amd.monodetr.misc import NestedTensor
     from monosowa_amd.monodetr.position_encoding import PositionEmbeddingSine
     g = _load(golden_dir, "position_sine")
-    pos = PositionEmbeddingSine(128, normalize=True)(NestedTensor(torch.zeros(2, 256, 6, 8), g["mask"]))
-    _assert_close(pos, g["pos"], 1e-6, "sine position encoding")
+    mask = torch.as_tensor(g["mask"]).to(device)
+    pos = PositionEmbeddingSine(128, normalize=True)(NestedTensor(torch.zeros(2, 256, 6, 8, device=device), mask))
+    assert pos.shape == g["pos"].shape
+    _assert_close(pos.cpu(), g["pos"], 1e-6, "sine position encoding")
+    if device == "cpu":
+        assert torch.equal(pos, torch.as_tensor(g["pos"])), "the CPU evaluation reproduces the reference's floats"
+
+
+def test_position_encoding(golden_dir):
+    """Fixture made from the reference class (position_encoding.py:36-56) on a mask with padded rows and columns."""
+    _position_case(golden_dir, "cpu")
+
+
+@pytest.mark.gpu
+def test_position_encoding_gpu(golden_dir):
+    _position_case(golden_dir, "cuda")
 
 
 def test_losses(golden_dir):
