@@ -1,0 +1,125 @@
+"""Row a10 on the GPU: the whole backbone path of this package -- ResNet-50 / ResNet-101 body with frozen batch-norm FOLDED
+into the convolutions, channels-last activations, the fused bias + ReLU (+ residual, + byte mask) kernels, the three-handle
+stage outputs, the 1x1 / 3x3 input projections with the convolution bias inside the NHWC GroupNorm kernels, and the sine
+position encoding -- against an independent float64 CPU evaluation of the SAME state dict written with nothing but
+F.conv2d, the frozen-BN affine map, F.max_pool2d and F.group_norm.
+
+Structure restated from the reference: lib/models/monodetr/backbone.py:28-135 (FrozenBatchNorm2d, BackboneBase with
+layer2..4 -> "0", "1", "2", Joiner), monodetr.py:84-105 (input_proj: Conv2d 1x1 + GroupNorm(32, 256) per level, one extra
+3x3 stride-2 level from C5), :165-184 (srcs / masks / pos per level), position_encoding.py:36-56.  torchvision (the
+reference's ResNet source) is absent from this image, so reference OUTPUTS do not exist: this test
+pins the optimised GPU path to plain arithmetic on the published ResNet-v1.5 structure."""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+import yaml
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEPTHS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}
+
+
+def _model(name):
+    from monosowa_amd.helpers.model_helper import build_model, to_mi355x_layout
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "monodetr.yaml")))
+    torch.manual_seed(5)
+    model, _ = build_model(dict(cfg["model"], backbone=name, device="cuda", depth_map_size=(20, 6)))
+    # frozen batch-norm buffers away from the identity map (a checkpoint's are), input projections with a bias
+    gen = torch.Generator().manual_seed(11)
+    for n, b in model.backbone.named_buffers():
+        if n.endswith("running_var"):
+            b.copy_(torch.rand(b.shape, generator=gen) * 1.5 + 0.5)
+        elif n.endswith("weight"):
+            b.copy_(torch.rand(b.shape, generator=gen) * 0.6 + 0.5)
+        else:
+            b.copy_(torch.randn(b.shape, generator=gen) * 0.2)
+    for proj in model.input_proj:
+        proj[0].bias.data.copy_(torch.randn(proj[0].bias.shape, generator=gen) * 0.3)
+        proj[1].weight.data.copy_(torch.rand(proj[1].weight.shape, generator=gen) + 0.5)
+        proj[1].bias.data.copy_(torch.randn(proj[1].bias.shape, generator=gen) * 0.3)
+    sd = {k: v.detach().double().cpu() for k, v in model.state_dict().items()}
+    return to_mi355x_layout(model.cuda()), sd
+
+
+def _reference(sd, name, x):
+    """float64, plain PyTorch functions only."""
+    def conv_bn(x, conv, bn, stride, padding):
+        y = F.conv2d(x, sd[conv + ".weight"], None, stride, padding)
+        scale = sd[bn + ".weight"] / torch.sqrt(sd[bn + ".running_var"] + 1e-5)             # FrozenBatchNorm2d, backbone.py:52-65
+        shift = sd[bn + ".bias"] - sd[bn + ".running_mean"] * scale
+        return y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+
+    p = "backbone.0.body."
+    x = F.relu(conv_bn(x, p + "conv1", p + "bn1", 2, 3))
+    x = F.max_pool2d(x, 3, 2, 1)
+    feats = []
+    for li, blocks in enumerate(DEPTHS[name], start=1):
+        for b in range(blocks):
+            q = "%slayer%d.%d." % (p, li, b)
+            stride = 2 if (b == 0 and li > 1) else 1                                         # v1.5: the 3x3 carries the stride
+            out = F.relu(conv_bn(x, q + "conv1", q + "bn1", 1, 0))
+            out = F.relu(conv_bn(out, q + "conv2", q + "bn2", stride, 1))
+            out = conv_bn(out, q + "conv3", q + "bn3", 1, 0)
+            idt = conv_bn(x, q + "downsample.0", q + "downsample.1", stride, 0) if (q + "downsample.0.weight") in sd else x
+            x = F.relu(out + idt)
+        if li >= 2:
+            feats.append(x)
+    srcs = []
+    for l in range(4):
+        src_in = feats[l] if l < 3 else feats[2]
+        k = "input_proj.%d." % l
+        y = F.conv2d(src_in, sd[k + "0.weight"], sd[k + "0.bias"], 1 if l < 3 else 2, 0 if l < 3 else 1)
+        srcs.append(F.group_norm(y, 32, sd[k + "1.weight"], sd[k + "1.bias"], 1e-5))
+    return feats, srcs
+
+
+def _sine_reference(B, H, W, num_pos_feats=128, temperature=10000.0):
+    """All-valid mask: the counts are 1..H / 1..W, normalised by the last one + 1e-6 and scaled by 2 pi."""
+    y = torch.arange(1, H + 1, dtype=torch.float64) / (H + 1e-6) * 2 * math.pi
+    x = torch.arange(1, W + 1, dtype=torch.float64) / (W + 1e-6) * 2 * math.pi
+    c = torch.arange(num_pos_feats, dtype=torch.float64)
+    period = temperature ** (2 * torch.floor(c / 2) / num_pos_feats)
+    even = (torch.arange(num_pos_feats) % 2 == 0)
+    ay, ax = y[:, None] / period, x[:, None] / period
+    ey = torch.where(even, ay.sin(), ay.cos())                      # [H, F]
+    ex = torch.where(even, ax.sin(), ax.cos())                      # [W, F]
+    pos = torch.cat([ey[:, None, :].expand(H, W, -1), ex[None, :, :].expand(H, W, -1)], -1)
+    return pos.permute(2, 0, 1)[None].expand(B, -1, -1, -1)
+
+
+def _rel(got, want):
+    return float((got.double().cpu() - want).abs().max() / want.abs().max())
+
+
+@pytest.mark.parametrize("name", ["resnet50", "resnet101"])
+@pytest.mark.parametrize("train", [False, True])
+def test_backbone_joiner_and_projections_equal_a_plain_float64_evaluation(name, train):
+    model, sd = _model(name)
+    model.train(train)
+    gen = torch.Generator().manual_seed(3)
+    images = torch.randn(2, 3, 96, 320, generator=gen)
+    want_feats, want_srcs = _reference(sd, name, images.double())
+    x = images.cuda().contiguous(memory_format=torch.channels_last)
+    with torch.set_grad_enabled(train):            # train: the trainable stages run the affine-in-kernel / forked-ReLU nodes
+        features, pos = model.backbone(x)
+        srcs, masks, pos = model.project_features(features, pos)
+    assert [tuple(f.tensors.shape) for f in features] == [tuple(w.shape) for w in want_feats]
+    for l, (f, w) in enumerate(zip(features, want_feats)):
+        assert not f.mask.any()
+        assert _rel(f.tensors, w) <= 1e-4, ("C%d" % (l + 3), _rel(f.tensors, w))
+    assert len(srcs) == 4 and len(pos) == 4 and len(masks) == 4
+    for l, (s, w) in enumerate(zip(srcs, want_srcs)):
+        assert tuple(s.shape) == tuple(w.shape)
+        assert _rel(s, w) <= 1e-4, ("input_proj level %d" % l, _rel(s, w))
+        want_pos = _sine_reference(2, s.shape[2], s.shape[3])
+        assert tuple(pos[l].shape) == tuple(want_pos.shape)
+        assert _rel(pos[l], want_pos) <= 1e-5, ("sine position encoding level %d" % l, _rel(pos[l], want_pos))
+    if train:
+        # the fused nodes carry a gradient to the trainable stages and none to the frozen stem / layer1 (backbone.py:72-74)
+        sum(s.square().mean() for s in srcs).backward()
+        body = model.backbone[0].body
+        assert body.layer2[0].conv1.weight.grad is not None and torch.isfinite(body.layer4[-1].conv3.weight.grad).all()
+        assert body.conv1.weight.grad is None and body.layer1[0].conv1.weight.grad is None
