@@ -9,14 +9,19 @@ Canonical Object Space: depth labels scaled by canonical_focal_length / fu of th
 lib/datasets/kitti/kitti_utils.py (Object3d :13-52, Calibration :137-330, affine helpers :332-388).  The same layout is
 what the converters k360_to_k.py / waymo_to_kitti_projected.py write.
 
-Not carried over (all off in the shipped configs and tied to files of the pseudo-label pipeline): `use_add_data` (per-car
-masks / lidar in dill+zstd), `use_depth`, `output_lidar`, `aug_pd` (OpenCV colour jitter) -- they raise.
+`aug_pd` (photometric distortion, lib/datasets/kitti/pd.py:114-416, ON in the reference's shipped mixed-dataset config
+checkpoints/best_kitti_k360_to_kitti/monodetr_kk360_05.yaml:18): monosowa_amd/photometric.py.
+
+Not carried over (off in both shipped configs and tied to files of the pseudo-label pipeline): `use_add_data` (per-car
+masks / lidar in dill+zstd), `use_depth`, `output_lidar` -- they raise.
 """
 import os
 
 import numpy as np
 import torch.utils.data as data
 from PIL import Image, ImageFile
+
+from .photometric import PhotometricDistort
 
 ImageFile.LOAD_TRUNCATED_IMAGES = True
 
@@ -180,9 +185,12 @@ class KITTI_Dataset(data.Dataset):
             self.writelist.extend(["Van", "Truck"])
         if cfg.get("use_dontcare", False):
             self.writelist.extend(["DontCare"])
-        for key in ("use_add_data", "use_depth", "output_lidar", "aug_pd"):
+        for key in ("use_add_data", "use_depth", "output_lidar"):
             if cfg.get(key, False):
-                raise NotImplementedError("dataset.%s needs the pseudo-label pipeline's side files / OpenCV and is off in the shipped configs" % key)
+                raise NotImplementedError("dataset.%s needs the pseudo-label pipeline's side files (per-car masks / lidar, depth maps) "
+                                          "and is off in both shipped configs" % key)
+        self.aug_pd = cfg.get("aug_pd", False)                       # on in checkpoints/.../monodetr_kk360_05.yaml:18
+        self.pd = PhotometricDistort()
         assert split in ["train", "val", "trainval", "test"]
         with open(os.path.join(self.root_dir, "ImageSets", split + ".txt")) as f:
             self.idx_list = [x.strip() for x in f.readlines()]
@@ -243,7 +251,9 @@ class KITTI_Dataset(data.Dataset):
         center = np.array(img_size) / 2
         crop_size, crop_scale = img_size, 1
         flipped = False
-        if self.data_augmentation:                                   # draw order of the reference: flip, crop?, scale, shift x, shift y
+        if self.data_augmentation:                                   # draw order of the reference: [photometric], flip, crop?, scale, shift x, shift y
+            if self.aug_pd:                                          # kitti_dataset.py:182-185
+                img = Image.fromarray(self.pd(np.array(img).astype(np.float32)).astype(np.uint8))
             if np.random.random() < self.random_flip:
                 flipped = True
                 img = img.transpose(Image.FLIP_LEFT_RIGHT)

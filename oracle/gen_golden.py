@@ -3,7 +3,7 @@
 Run in the build container only (``/root/reference`` does not exist on the GPU box):
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [msda] [module] [transformer] [depth] [misc]
-                                                       [adamw] [decode] [criterion] [heads] [kitti_eval] [kitti_dataset]
+                                                       [adamw] [decode] [criterion] [heads] [kitti_eval] [kitti_dataset] [kitti_dataset_pd]
 
 The reference tree is imported read-only, unmodified.  Third-party symbols that are absent
 from this image are shimmed (never reference code): the unbuilt CUDA extension module
@@ -803,6 +803,91 @@ def gen_kitti_dataset():
                               "scale_depth", "flip"):
                         out[key + "info_" + k] = np.asarray(info[k])
     _save("kitti_dataset", **out)
+
+
+def _cv2_color_shim():
+    """cv2.cvtColor(float32 image, COLOR_BGR2HSV | COLOR_HSV2BGR) for pd.py:159-165, restated from OpenCV's DOCUMENTED float
+    definition (imgproc "Color conversions", RGB <-> HSV: V = max, S = (V - min) / V or 0, H = 60 (G - B) / (V - min) | 120 + 60
+    (B - R) / (V - min) | 240 + 60 (R - G) / (V - min), + 360 if negative; inverse by hue sector) -- OpenCV itself is absent
+    from this image, so the photometric fixture is pinned to the published formula, not to OpenCV's binaries."""
+    cv2 = sys.modules["cv2"]
+    cv2.COLOR_BGR2HSV, cv2.COLOR_HSV2BGR = 40, 54
+
+    def cvt(img, code):
+        img = np.asarray(img, dtype=np.float32)
+        f = np.float32
+        if code == cv2.COLOR_BGR2HSV:
+            b, g, r = img[..., 0], img[..., 1], img[..., 2]
+            v = np.maximum(np.maximum(b, g), r)
+            d = v - np.minimum(np.minimum(b, g), r)
+            s = np.where(v != 0, d / np.where(v != 0, v, f(1)), f(0)).astype(np.float32)
+            k = (f(60) / np.where(d != 0, d, f(1))).astype(np.float32)
+            h = np.where(v == r, (g - b) * k, np.where(v == g, f(120) + (b - r) * k, f(240) + (r - g) * k))
+            h = np.where(d != 0, h, f(0)).astype(np.float32)
+            h = np.where(h < 0, h + f(360), h).astype(np.float32)
+            return np.stack([h, s, v], -1)
+        assert code == cv2.COLOR_HSV2BGR
+        h, s, v = img[..., 0], img[..., 1], img[..., 2]
+        hh = (h / f(60)).astype(np.float32)
+        hh = hh - f(6) * np.floor(hh / f(6))
+        sec = np.floor(hh)
+        fr = (hh - sec).astype(np.float32)
+        sec = sec.astype(np.int64) % 6
+        p_, q_, t_ = v * (f(1) - s), v * (f(1) - s * fr), v * (f(1) - s * (f(1) - fr))
+        r = np.choose(sec, [v, q_, p_, p_, t_, v])
+        g = np.choose(sec, [t_, v, v, q_, p_, p_])
+        b = np.choose(sec, [p_, p_, t_, v, v, q_])
+        return np.stack([b, g, r], -1).astype(np.float32)
+    cv2.cvtColor = cvt
+
+
+def gen_kitti_dataset_pd():
+    """The reference KITTI_Dataset with the dataset section of its shipped mixed-dataset config (checkpoints/
+    best_kitti_k360_to_kitti/monodetr_kk360_05.yaml: aug_pd + aug_crop on, canonical focal length 1000) on the synthetic
+    KITTI directory of gen_kitti_dataset (same files: they travel in kitti_dataset.npz), and the reference PhotometricDistort
+    (pd.py:398-416) alone on a seeded float image."""
+    import importlib
+    import tempfile
+    import yaml
+    _dataset_shims()
+    _cv2_color_shim()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    mod = importlib.import_module("lib.datasets.kitti.kitti_dataset")
+    pdm = importlib.import_module("lib.datasets.kitti.pd")
+    files = _synthetic_kitti_files(np.random.default_rng(777), [3, 7, 12, 25, 31, 40])
+    shipped = yaml.safe_load(open(os.path.join(REF, "checkpoints", "best_kitti_k360_to_kitti", "monodetr_kk360_05.yaml")))["dataset"]
+    cfg = {k: v for k, v in shipped.items() if k not in ("root_dir", "type", "batch_size", "train_split", "test_split")}
+    assert cfg.get("aug_pd") is True and cfg.get("aug_crop") is True
+    out = {"cfg_json": np.array(__import__("json").dumps(cfg))}
+    # (a) the distortion alone: every branch combination shows up within 24 seeds
+    rng = np.random.default_rng(5)
+    image = (rng.uniform(0, 255, (24, 40, 3))).astype(np.float32)
+    image[0, :4] = [[0, 0, 0], [255, 255, 255], [10, 10, 200], [200, 10, 10]]       # grey / saturated corner cases
+    out["pd_image"] = image
+    pd = pdm.PhotometricDistort()
+    for seed in range(24):
+        np.random.seed(1000 + seed)
+        out["pd_out_%02d" % seed] = np.asarray(pd(image), dtype=np.float32)
+    # (b) whole train samples
+    with tempfile.TemporaryDirectory() as root:
+        for name, blob in files.items():
+            os.makedirs(os.path.dirname(os.path.join(root, name)), exist_ok=True)
+            with open(os.path.join(root, name), "wb") as f:
+                f.write(blob)
+        ds = mod.KITTI_Dataset("train", dict(cfg, root_dir=root))
+        for seed in (21, 22):
+            for item in range(len(ds)):
+                np.random.seed(seed * 100 + item)
+                img, P2, targets, info = ds[item]
+                key = "train_s%d_i%d__" % (seed, item)
+                out[key + "img_sub"] = np.ascontiguousarray(img[:, ::8, ::8])
+                out[key + "img_sum"] = np.float64(img.astype(np.float64).sum())
+                out[key + "P2"] = np.asarray(P2)
+                for k in ("boxes_3d", "depth", "mask_2d", "labels"):
+                    out[key + "t_" + k] = np.asarray(targets[k])
+                out[key + "info_flip"] = np.asarray(info["flip"])
+    _save("kitti_dataset_pd", **out)
 
 
 def importlib_misc():

@@ -65,9 +65,55 @@ def test_loader_batches_feed_the_training_step_contract(kitti_root):
     assert len(train_loader.dataset) == len(g["ids"])
 
 
+def test_photometric_distortion_equals_the_reference_class(golden_dir):
+    """monosowa_amd.photometric.PhotometricDistort against the reference class (pd.py:398-416, run by oracle/gen_golden.py
+    kitti_dataset_pd with cv2.cvtColor restated from OpenCV's documented float formulas) on a seeded image under 24 numpy
+    seeds: same draws in the same order, same floats."""
+    from monosowa_amd.photometric import PhotometricDistort
+    g = np.load(os.path.join(golden_dir, "kitti_dataset_pd.npz"), allow_pickle=False)
+    pd = PhotometricDistort()
+    image = g["pd_image"]
+    changed = permuted = 0
+    for seed in range(24):
+        np.random.seed(1000 + seed)
+        out = pd(image)
+        ref = g["pd_out_%02d" % seed]
+        assert out.dtype == np.float32 and out.shape == ref.shape
+        assert np.array_equal(out, ref), (seed, float(np.abs(out - ref).max()))
+        changed += int(not np.array_equal(ref, image))
+        permuted += int(np.abs(ref[..., 0] - image[..., 0]).mean() > 40)
+    assert changed >= 20 and permuted >= 1 and np.array_equal(image, g["pd_image"])      # branches taken; the input is not modified
+
+
+def test_shipped_mixed_dataset_config_constructs_and_matches_the_reference(kitti_root, golden_dir):
+    """The dataset section of the reference's shipped mixed-dataset config (checkpoints/best_kitti_k360_to_kitti/
+    monodetr_kk360_05.yaml: aug_pd and aug_crop on, canonical focal length 1000) builds a KITTI_Dataset here, and its train
+    samples equal the reference class's: image (strided sample exactly, sum to 1e-9), intrinsics, box / depth targets."""
+    from monosowa_amd.kitti_dataset import KITTI_Dataset
+    _, base = kitti_root
+    g = np.load(os.path.join(golden_dir, "kitti_dataset_pd.npz"), allow_pickle=False)
+    cfg = dict(json.loads(str(g["cfg_json"])), root_dir=base["root_dir"])
+    assert cfg["aug_pd"] is True and cfg["aug_crop"] is True
+    ds = KITTI_Dataset("train", cfg)
+    n = 0
+    for seed in (21, 22):
+        for item in range(len(ds)):
+            np.random.seed(seed * 100 + item)
+            img, P2, targets, info = ds[item]
+            key = "train_s%d_i%d__" % (seed, item)
+            assert np.array_equal(img[:, ::8, ::8], g[key + "img_sub"]), key
+            assert abs(img.astype(np.float64).sum() - float(g[key + "img_sum"])) <= 1e-9 * max(1.0, abs(float(g[key + "img_sum"])))
+            assert np.array_equal(np.asarray(P2), g[key + "P2"])
+            for k in ("boxes_3d", "depth", "mask_2d", "labels"):
+                assert np.array_equal(np.asarray(targets[k]), g[key + "t_" + k]), (key, k)
+            assert np.array_equal(np.asarray(info["flip"]), g[key + "info_flip"])
+            n += 1
+    assert n == 2 * len(ds)
+
+
 def test_unshipped_side_inputs_are_refused(kitti_root):
     from monosowa_amd.kitti_dataset import KITTI_Dataset
     _, cfg = kitti_root
-    for key in ("use_add_data", "use_depth", "output_lidar", "aug_pd"):
+    for key in ("use_add_data", "use_depth", "output_lidar"):
         with pytest.raises(NotImplementedError):
             KITTI_Dataset("val", dict(cfg, **{key: True}))
