@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 7
+#define MSDA_ABI_VERSION 8
 
 #define MSDA_E_NULLPTR (-1)   /* a required pointer is NULL                        */
 #define MSDA_E_SHAPE (-2)     /* a dimension is <= 0 or exceeds the indexing range */
@@ -155,6 +155,13 @@ int msda_fused_backward_strided_f32(const float *value, const int64_t *shapes, c
  * (2-d reference points on the self-attention shape); else use the v5 pair. */
 int msda_fused_save_supported(int S, int M, int D, int L, int Lq, int P, int ref_dim, const int64_t *shapes_host,
                               const int64_t *level_start_host);
+/* ABI v8: the same question for the VIEW entry points (msda_fused_forward_view_f32 with loc_save / msda_fused_backward_view_f32
+ * with saved = 1), whose value token stride and projection row strides also bound the kernels' 32-bit plane addressing: a value
+ * column block of a very wide projection (token stride > 4096 floats) is answered 0 here, and the caller takes the v7 pair that
+ * re-evaluates the prologue.  (msda_fused_save_supported() answers for dense operands.) */
+int msda_fused_save_supported_view(int S, int M, int D, int L, int Lq, int P, int ref_dim, int value_token_stride,
+                                   int offsets_row_stride, int logits_row_stride, const int64_t *shapes_host,
+                                   const int64_t *level_start_host);
 int msda_fused_forward_save_f32(const float *value, const int64_t *shapes, const int64_t *level_start,
                                 const float *offsets, const float *logits, const float *ref, int ref_dim, float *out,
                                 float *loc_save, float *attn_save, int B, int S, int M, int D, int L, int Lq, int P,

@@ -356,7 +356,9 @@ def fused_save_supported(value, spatial_shapes, level_start_index, Lq, ref_dim=2
     the self-attention shape (Lq == S) on the window / row-tile kernels."""
     B, S, M, D = value.shape
     geom = host_geometry(spatial_shapes, level_start_index)
-    return bool(_lib.load().msda_fused_save_supported(S, M, D, 4, Lq, 4, ref_dim, geom[0], geom[1]))
+    # ``value`` may be a column block of a wider projection: its token stride bounds the kernels' plane addressing too
+    return bool(_lib.load().msda_fused_save_supported_view(S, M, D, 4, Lq, 4, ref_dim, value.stride(1), M * 48, M * 48,
+                                                           geom[0], geom[1]))
 
 
 def ms_deform_attn_fused_forward_merged_save(value, spatial_shapes, level_start_index, proj, reference_points, value_mask=None):

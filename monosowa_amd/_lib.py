@@ -10,11 +10,11 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmonosowa_msda.so")
 SYMBOLS = ("msda_abi_version", "msda_strerror", "msda_set_option", "msda_backward_workspace_bytes",
            "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64",
            "msda_fused_forward_f32", "msda_fused_backward_f32", "msda_fused_forward_strided_f32",
-           "msda_fused_backward_strided_f32", "msda_fused_save_supported", "msda_fused_forward_save_f32", "msda_fused_forward_view_f32", "msda_fused_backward_view_f32",
+           "msda_fused_backward_strided_f32", "msda_fused_save_supported", "msda_fused_save_supported_view", "msda_fused_forward_save_f32", "msda_fused_forward_view_f32", "msda_fused_backward_view_f32",
            "msda_fused_backward_saved_f32")
 
 _lib = None
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class MSDALibraryError(RuntimeError):
@@ -56,6 +56,8 @@ def load():
     lib.msda_fused_backward_strided_f32.argtypes = [P] * 6 + [I] + [P] * 4 + [I] * 9 + [P, P, P, Z, P]
     lib.msda_fused_save_supported.restype = I
     lib.msda_fused_save_supported.argtypes = [I] * 7 + [P, P]
+    lib.msda_fused_save_supported_view.restype = I
+    lib.msda_fused_save_supported_view.argtypes = [I] * 10 + [P, P]
     lib.msda_fused_forward_save_f32.restype = I
     lib.msda_fused_forward_save_f32.argtypes = [P] * 6 + [I, P, P, P] + [I] * 9 + [P, P, P]
     lib.msda_fused_backward_saved_f32.restype = I

@@ -599,7 +599,9 @@ int msda_fused_forward_view_f32(const float *value, int value_token_stride, cons
   vv.token_stride = value_token_stride;
   vv.mask = value_mask;
   if (loc_save) {
-    if (!msda_fused_save_supported(S, M, D, L, Lq, P, ref_dim, shapes_host, level_start_host)) return MSDA_E_UNSUPPORTED;
+    if (!msda_fused_save_supported_view(S, M, D, L, Lq, P, ref_dim, value_token_stride, offsets_row_stride, logits_row_stride,
+                                        shapes_host, level_start_host))
+      return MSDA_E_UNSUPPORTED;
     launch_gather<false, true, true>(value, offsets, logits, nullptr, out, loc_save, attn_save, ref, ref_dim, shapes_host,
                                      level_start_host, B, S, M, Lq, (hipStream_t)stream, offsets_row_stride, logits_row_stride,
                                      nullptr, -1, vv);
@@ -622,7 +624,9 @@ int msda_fused_backward_view_f32(const float *value, int value_token_stride, con
   if (offsets_row_stride < M * 32 || logits_row_stride < M * 16 || (offsets_row_stride & 3) || (logits_row_stride & 3))
     return MSDA_E_SHAPE;
   if (value_token_stride < M * 32 || (value_token_stride & 3) || (long long)S * value_token_stride >= (1LL << 31)) return MSDA_E_SHAPE;
-  if (saved && !msda_fused_save_supported(S, M, D, L, Lq, P, ref_dim, shapes_host, level_start_host)) return MSDA_E_UNSUPPORTED;
+  if (saved && !msda_fused_save_supported_view(S, M, D, L, Lq, P, ref_dim, value_token_stride, offsets_row_stride, logits_row_stride,
+                                               shapes_host, level_start_host))
+    return MSDA_E_UNSUPPORTED;
   ValueView vv;
   vv.token_stride = value_token_stride;
   vv.mask = value_mask;
@@ -705,16 +709,23 @@ int msda_fused_backward_strided_f32(const float *value, const int64_t *shapes, c
 }
 
 // ---- ABI v6: the fused forward hands the backward the locations / weights it evaluated -------------------------------
-int msda_fused_save_supported(int S, int M, int D, int L, int Lq, int P, int ref_dim, const int64_t *shapes_host,
-                              const int64_t *level_start_host) {
+int msda_fused_save_supported_view(int S, int M, int D, int L, int Lq, int P, int ref_dim, int value_token_stride,
+                                   int offsets_row_stride, int logits_row_stride, const int64_t *shapes_host,
+                                   const int64_t *level_start_host) {
   // (the tile-window kernels evaluate the 2-d reference-point formula only; 6-d reference points stay on the v5 pair)
   if (!shapes_host || !level_start_host || !(D == 32 && L == 4 && P == 4) || M * L * 8 > 1024 || ref_dim != 2) return 0;
   if (check_host_geometry(shapes_host, level_start_host, L, S)) return 0;
   msda::RowPlan rp;
-  // (row strides: the entry points refuse strides beyond kWinMaxStride for the saved pair)
-  return options().scatter_rows && window_applies(true, shapes_host, level_start_host, Lq, S, M * 48) &&
-         window_applies(false, shapes_host, level_start_host, Lq, S, M * 48) &&
+  // the widest row stride the view entry points will address a plane with (their 32-bit lane offsets: window_fits())
+  const long long widest = std::max<long long>(std::max(offsets_row_stride, logits_row_stride), std::max(M * 32, value_token_stride));
+  return options().scatter_rows && window_applies(true, shapes_host, level_start_host, Lq, S, widest) &&
+         window_applies(false, shapes_host, level_start_host, Lq, S, widest) &&
          msda::make_row_plan(shapes_host, level_start_host, options().scatter_reach, rp) ? 1 : 0;
+}
+
+int msda_fused_save_supported(int S, int M, int D, int L, int Lq, int P, int ref_dim, const int64_t *shapes_host,
+                              const int64_t *level_start_host) {
+  return msda_fused_save_supported_view(S, M, D, L, Lq, P, ref_dim, M * 32, M * 48, M * 48, shapes_host, level_start_host);
 }
 
 int msda_fused_forward_save_f32(const float *value, const int64_t *shapes, const int64_t *level_start,

@@ -35,6 +35,18 @@ def wrap_ddp(model, device):
                                                      gradient_as_bucket_view=True, broadcast_buffers=False)
 
 
+_EVAL_WAIT_GROUP = []
+
+
+def wait_for_evaluation(timeout_hours=6.0):
+    """All ranks meet here after rank 0's checkpoint / evaluation block: a barrier on a dedicated gloo group (host-side, created
+    on first use by every rank at the same point of the epoch loop) whose timeout covers a whole KITTI val inference + AP run."""
+    import datetime
+    if not _EVAL_WAIT_GROUP:
+        _EVAL_WAIT_GROUP.append(torch.distributed.new_group(backend="gloo", timeout=datetime.timedelta(hours=timeout_hours)))
+    torch.distributed.monitored_barrier(group=_EVAL_WAIT_GROUP[0], timeout=datetime.timedelta(hours=timeout_hours))
+
+
 class Trainer(object):
     def __init__(self, cfg, model, optimizer, train_loader, test_loader, lr_scheduler, warmup_lr_scheduler,
                  logger, loss, model_name):
@@ -107,8 +119,10 @@ class Trainer(object):
                     self.logger.info("Best Result:{}, epoch:{}".format(best_result, best_epoch))
             if (self.epoch % self.cfg["save_frequency"]) == 0 and misc.is_dist_avail_and_initialized():
                 # rank 0 saved / evaluated alone: the other ranks wait here instead of inside the next epoch's first
-                # gradient all-reduce (where a long evaluation would run into the collective watchdog)
-                torch.distributed.barrier()
+                # gradient all-reduce.  The wait runs on its own gloo group with a timeout sized for a full validation pass
+                # (the default group's collective timeout -- 10 minutes under RCCL -- would abort a long evaluation just the
+                # same, only inside this barrier)
+                wait_for_evaluation()
             bar.update()
         self.logger.info("Best Result:{}, epoch:{}".format(best_result, best_epoch))
         return None

@@ -68,7 +68,19 @@ def match_groups(cost, sizes, group_num, padded=False):
     return out
 
 
-N_THREADS = max(1, min(8, (os.cpu_count() or 1) // 2))      # persistent pool in the library: 0.13 ms for the 528 problems of a train step (4 threads: 0.21)
+def _default_threads():
+    """Host threads of the assignment pool: 8 (0.13 ms for the 528 problems of a train step; 4 threads: 0.21), capped by this
+    rank's SHARE of the host's cores -- under torch.distributed.run every rank of the node has its own pool (8 ranks x 8 threads
+    next to 8 x OMP would oversubscribe the cores the matcher's wait sits on)."""
+    cores = os.cpu_count() or 1
+    try:
+        ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        ranks = 1
+    return max(1, min(8, cores // (2 * ranks)))
+
+
+N_THREADS = _default_threads()
 
 
 _pinned = {}

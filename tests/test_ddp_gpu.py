@@ -74,7 +74,9 @@ for it in range(2):                            # second iteration: bucket views 
     noise, worst = deviation(ga, gc), deviation(ga, gb)
     # DDP adds nothing beyond the step's own nondeterminism.  The per-tensor maximum over ~300 tensors is heavy-tailed (a few
     # tensors with tiny gradients carry all of it), hence the factor; the L2 distance of the whole gradient is the tight check
-    assert worst <= max(5e-2, 10 * noise), (worst, noise)      # (a tensor that missed the reduction would be off by O(1))
+    # (at world size 1 the all-reduce is an identity: this variant rehearses reducer x fused nodes x bucket views x AdamW, it cannot
+    # see a tensor that missed the reduction -- the two-rank variant below checks that per tensor)
+    assert worst <= max(5e-2, 10 * noise), (worst, noise)
     l2 = lambda a, b: (torch.cat([(a[n] - b[n]).reshape(-1) for n in a]).norm() / torch.cat([a[n].reshape(-1) for n in a]).norm()).item()
     assert l2(ga, gb) <= 2e-3 + 3 * l2(ga, gc), (l2(ga, gb), l2(ga, gc))
     opt_a.step(); opt_c.step(); opt_b.step()
@@ -172,6 +174,17 @@ noise, worst = deviation(local_a, local_b), deviation(mean, synced)
 # of a relative deviation is heavy-tailed run-to-run noise; a tensor that missed the reduction would be off by O(1)); the
 # tight check is the L2 distance of the whole gradient against the step's own run-to-run noise
 assert worst <= max(5e-2, 10 * noise), (worst, noise)
+# ... and PER TENSOR, whatever its size: a parameter the reducer skipped would come back with this rank's LOCAL gradient, i.e.
+# as far from the mean as local_a is (the ranks saw different images); every synchronised tensor must be several times closer
+# to the mean than that, up to the tensor's own run-to-run noise
+missed = []
+for n in names:
+    d_sync = (synced[n] - mean[n]).norm().item()
+    d_local = (local_a[n] - mean[n]).norm().item()
+    noise_n = (local_a[n] - local_b[n]).norm().item()
+    if d_sync > 0.2 * d_local + 3.0 * noise_n + 1e-12:
+        missed.append((n, d_sync, d_local, noise_n))
+assert not missed, missed[:5]
 l2 = lambda a, b: (torch.cat([(a[n] - b[n]).reshape(-1) for n in a]).norm() / torch.cat([a[n].reshape(-1) for n in a]).norm()).item()
 own = torch.tensor([l2(local_a, local_b)])
 noises = [torch.zeros(1) for _ in range(world)]
@@ -204,19 +217,33 @@ def test_two_ranks_on_one_gpu_allreduce_the_fused_steps_gradients(tmp_path):
         port = s.getsockname()[1]
     script = tmp_path / "ddp_ws2.py"
     script.write_text(WORKER2)
-    procs = []
+    procs, logs = [], []
     for rank in range(2):
         env = dict(os.environ, MONOSOWA_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2",
                    LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = []
+        # output to files: a pipe nobody drains fills at 64 KB and blocks its writer inside the next collective
+        out, err = open(tmp_path / ("rank%d.out" % rank), "w+"), open(tmp_path / ("rank%d.err" % rank), "w+")
+        logs.append((out, err))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=out, stderr=err, text=True))
+    timed_out = False
     for p in procs:
         try:
-            outs.append(p.communicate(timeout=900))
+            p.wait(timeout=900)
         except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            pytest.fail("DDP world-size-2 workers timed out", pytrace=False)
+            timed_out = True
+            break
+    if timed_out:
+        for q in procs:
+            q.kill()
+        for q in procs:
+            q.wait()
+    outs = []
+    for out, err in logs:
+        out.seek(0); err.seek(0)
+        outs.append((out.read(), err.read()))
+        out.close(); err.close()
+    if timed_out:
+        pytest.fail("DDP world-size-2 workers timed out\n" + "\n".join(e[-3000:] for _, e in outs), pytrace=False)
     if any(p.returncode != 0 for p in procs) or "ddp-ws2 ok" not in outs[0][0]:
         pytest.fail("DDP world-size-2 worker failed\n" + "\n".join("--- rank %d (rc %s) ---\n%s\n%s" % (i, procs[i].returncode, o[-1500:], e[-5000:])
                                                                      for i, (o, e) in enumerate(outs)), pytrace=False)
