@@ -415,7 +415,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
           reach = directional ? std::max(options().scatter_reach, options().plan_reach) : options().scatter_reach;
           plan_b = directional ? align256(msda::plan_bytes(M)) : 0;
           stats_b = directional ? align256(msda::plan_stats_bytes(M) * msda::kStatsBlocks) : 0;
-          ok = msda::make_row_plan(shapes_host, lsi_host, reach, rp) &&
+          ok = msda::make_row_plan(shapes_host, lsi_host, reach, rp) && (!directional || rp.n_items <= msda::kPlanMaxItems) &&
                plan_b + stats_b + msda::row_plan_table_bytes(rp) * (directional ? M : 1) <= workspace_bytes;
           if (!ok) { if (!directional) break; directional = false; }
         }

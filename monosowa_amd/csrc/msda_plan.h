@@ -42,6 +42,20 @@ struct DirStats {
   unsigned long long sq_y, sq_x;
 };
 
+// One work item of the row-tile scatter, ready to use: a workgroup reads its descriptor with one (scalar) load instead of
+// walking first_item -> order -> n_chunks -> two axis records -> candidate counts, each a dependent global load (phase clocks:
+// that chain was 35 % of the scatter's wave time -- its workgroups live for three or four batches only).
+struct RowItem {
+  short level, chunk, n_chunks, pad0;
+  short y0, th, x0, tw;                    // the tile's output rows
+  int c_begin, c_end;                      // this chunk's candidates within the tile's scan list
+  int cand_off;                            // the tile's scan list: table[head * cand_total + cand_off ...)
+  int pad1;
+  DirBounds near;                          // the head's near-bounds at this level
+  int pad2[2];
+};
+constexpr int kPlanMaxItems = 768;         // per head; a pyramid with more items keeps the isotropic host plan
+
 // Everything the kernels read for one head.
 struct HeadPlan {
   DirBounds win[kWinLevels];               // window bounds after fitting the LDS budget
@@ -54,6 +68,7 @@ struct HeadPlan {
   AxisSpec wax[kWinMaxAxisTiles][kWinLevels];            // [0, n_ty): rows of tiles, [n_ty, n_ty + n_tx): columns of tiles
   AxisSpec wax2[kWinMaxAxisTiles / 2][kWinLevels];       // merged column pairs
   RowAxis rax[kRowMaxAxisTiles];
+  RowItem items[kPlanMaxItems];
 };
 
 // Static inputs of the plan kernel (kernel argument).

@@ -311,6 +311,28 @@ __global__ __launch_bounds__(256) void dir_plan_kernel(const DirStats *__restric
     }
     hp.n_items = hp.first_item[4];
   }
+  __syncthreads();
+  // the items, ready to use (RowItem): what scatter_rows_kernel would otherwise derive with a chain of dependent loads
+  const int n_items = min(hp.n_items, kPlanMaxItems);
+  for (int it = tid; it < n_items; it += 256) {
+    int oi = 0;
+    while (oi < 3 && it >= hp.first_item[oi + 1]) ++oi;
+    const int l = hp.order[oi], local = it - hp.first_item[oi], nc = hp.n_chunks[l];
+    const int chunk = local % nc, tile = local / nc;
+    const int ty = tile / rp.n_tx[l], tx = tile - ty * rp.n_tx[l];
+    const RowAxis ay = s_rax[rp.axis0[l] + ty], ax = s_rax[rp.axis0[l] + rp.n_ty[l] + tx];
+    int n_cand = 0;
+#pragma unroll
+    for (int lq = 0; lq < 4; ++lq) n_cand += (int)ay.qn[lq] * (int)ax.qn[lq];
+    RowItem d{};
+    d.level = (short)l; d.chunk = (short)chunk; d.n_chunks = (short)nc;
+    d.y0 = ay.r0; d.th = ay.rn; d.x0 = ax.r0; d.tw = ax.rn;
+    d.c_begin = (int)((long long)n_cand * chunk / nc);
+    d.c_end = (int)((long long)n_cand * (chunk + 1) / nc);
+    d.cand_off = rp.cand_base[l] + tile * rp.cand_stride[l];
+    d.near = s_near[l];
+    hp.items[it] = d;
+  }
 }
 
 }  // namespace msda

@@ -96,29 +96,39 @@ __global__ __launch_bounds__(kRowThreads, 4) void scatter_rows_kernel(
   const int it = (int)((blockIdx.x / 8) % p.n_items);
   const int b = bm / M, m = bm - b * M;
   const HeadPlan *hp = plans ? plans + m : nullptr;
-  if (hp && it >= hp->n_items) return;
-  const int *first_item = hp ? hp->first_item : p.first_item;
-  int oi = 0;
-  while (oi < 3 && it >= first_item[oi + 1]) ++oi;
-  const int l = hp ? hp->order[oi] : p.order[oi];
-  const int local = it - first_item[oi];
-  const int n_chunks = hp ? hp->n_chunks[l] : p.n_chunks[l];
-  const int chunk = local % n_chunks, tile = local / n_chunks;
-  const int ty = tile / p.n_tx[l], tx = tile - ty * p.n_tx[l];
-  const RowAxis *axes = hp ? hp->rax : p.ax;
-  const RowAxis ay = axes[p.axis0[l] + ty], ax = axes[p.axis0[l] + p.n_ty[l] + tx];
-  // near <=> the footprint's top-left pixel lies inside the head's bounds around the query's centre floor
-  DirBounds nb;
-  if (hp) nb = hp->near[l]; else { nb.ylo = nb.xlo = (short)-p.reach; nb.yhi = nb.xhi = (short)p.reach; }
+  int l, n_chunks, y0, th, x0, tw, c_begin, c_end;
+  const RowCandidate *cands;
+  DirBounds nb;              // near <=> the footprint's top-left pixel lies inside these bounds around the query's centre floor
+  if (hp) {
+    // planned call: ONE descriptor (msda_plan.h: RowItem)
+    if (it >= hp->n_items) return;
+    const RowItem d = hp->items[it];
+    l = d.level; n_chunks = d.n_chunks;
+    y0 = d.y0; th = d.th; x0 = d.x0; tw = d.tw;
+    c_begin = d.c_begin; c_end = d.c_end;
+    cands = table + (long long)m * p.cand_total + d.cand_off;
+    nb = d.near;
+  } else {
+    int oi = 0;
+    while (oi < 3 && it >= p.first_item[oi + 1]) ++oi;
+    l = p.order[oi];
+    const int local = it - p.first_item[oi];
+    n_chunks = p.n_chunks[l];
+    const int chunk = local % n_chunks, tile = local / n_chunks;
+    const int ty = tile / p.n_tx[l], tx = tile - ty * p.n_tx[l];
+    const RowAxis ay = p.ax[p.axis0[l] + ty], ax = p.ax[p.axis0[l] + p.n_ty[l] + tx];
+    nb.ylo = nb.xlo = (short)-p.reach; nb.yhi = nb.xhi = (short)p.reach;
+    y0 = ay.r0; x0 = ax.r0; th = ay.rn; tw = ax.rn;                    // the tile's output rows
+    int n_cand = 0;
+#pragma unroll
+    for (int lq = 0; lq < 4; ++lq) n_cand += (int)ay.qn[lq] * (int)ax.qn[lq];
+    c_begin = (int)((long long)n_cand * chunk / n_chunks);
+    c_end = (int)((long long)n_cand * (chunk + 1) / n_chunks);
+    cands = table + p.cand_base[l] + (long long)tile * p.cand_stride[l];
+  }
   const int H = p.H[l], W = p.W[l];
-  const int y0 = ay.r0, x0 = ax.r0, th = ay.rn, tw = ax.rn;          // the tile's output rows
   const int cw = tw + 1, n_cells = (th + 1) * cw;                    // its cells: one more row above, one more column to the left
   constexpr int cap = kRowCellCap, bstride = kRowCellCap + 1;        // (odd stride in 2-byte units: the buckets start on different banks)
-  int n_cand = 0;
-#pragma unroll
-  for (int lq = 0; lq < 4; ++lq) n_cand += (int)ay.qn[lq] * (int)ax.qn[lq];
-  const int c_begin = (int)((long long)n_cand * chunk / n_chunks), c_end = (int)((long long)n_cand * (chunk + 1) / n_chunks);
-  const RowCandidate *cands = table + (hp ? (long long)m * p.cand_total : 0) + p.cand_base[l] + (long long)tile * p.cand_stride[l];
 
   const int tid = threadIdx.x;
   const int slot0 = tid >> 2, pt = tid & 3;                // scan role: candidate slots slot0, slot0 + 128 of the batch; point
