@@ -381,13 +381,43 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
 #pragma unroll
       for (int s = 0; s < 4; ++s) vv[s] = *reinterpret_cast<const float4 *>(wbytes + (o ^ ((4 * h + s) * 16)));
     };
-    const bool outside = out_pts != 0;
     // value token of corner c of this lane's point k2, -1 for a corner the reference drops (cold path: re-derived)
     auto outside_token = [&](const int k2, const int c) {
       const Tap<float> tp = make_tap<float>(k2 ? l4.z : l4.x, k2 ? l4.w : l4.y, Hm, Wm);
       const bool keep = ((c & 2) ? tp.b : tp.t) && ((c & 1) ? tp.r : tp.l);
       return keep ? start_m + ((c & 2) ? tp.y1 : tp.y0) * Wm + ((c & 1) ? tp.x1 : tp.x0) : -1;
     };
+
+    // Serves the wave's outside points slot by slot (lane-in-pair j, point k2): `add(k2, c, weight, slot data)` for each kept
+    // corner c with this lane's 16-byte share of the corner row, then `done(j, k2)`.  Wave-uniform control flow.
+    auto fixup_outside = [&](auto add, auto done) {
+#pragma unroll 1
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const bool mine = sub == j && (out_pts & (1 << k2));
+          if (!__any(mine)) continue;
+          const int src = ((lane & ~7) | j) << 2;                       // ds_bpermute address of the pair's lane j
+          int tk[4];
+          float wk[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int t_own = mine ? outside_token(k2, c) : -1;
+            tk[c] = __builtin_amdgcn_ds_bpermute(src, t_own);
+            wk[c] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(cw[k2][c])));
+          }
+          float4 x[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            x[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tk[c] >= 0) x[c] = ld4(value_bm + (long long)tk[c] * tok + 4 * rot);
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) add(k2, c, wk[c], x[c]);
+          done(j, k2);
+        }
+    };
+    auto fixup_nop = [](const int, const int) {};
 
     if (!BWD) {
       float4 acc[8];
@@ -428,27 +458,15 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
           }
         }
       MSDA_STAMP(5);
-      // corners outside their window (they read the zero row above): from global memory, one 16-byte slot at a time.  A pass
-      // of its own, so that its addresses and loads do not occupy registers across the row loops; skipped by a wave without
-      // such a corner (the usual case)
-      if (outside) {
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int token = (out_pts & (1 << k2)) ? outside_token(k2, c) : -1;
-            if (token >= 0) {
-              const float w = cw[k2][c];
-              const float *p = value_bm + (long long)token * tok;
-#pragma unroll
-              for (int s = 0; s < 8; ++s) {
-                const float4 x = ld4(p + 4 * (s ^ rot));
-                acc[s].x += w * x.x; acc[s].y += w * x.y; acc[s].z += w * x.z; acc[s].w += w * x.w;
-                asm volatile("" : "+v"(acc[s].x), "+v"(acc[s].y), "+v"(acc[s].z), "+v"(acc[s].w) : : "memory");
-              }
-            }
-          }
-      }
+      // points outside their window (their corners read the zero row above): from global memory, by the PAIR.  Every lane of
+      // a pair accumulates all 32 channels and the reduce-scatter below sums over the pair's lanes -- so any lane of the pair may
+      // add a share: the owner hands the point's four corner tokens and weights to its pair (ds_bpermute), lane i fetches the
+      // 16-byte slot its acc[0] stands for (slot `rot`: the pair's 8 lanes cover the 8 slots) of all four corner rows in ONE
+      // round trip.  (Round 2 let the owner lane fetch 4 x 8 slots one after the other, each waited for: 64 dependent global
+      // loads per wave as soon as ONE of its 128 points left its window -- 3 % of points outside cost the forward 60 %.)
+      if (__any(out_pts != 0)) fixup_outside([&](const int, const int, const float w, const float4 x) {
+        acc[0].x += w * x.x; acc[0].y += w * x.y; acc[0].z += w * x.z; acc[0].w += w * x.w;
+      }, fixup_nop);
       // reduce-scatter over the pair's 8 lanes.  acc[s] holds slot s ^ rot, so in a butterfly with partners sub ^ 7, sub ^ 2,
       // sub ^ 1 every lane keeps its low registers and receives the partner's registers of the same slots (no selects):
       // acc[0] ends as slot rot = channels 4 rot .. 4 rot + 3 summed over the pair -- a permutation of the pair's lanes, still
@@ -482,29 +500,48 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
         for (int s = 0; s < 8; ++s) gq[s] = *reinterpret_cast<const float4 *>(gow + ((s ^ rot) * 16));
         wave_lds_order();
       }
-      if (far_points) {
-        // far points (rare): their corner contributions w_corner attn_w grad_out[q, m, :] (cuh:125-152), which the row-tile
-        // scatter leaves out, with global atomics
+      if (__any(far_points != 0)) {
+        // far points: their corner contributions w_corner attn_w grad_out[q, m, :] (cuh:125-152), which the row-tile scatter
+        // leaves out, with global atomics -- by HALF-WAVES, lane = channel: one wave instruction adds two full 128-byte rows,
+        // the shape global float atomics run at full rate in (MI355X_MICROARCH.md, "Global float atomics").  Round 2 let the
+        // owner lane add its 4 x 32 values itself, 64 lanes in 64 different rows per instruction (17x slower): fine for a
+        // stray point, a cliff as soon as a trained layer puts a few per cent of its points beyond the scan bounds.
         float *gv = grad_value + ((long long)it.b * S * M + it.m) * 32;
+        const char *go_w = wbytes + kGoOff + wave * 1024;                 // the wave's eight grad_out rows (written above)
+        const int hw_half = lane >> 5, ch = lane & 31;
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
-          if (!(far_points & (1 << k2))) continue;
-          const float lx = k2 ? l4.z : l4.x, ly = k2 ? l4.w : l4.y, wt = k2 ? a2.y : a2.x;
-          const Tap<float> tp = make_tap<float>(lx, ly, Hm, Wm);
-          auto corner_add = [&](const int y, const int x, const bool keep, const float w) {
-            if (!keep || (MASKED && vmask[(long long)it.b * S + start_m + y * Wm + x])) return;
-            float *row_p = gv + (long long)(start_m + y * Wm + x) * (M * 32);      // grad_value is dense, whatever `vts` is
-            const float cwt = w * wt;
+          unsigned long long todo = __ballot((far_points >> k2) & 1);
+          if (!todo) continue;
+          int tkn[4] = {-1, -1, -1, -1};                                  // owner lanes: the point's corner tokens (-1: dropped / padded)
+          float cfs[4] = {0.f, 0.f, 0.f, 0.f};
+          if (far_points & (1 << k2)) {
+            const float lx = k2 ? l4.z : l4.x, ly = k2 ? l4.w : l4.y, wt = k2 ? a2.y : a2.x;
+            const Tap<float> tp = make_tap<float>(lx, ly, Hm, Wm);
+            auto corner = [&](const int c, const int y, const int x, const bool keep, const float w) {
+              const int t = start_m + y * Wm + x;
+              if (keep && !(MASKED && vmask[(long long)it.b * S + t])) { tkn[c] = t; cfs[c] = w * wt; }
+            };
+            corner(0, tp.y0, tp.x0, tp.t && tp.l, tp.w1);
+            corner(1, tp.y0, tp.x1, tp.t && tp.r, tp.w2);
+            corner(2, tp.y1, tp.x0, tp.b && tp.l, tp.w3);
+            corner(3, tp.y1, tp.x1, tp.b && tp.r, tp.w4);
+          }
+          while (todo) {                                                  // two points per trip: lower / upper half-wave
+            const int la = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            int lb = -1;
+            if (todo) { lb = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+            const int owner = hw_half ? lb : la;
+            const int src = owner >= 0 ? owner : lane;                    // (every lane takes part in the exchange)
+            const float g = *reinterpret_cast<const float *>(go_w + (src >> 3) * 128 + ch * 4);
 #pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) {
-              float *d4 = row_p + 4 * (s2 ^ rot);
-              atomicAdd(d4, cwt * gq[s2].x); atomicAdd(d4 + 1, cwt * gq[s2].y); atomicAdd(d4 + 2, cwt * gq[s2].z); atomicAdd(d4 + 3, cwt * gq[s2].w);
+            for (int c = 0; c < 4; ++c) {
+              const int t = __builtin_amdgcn_ds_bpermute(src << 2, tkn[c]);
+              const float cf = __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(cfs[c])));
+              if (owner >= 0 && t >= 0) atomicAdd(gv + (long long)t * (M * 32) + ch, cf * g);     // grad_value is dense, whatever `vts` is
             }
-          };
-          corner_add(tp.y0, tp.x0, tp.t && tp.l, tp.w1);
-          corner_add(tp.y0, tp.x1, tp.t && tp.r, tp.w2);
-          corner_add(tp.y1, tp.x0, tp.b && tp.l, tp.w3);
-          corner_add(tp.y1, tp.x1, tp.b && tp.r, tp.w4);
+          }
         }
       }
       float d[2][4];
@@ -546,22 +583,18 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
           d[k2][2] = sw_b ? d3 : d2; d[k2][3] = sw_b ? d2 : d3;
         }
       }
-      if (outside) {                                                      // see the forward
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
+      if (__any(out_pts != 0)) {                                          // see the forward; here: partial dot products of the lane's slot
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+        fixup_outside([&](const int, const int c, const float, const float4 x) {
+          part[c] = gq[0].x * x.x + gq[0].y * x.y + gq[0].z * x.z + gq[0].w * x.w;       // this lane's slot of corner c (gq[0] = slot rot)
+        }, [&](const int j, const int k2) {
+          // one served point done: the pair's partial sums -> the owner's corner dot products
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const int token = (out_pts & (1 << k2)) ? outside_token(k2, c) : -1;
-            if (token >= 0) {
-              const float *p = value_bm + (long long)token * tok;
-#pragma unroll
-              for (int s = 0; s < 8; ++s) {
-                const float4 x = ld4(p + 4 * (s ^ rot));
-                d[k2][c] += gq[s].x * x.x + gq[s].y * x.y + gq[s].z * x.z + gq[s].w * x.w;
-                asm volatile("" : "+v"(d[k2][c]) : : "memory");
-              }
-            }
+            const float tot = group_sum(part[c]);
+            if (sub == j) { if (k2 == 0) d[0][c] += tot; else d[1][c] += tot; }
           }
+        });
       }
       if (MASKED && padded) {
 #pragma unroll

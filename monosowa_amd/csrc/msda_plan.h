@@ -21,6 +21,13 @@
 namespace msda {
 
 constexpr int kPlanMaxHeads = 32;        // M * L * 8 <= 1024 threads in the d32 kernels
+#ifndef MSDA_PLAN_SIGMAS
+#define MSDA_PLAN_SIGMAS 3.0f
+#endif
+// bounds = [min, max] of the sampled d, cut at mean +- this many standard deviations: the scan (and window) area grows with the
+// square of the bounds, the points beyond them (0.3 % per axis of a normal distribution at 3 sigma) take the full-rate atomic /
+// global-load paths of the gather kernel
+constexpr float kPlanSigmas = MSDA_PLAN_SIGMAS;
 constexpr int kPlanClip = 64;            // |d| is clipped here before it enters the statistics
 constexpr int kPlanSamples = 256;        // sampled queries per batch element (of Lq): >= 16 k points per (head, level) at B = 16
 

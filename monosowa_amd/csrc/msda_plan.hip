@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void dir_plan_kernel(const DirStats *__restric
   __shared__ int s_rows_max, s_cand_max[4], s_q_max;
   HeadPlan &hp = plans[m];
 
-  // ---- A. bounds: [min, max] of the sample, cut at mean +- 4 sigma (one stray point must not size every window) ----------------
+  // ---- A. bounds: [min, max] of the sample, cut at mean +- kPlanSigmas sigma (one stray point must not size every window) ------
   // (the partial records are summed by all threads: one dependent global load per thread instead of n_partial per level)
   __shared__ int s_acc[4][8];                    // n, up_y, dn_y, up_x, dn_x, sum_y, sum_x, -
   __shared__ unsigned long long s_sq[4][2];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void dir_plan_kernel(const DirStats *__restric
     } else {
       my = (float)sy / (float)n; mx = (float)sx / (float)n;
       const float vy = fmaxf((float)qy / (float)n - my * my, 0.f), vx = fmaxf((float)qx / (float)n - mx * mx, 0.f);
-      const float dy = 4.f * sqrtf(vy) + 0.5f, dx = 4.f * sqrtf(vx) + 0.5f;
+      const float dy = kPlanSigmas * sqrtf(vy) + 0.5f, dx = kPlanSigmas * sqrtf(vx) + 0.5f;
       b.ylo = (short)max(kPlanClip - dn_y, (int)floorf(my - dy)); b.yhi = (short)min(up_y - kPlanClip, (int)ceilf(my + dy));
       b.xlo = (short)max(kPlanClip - dn_x, (int)floorf(mx - dx)); b.xhi = (short)min(up_x - kPlanClip, (int)ceilf(mx + dx));
     }

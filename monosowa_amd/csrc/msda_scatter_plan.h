@@ -21,7 +21,10 @@ namespace msda {
 #endif
 constexpr int kRowTileRows = MSDA_ROW_CELLS;   // bilinear cells per tile: 512 threads = 128 cells x 4 lanes (8 channels x 4 corner sums each);
                                            // a tile of th x tw output rows has (th + 1) x (tw + 1) cells
-constexpr int kRowCellCap = 32;            // points one cell's bucket holds per batch and round
+#ifndef MSDA_ROW_CAP
+#define MSDA_ROW_CAP 32
+#endif
+constexpr int kRowCellCap = MSDA_ROW_CAP;  // points one cell's bucket holds per batch and round
 constexpr int kRowThreads = MSDA_ROW_THREADS;
 #ifndef MSDA_ROW_SUB
 #define MSDA_ROW_SUB 2

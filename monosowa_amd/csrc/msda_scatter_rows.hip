@@ -75,8 +75,11 @@ __global__ __launch_bounds__(256) void row_candidates_kernel(const RowPlan p, Ro
 
 // FUSED: `loc` / `attw` carry raw sampling offsets / attention logits, `ref` the reference points [B, Lq, 4, ref_dim].
 // LEVEL_MAJOR (not FUSED): `loc` / `attw` are the fused forward's saved tensors, [B, M, L, Lq, P(, 2)].
+#ifndef MSDA_ROW_WAVES
+#define MSDA_ROW_WAVES 4
+#endif
 template <bool FUSED, bool LEVEL_MAJOR = false>
-__global__ __launch_bounds__(kRowThreads, 4) void scatter_rows_kernel(
+__global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kernel(
     const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out,
     float *__restrict__ grad_value, const float *__restrict__ ref, int ref_dim, const RowCandidate *__restrict__ table,
     const RowPlan p, int B, int S, int M, int loc_rs, int aw_rs, const unsigned char *__restrict__ vmask = nullptr,

@@ -40,7 +40,10 @@ def make(B, kind, offsets, dev, seed=0):
         Lq = int(kind)
         ref = torch.cat([torch.rand(B, Lq, 1, 2, device=dev, generator=g).expand(B, Lq, L, 2),
                          torch.rand(B, Lq, 1, 4, device=dev, generator=g).expand(B, Lq, L, 4) * 0.2], -1).contiguous()
-    if offsets == "init":
+    if offsets.startswith("normal:"):
+        # isotropic learned drift of sigma pixels (of each sampled level) around the query's own pixel
+        off = float(offsets.split(":")[1]) * torch.randn(B, Lq, M, L, P, 2, device=dev, generator=g)
+    elif offsets == "init":
         th = torch.arange(M, dtype=torch.float32, device=dev) * (2.0 * math.pi / M)
         d = torch.stack([th.cos(), th.sin()], -1)
         d = d / d.abs().max(-1, keepdim=True)[0]
@@ -52,6 +55,63 @@ def make(B, kind, offsets, dev, seed=0):
     proj = torch.cat([off.reshape(B, Lq, M * 32), logits.reshape(B, Lq, M * 16)], -1).contiguous()
     go = torch.randn(B, Lq, M * D, device=dev, generator=g)
     return value, shapes, lsi, proj, ref, go
+
+
+def trained_projections(steps, dev):
+    """The [B, S, 384] sampling-offset | attention-logit projections of the three encoder layers after `steps` optimizer steps
+    on one synthetic batch (the loop of tools/overfit_check.py), captured at the fused operator's entry."""
+    import yaml
+    from monosowa_amd import miopen_tuning
+    miopen_tuning.use_shipped_db(0)
+    from monosowa_amd.helpers.model_helper import build_model, to_mi355x_layout
+    from monosowa_amd.helpers.optimizer_helper import build_optimizer
+    from monosowa_amd.monodetr.criterion import weighted_total
+    from monosowa_amd.synthetic import make_batch, prepare_targets
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "configs", "monodetr.yaml")))
+    torch.manual_seed(444)
+    model, crit = build_model(cfg["model"])
+    model = to_mi355x_layout(model.to(dev)).train()
+    crit.to(dev).train()
+    opt = build_optimizer(cfg["optimizer"], model)
+    inputs, calibs, targets, _ = make_batch(16, dev)
+    inputs = inputs.contiguous(memory_format=torch.channels_last)
+    for i in range(steps):
+        tl = prepare_targets(targets, 16)
+        opt.zero_grad(set_to_none=True)
+        weighted_total(crit(model(inputs, calibs, tl, targets["img_size"]), tl), crit.weight_dict).backward()
+        opt.step()
+    captured = []
+    real = MSDA.ms_deform_attn_fused_forward_merged_save
+
+    def spy(value, shapes, lsi, proj, ref, value_mask=None):
+        if proj.shape[1] == value.shape[1]:
+            captured.append((value.detach().clone(), proj.detach().clone(), ref.detach().clone()))
+        return real(value, shapes, lsi, proj, ref, value_mask)
+    MSDA.ms_deform_attn_fused_forward_merged_save = spy
+    try:
+        tl = prepare_targets(targets, 16)
+        model(inputs, calibs, tl, targets["img_size"])
+    finally:
+        MSDA.ms_deform_attn_fused_forward_merged_save = real
+    torch.cuda.synchronize()
+    del model, crit, opt
+    torch.cuda.empty_cache()
+    return captured
+
+
+def offset_statistics(proj, ref, M=8):
+    """What the kernels' plan sees: d = floor(loc * size - 0.5) - centre floor of the query's own pixel, per axis, over all
+    points: |d| quantiles and the share of points beyond the isotropic window (halo 5) / the scan capacity (8 px)."""
+    B, Lq, _ = proj.shape
+    off = proj[:, :, :M * 32].reshape(B, Lq, M, 4, 4, 2)
+    sizes = torch.tensor([[w, h] for h, w in LEVELS], dtype=torch.float32, device=proj.device)            # (W, H) per level
+    loc = ref[:, :, None, :, None, :] + off / sizes[None, None, None, :, None, :]
+    low = torch.floor(loc * sizes[None, None, None, :, None, :] - 0.5)
+    cen = torch.floor(ref[:, :, None, :, None, :] * sizes[None, None, None, :, None, :] - 0.5)
+    d = (low - cen).abs().amax(-1).flatten()
+    q = torch.quantile(d[:: max(1, d.numel() // 2000000)].float(), torch.tensor([0.5, 0.9, 0.99], device=d.device))
+    return {"abs_d_median_px": q[0].item(), "abs_d_p90_px": q[1].item(), "abs_d_p99_px": q[2].item(),
+            "beyond_window_halo5": (d > 5).float().mean().item(), "beyond_scan_reach8": (d > 8).float().mean().item()}
 
 
 def alg_bytes(B, S, M, D, L, P, Lq, bwd):
@@ -80,12 +140,40 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--kinds", default="enc,550")
-    ap.add_argument("--offsets", choices=["init", "uniform"], default="init")
+    ap.add_argument("--offsets", default="init",
+                    help="init (the module's initial pattern + N(0, 0.3) px), uniform (U(-4, 4) px), normal:<sigma px>, "
+                         "trained[:steps] (the encoder layers' projections of a model trained for that many steps on one synthetic "
+                         "batch, tools/overfit_check.py's loop; default 150)")
+    ap.add_argument("--sweep", default=None, help="comma-separated --offsets values: one table / JSON over all of them (encoder shape)")
     ap.add_argument("--recompute", action="store_true", help="ABI v5 pair (backward re-evaluates the prologue)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     res = {}
+    if a.sweep:
+        # one row per offset distribution, encoder shape: forward / backward time and what the plan sees
+        for spec in a.sweep.split(","):
+            cases = []
+            if spec.startswith("trained"):
+                steps = int(spec.split(":")[1]) if ":" in spec else 150
+                value, shapes, lsi, _, _, go = make(a.batch, "enc", "init", dev)
+                for i, (v, proj, ref) in enumerate(trained_projections(steps, dev)):
+                    cases.append(("%s/layer%d" % (spec, i), v.view(a.batch, -1, 8, 32).contiguous(), proj.contiguous(), ref.contiguous()))
+            else:
+                value, shapes, lsi, proj, ref, go = make(a.batch, "enc", spec, dev)
+                cases.append((spec, value, proj, ref))
+            for name, value, proj, ref in cases:
+                _, loc, attw = MSDA.ms_deform_attn_fused_forward_merged_save(value, shapes, lsi, proj, ref)
+                t_f = timeit(lambda: MSDA.ms_deform_attn_fused_forward_merged_save(value, shapes, lsi, proj, ref), a.warmup, a.iters)
+                t_b = timeit(lambda: MSDA.ms_deform_attn_fused_backward_merged_saved(value, shapes, lsi, loc, attw, ref, go), a.warmup, a.iters)
+                row = dict(offset_statistics(proj, ref), fwd_ms=t_f, bwd_ms=t_b)
+                res[name] = row
+                print("%-18s fwd %.3f ms  bwd %.3f ms  |d| p50 %.1f p90 %.1f p99 %.1f px  beyond halo 5: %.1f %%  beyond reach 8: %.1f %%"
+                      % (name, t_f, t_b, row["abs_d_median_px"], row["abs_d_p90_px"], row["abs_d_p99_px"],
+                         100 * row["beyond_window_halo5"], 100 * row["beyond_scan_reach8"]), flush=True)
+        if a.out:
+            json.dump(res, open(a.out, "w"), indent=1)
+        return
     for kind in a.kinds.split(","):
         value, shapes, lsi, proj, ref, go = make(a.batch, kind, a.offsets, dev)
         B, S, M, D = value.shape
