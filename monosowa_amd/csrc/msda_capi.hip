@@ -7,6 +7,7 @@
 #include "msda_kernels.hip"
 #include "msda_backward_tiled.hip"
 #include "msda_backward_sorted.hip"
+#include "msda_backward_bands.hip"
 #include "msda_gather_rec.hip"
 #include "msda_gather_win.hip"
 #include "msda_scatter_rows.hip"
@@ -62,6 +63,7 @@ struct Options {
   int scatter_reach = 6;       // its near-point reach in pixels (farther points: global atomics in the gather kernel)
   int directional = 1;         // 1 (default): per-head directional bounds measured on the call's own offsets (msda_plan.h) size the
                                // scatter's scan regions (and the windows); 0: isotropic reach / halo for every head
+  int scatter_bands = 1;       // 1 (default): row-band scatter (msda_backward_bands.hip) for short record lists (Lq <= 576: the decoder)
   int plan_reach = 8;          // capacity of the directional scan: |footprint - centre| beyond this many pixels is "far" in any case
   Options() {                                               // the environment is read ONCE, at first use
     if (const char *e = std::getenv("MSDA_GATHER")) gather = std::atoi(e);
@@ -75,6 +77,7 @@ struct Options {
     if (const char *e = std::getenv("MSDA_SCATTER_REACH")) scatter_reach = std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("MSDA_WINDOW_HALO")) window_halo = std::min(32, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("MSDA_DIRECTIONAL")) directional = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MSDA_SCATTER_BANDS")) scatter_bands = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSDA_PLAN_REACH")) plan_reach = std::min(16, std::max(1, std::atoi(e)));
   }
 };
@@ -491,15 +494,24 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       else
         msda::bwd_prep_kernel<4, false><<<(unsigned)(B * ws.n_chunks_per_list), M * L * 8, 0, stream>>>(
             loc, attw, grad_out, shapes, rec_hw, rec_aw, boxes, nullptr, 0, M, L, Lq, (int)ws.n_chunks_per_list, M * 32, M * 16);
-      msda::bwd_bounds_kernel<<<B * M, 256, 0, stream>>>(boxes, bounds, (int)(L * ws.n_chunks_per_list));
+      // short record lists (the decoder's cross-attention): the row-band scatter (msda_backward_bands.hip) -- every level written
+      // with plain stores, f32 sums in registers: no fixed-point bounds, no zero fill
+      msda::BandPlan bp;
+      const bool bands = options().scatter_bands && options().scatter_sorted != 2 && L == 4 && P == 4 &&
+                         msda::make_band_plan(shapes_host, lsi_host, Lq, bp);
+      if (!bands) msda::bwd_bounds_kernel<<<B * M, 256, 0, stream>>>(boxes, bounds, (int)(L * ws.n_chunks_per_list));
       // levels shared by several workgroups are accumulated with atomics: zero exactly those rows
-      for (int l = 0; l < L; ++l) {
+      for (int l = 0; l < L && !bands; ++l) {
         if (plan.n_chunks[l] == 1) continue;
         hipError_t e = hipMemset2DAsync(grad_value + (size_t)plan.start[l] * M * 32, sizeof(float) * (size_t)S * M * 32,
                                         0, sizeof(float) * (size_t)plan.H[l] * plan.W[l] * M * 32, B, stream);
         if (e != hipSuccess) return (int)e;
       }
       const int bm_groups = (B * M + 7) / 8;
+      if (bands) {
+        msda::bwd_scatter_bands_kernel<<<8 * bp.n_items * bm_groups, msda::kBandThreads, 0, stream>>>(
+            rec_hw, rec_aw, grad_out, grad_value, bp, B, S, M, Lq, vv.mask);
+      } else
       // measured (B = 16, KITTI pyramid): sorted 0.90 ms vs 1.04 ms at Lq = 10200; 0.259 vs 0.245 at Lq = 550; 0.137 vs
       // 0.091 at Lq = 50 -- the batches' barriers only pay off on long record lists
       if (options().scatter_sorted == 1 ? Lq * P >= 8192 : options().scatter_sorted == 2)
@@ -551,6 +563,7 @@ int msda_set_option(const char *name, int value) {
   if (n == "scatter_rows" && (value == 0 || value == 1)) { options().scatter_rows = value; return 0; }
   if (n == "scatter_reach" && value >= 1 && value <= 16) { options().scatter_reach = value; return 0; }
   if (n == "directional" && (value == 0 || value == 1)) { options().directional = value; return 0; }
+  if (n == "scatter_bands" && (value == 0 || value == 1)) { options().scatter_bands = value; return 0; }
   if (n == "plan_reach" && value >= 1 && value <= 16) { options().plan_reach = value; return 0; }
   return MSDA_E_UNSUPPORTED;
 }
