@@ -55,16 +55,17 @@ for (k, grid), cs in sorted(msda.items()):
                                                 "raw_write_counter_bytes": cs.get("WRITE_SIZE", 0.0)}
     print("%-70s fetch %8.1f MB  write %8.1f MB" % (k + " grid=" + grid, fetch / 1e6, write / 1e6))
 # op-level sums in the keys bench.py looks up.  The fused micro-benchmark runs the encoder shape (Lq = S: tile-window gather
-# + row-tile scatter) and the 550-query decoder shape (record gather + tile-owner scatter); a kernel template that serves both
+# + cell scatter behind the device-side directional plan) and the 550-query decoder shape (record gather + row-band scatter); a kernel template that serves both
 # shapes is told apart by its grid (the encoder launch is the larger one).
 by_kernel = defaultdict(list)
 for (k, grid), cs in msda.items():
     by_kernel[k].append((int(grid), k, grid))
 ops = {
     "msda_fwd_Lq10200_B16": [("gather_win_kernel<false", -1)],
-    "msda_bwd_Lq10200_B16": [("row_candidates_kernel", -1), ("scatter_rows_kernel", -1), ("gather_win_kernel<true", -1)],
+    "msda_bwd_Lq10200_B16": [("dir_stats_kernel", -1), ("dir_plan_kernel", -1), ("row_candidates_kernel", -1), ("scatter_rows_kernel", -1),
+                             ("gather_win_kernel<true", -1)],
     "msda_fwd_Lq550_B16": [("gather_rec_kernel<false", 0)],
-    "msda_bwd_Lq550_B16": [("bwd_prep_kernel", 0), ("bwd_bounds_kernel", 0), ("bwd_scatter_kernel", 0), ("gather_rec_kernel<true", 0)],
+    "msda_bwd_Lq550_B16": [("bwd_prep_kernel", 0), ("bwd_scatter_bands_kernel", 0), ("gather_rec_kernel<true", 0)],
 }
 res["_source"] = {"command": "bash tools/collect_pmc.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on "
                              "tools/msda_fused_bench.py --kinds enc,550: the fused strided operator of the train step, B = 16)",
