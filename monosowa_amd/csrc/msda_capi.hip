@@ -63,6 +63,7 @@ struct Options {
   int scatter_reach = 6;       // its near-point reach in pixels (farther points: global atomics in the gather kernel)
   int directional = 1;         // 1 (default): per-head directional bounds measured on the call's own offsets (msda_plan.h) size the
                                // scatter's scan regions (and the windows); 0: isotropic reach / halo for every head
+  int scatter_lists = 1;       // 1 (default): exact scan lists from the saved locations (msda_bin.hip) for the saved backward
   int scatter_bands = 1;       // 1 (default): row-band scatter (msda_backward_bands.hip) for short record lists (Lq <= 576: the decoder)
   int plan_reach = 8;          // capacity of the directional scan: |footprint - centre| beyond this many pixels is "far" in any case
   Options() {                                               // the environment is read ONCE, at first use
@@ -78,6 +79,7 @@ struct Options {
     if (const char *e = std::getenv("MSDA_WINDOW_HALO")) window_halo = std::min(32, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("MSDA_DIRECTIONAL")) directional = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSDA_SCATTER_BANDS")) scatter_bands = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MSDA_SCATTER_LISTS")) scatter_lists = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSDA_PLAN_REACH")) plan_reach = std::min(16, std::max(1, std::atoi(e)));
   }
 };
@@ -233,7 +235,7 @@ void launch_gather(const float *value, const float *loc, const float *attw, cons
                    float *grad_loc, float *grad_attw, const float *ref, int ref_dim, const int64_t *shapes_host,
                    const int64_t *lsi_host, int B, int S, int M, int Lq, hipStream_t stream, int loc_rs = 0, int aw_rs = 0,
                    float *grad_value = nullptr, int far_reach = -1, ValueView vv = ValueView(),
-                   const msda::HeadPlan *plans = nullptr) {
+                   const msda::HeadPlan *plans = nullptr, const unsigned char *far_mask = nullptr) {
   if (!loc_rs) loc_rs = M * 32;
   if (!aw_rs) aw_rs = M * 16;
   const int vts = vv.token_stride ? vv.token_stride : M * 32;
@@ -259,11 +261,11 @@ void launch_gather(const float *value, const float *loc, const float *attw, cons
       if (vv.mask)
         msda::gather_win_kernel<BWD, FUSED, SAVED, true><<<grid, threads, 0, stream>>>(
             value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, wt, B, S, M, loc_rs, aw_rs, grad_value, far_reach,
-            n_virtual, vts, vv.mask, qtab, plans);
+            n_virtual, vts, vv.mask, qtab, plans, far_mask);
       else
         msda::gather_win_kernel<BWD, FUSED, SAVED, false><<<grid, threads, 0, stream>>>(
             value, loc, attw, grad_out, out, grad_loc, grad_attw, ref, ref_dim, wt, B, S, M, loc_rs, aw_rs, grad_value, far_reach,
-            n_virtual, vts, nullptr, qtab, plans);
+            n_virtual, vts, nullptr, qtab, plans, far_mask);
       return;
     }
   }
@@ -409,6 +411,57 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
       const long long widest = std::max<long long>(std::max(loc_rs, aw_rs), std::max(M * 32, vv.token_stride));
       if (options().scatter_rows && window_applies(true, shapes_host, lsi_host, Lq, S, widest) && (!fused_ref || fused_ref_dim == 2)) {
         msda::RowPlan rp;
+        // ---- saved backward: exact scan lists (msda_bin.hip) -- one streaming pass over the saved locations bins every (query,
+        // level) unit into the tiles its points fall into; the cell scatter scans exactly those, whatever the offsets look like
+        if (saved && options().scatter_lists && msda::make_row_plan(shapes_host, lsi_host, options().scatter_reach, rp)) {
+          msda::BinPlan bp{};
+          int n_tiles = 0, entries = 0;
+          double work[4];
+          for (int l = 0; l < 4; ++l) {
+            bp.H[l] = rp.H[l]; bp.W[l] = rp.W[l];
+            bp.th[l] = rp.th[l]; bp.tw[l] = rp.tw[l]; bp.n_ty[l] = rp.n_ty[l]; bp.n_tx[l] = rp.n_tx[l];
+            bp.tile0[l] = n_tiles;
+            const int tiles = rp.n_ty[l] * rp.n_tx[l];
+            // capacity: twice the share of a uniform spread (1.5 lists per unit: cells on an apron belong to two tiles), + slack
+            bp.cap[l] = (int)((3LL * Lq + tiles - 1) / tiles) + 256;
+            bp.list_off[l] = entries;
+            n_tiles += tiles;
+            entries += tiles * bp.cap[l];
+            rp.n_chunks[l] = std::max(1, std::min(16, (bp.cap[l] + msda::kRowChunkQueries - 1) / msda::kRowChunkQueries));
+            work[l] = (double)bp.cap[l] / rp.n_chunks[l];
+            rp.order[l] = l;
+          }
+          bp.n_tiles = n_tiles; bp.plane_entries = entries;
+          std::sort(rp.order, rp.order + 4, [&](int a, int b) { return work[a] > work[b]; });
+          rp.first_item[0] = 0;
+          for (int i = 0; i < 4; ++i) rp.first_item[i + 1] = rp.first_item[i] + rp.n_ty[rp.order[i]] * rp.n_tx[rp.order[i]] * rp.n_chunks[rp.order[i]];
+          rp.n_items = rp.first_item[4];
+          const size_t counts_b = align256(sizeof(unsigned) * (size_t)B * M * n_tiles);
+          const size_t lists_b = align256(sizeof(unsigned) * (size_t)B * M * entries);
+          const size_t far_b = align256((size_t)B * M * 4 * S);
+          if ((long long)B * M * entries < (1LL << 31) && counts_b + lists_b + far_b <= workspace_bytes) {
+            char *wsp = reinterpret_cast<char *>(workspace);
+            unsigned *counts = reinterpret_cast<unsigned *>(wsp);
+            unsigned *lists = reinterpret_cast<unsigned *>(wsp + counts_b);
+            unsigned char *far_mask = reinterpret_cast<unsigned char *>(wsp + counts_b + lists_b);
+            hipError_t e = hipMemsetAsync(counts, 0, counts_b, stream);
+            if (e != hipSuccess) return (int)e;
+            const long long n_units = (long long)B * M * 4 * S;
+            msda::bin_points_kernel<<<(unsigned)((n_units + 255) / 256), 256, 0, stream>>>(loc, bp, n_units, S, counts, lists, far_mask);
+            for (int l = 0; l < L; ++l) {          // levels shared by several workgroups are accumulated with atomics
+              if (rp.n_chunks[l] == 1) continue;
+              e = hipMemset2DAsync(grad_value + (size_t)rp.start[l] * M * 32, sizeof(float) * (size_t)S * M * 32, 0,
+                                   sizeof(float) * (size_t)rp.H[l] * rp.W[l] * M * 32, B, stream);
+              if (e != hipSuccess) return (int)e;
+            }
+            const int groups = (B * M + 7) / 8;
+            msda::scatter_rows_kernel<false, true><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
+                loc, attw, grad_out, grad_value, nullptr, 0, nullptr, rp, B, S, M, 0, 0, vv.mask, nullptr, lists, counts, bp);
+            launch_gather<true, true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
+                                            shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, 0, vv, nullptr, far_mask);
+            return launch_status();
+          }
+        }
         // directional plan (msda_plan.h): fused operator with 2-d reference points, or the forward's saved locations
         bool directional = options().directional && (saved || fused_ref) && M <= msda::kPlanMaxHeads;
         int reach = 0;
@@ -564,6 +617,7 @@ int msda_set_option(const char *name, int value) {
   if (n == "scatter_reach" && value >= 1 && value <= 16) { options().scatter_reach = value; return 0; }
   if (n == "directional" && (value == 0 || value == 1)) { options().directional = value; return 0; }
   if (n == "scatter_bands" && (value == 0 || value == 1)) { options().scatter_bands = value; return 0; }
+  if (n == "scatter_lists" && (value == 0 || value == 1)) { options().scatter_lists = value; return 0; }
   if (n == "plan_reach" && value >= 1 && value <= 16) { options().plan_reach = value; return 0; }
   return MSDA_E_UNSUPPORTED;
 }

@@ -77,7 +77,10 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
     const float *__restrict__ grad_out, float *__restrict__ out, float *__restrict__ grad_loc,
     float *__restrict__ grad_attw, const float *__restrict__ ref, int ref_dim, const WinTable g, int B, int S, int M,
     int loc_rs, int aw_rs, float *__restrict__ grad_value, int far_reach, int n_virtual, int vts,
-    const unsigned char *__restrict__ vmask, const WinQuery *__restrict__ qtab, const HeadPlan *__restrict__ plans = nullptr) {
+    const unsigned char *__restrict__ vmask, const WinQuery *__restrict__ qtab, const HeadPlan *__restrict__ plans = nullptr,
+    const unsigned char *__restrict__ far_mask = nullptr) {
+  // far_mask [B, M, L, Lq] (backward with the exact scan lists, msda_bin.hip): bit p = point p of the unit did not fit its tile's
+  // list and takes the row-atomic path here (normally all zero)
   // plans (optional): the directional plan (msda_plan.h); backward: the head's near-bounds replace the isotropic far_reach
   // far_reach >= 0 (backward, with msda_scatter_rows.hip): points that are not near_point(.., far_reach) add their
   // grad_value contributions here with global atomics -- the row-tile scatter handles exactly the near ones
@@ -249,6 +252,9 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
     DirBounds near_b;        // backward with the row-tile scatter: the points it covers (everything else is "far": atomics below)
     near_b.ylo = near_b.xlo = (short)-far_reach; near_b.yhi = near_b.xhi = (short)far_reach;
     if (BWD && plans) near_b = plans[it.m].near[l_mine];
+    unsigned far_bits = 0;   // this lane's two points: bits 2 (sub & 1), 2 (sub & 1) + 1 of the unit's byte
+    if (BWD && far_mask && live)
+      far_bits = (unsigned)far_mask[((long long)(it.b * M + it.m) * 4 + l_mine) * S + q_u] >> (2 * (sub & 1));
     int off[2][4];
     float cw[2][4];          // forward: corner weights x attn_w.  backward: lh, lw, W attn_w, H attn_w
     int far_points = 0;      // backward with the row-tile scatter: which of the two points it does not cover
@@ -289,7 +295,9 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
         if (BWD) padded |= ((p0 ? 1 : 0) | (p1 ? 2 : 0) | (p2 ? 4 : 0) | (p3 ? 8 : 0)) << (4 * k2);
         else { if (p0) cw[k2][0] = 0.f; if (p1) cw[k2][1] = 0.f; if (p2) cw[k2][2] = 0.f; if (p3) cw[k2][3] = 0.f; }
       }
-      if (BWD && far_reach >= 0 && live && tp.valid && !inside_bounds(tp.h_low - in.cf_y, tp.w_low - in.cf_x, near_b))
+      if (BWD && far_mask) {
+        if (live && tp.valid && (far_bits >> k2 & 1)) far_points |= 1 << k2;
+      } else if (BWD && far_reach >= 0 && live && tp.valid && !inside_bounds(tp.h_low - in.cf_y, tp.w_low - in.cf_x, near_b))
         far_points |= 1 << k2;
       // Bank parity: a ds_read_b128 is served in groups of 16 lanes over 16 sixteen-byte bank slots; a 128-byte row covers the
       // 8 slots of its parity, and in every group exactly two lanes share a slot position (rot ^ s) -- lanes 16 apart.  The

@@ -22,6 +22,7 @@
 #include "msda_common.h"
 #include "msda_scatter_plan.h"
 #include "msda_plan.h"
+#include "msda_bin.hip"
 
 #ifndef MSDA_ROWS_SKIP
 #define MSDA_ROWS_SKIP 0         // measurement builds only: 1 no bucket walk, 2 no appends (scan only)
@@ -83,7 +84,10 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
     const float *__restrict__ loc, const float *__restrict__ attw, const float *__restrict__ grad_out,
     float *__restrict__ grad_value, const float *__restrict__ ref, int ref_dim, const RowCandidate *__restrict__ table,
     const RowPlan p, int B, int S, int M, int loc_rs, int aw_rs, const unsigned char *__restrict__ vmask = nullptr,
-    const HeadPlan *__restrict__ plans = nullptr) {
+    const HeadPlan *__restrict__ plans = nullptr, const unsigned *__restrict__ lists = nullptr,
+    const unsigned *__restrict__ counts = nullptr, const BinPlan bp = BinPlan()) {
+  // lists / counts / bp (optional): EXACT scan lists (msda_bin.hip) -- a candidate entry is a query with a 4-bit mask of its points
+  // that fall into this tile's cells; no bounds, no near / far classes.  `p` supplies the tiling and the (capacity-derived) chunking.
   // plans (optional): the directional plan (msda_plan.h) -- per head the scan runs, chunking and near-bounds; `p` then only
   // supplies the static tiling and the table capacities (the grid is sized for its isotropic worst case: surplus items exit)
   // vmask [B, S] (optional): padded value tokens -- their grad_value rows come out as zero (ms_deform_attn.py:139-140)
@@ -102,7 +106,30 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
   int l, n_chunks, y0, th, x0, tw, c_begin, c_end;
   const RowCandidate *cands;
   DirBounds nb;              // near <=> the footprint's top-left pixel lies inside these bounds around the query's centre floor
-  if (hp) {
+  bool by_list = false;
+  const unsigned *list = nullptr;
+  if (lists) {
+    int oi = 0;
+    while (oi < 3 && it >= p.first_item[oi + 1]) ++oi;
+    l = p.order[oi];
+    const int local = it - p.first_item[oi];
+    n_chunks = p.n_chunks[l];
+    const int chunk = local % n_chunks, tile = local / n_chunks;
+    const int ty = tile / p.n_tx[l], tx = tile - ty * p.n_tx[l];
+    const RowAxis ay = p.ax[p.axis0[l] + ty], ax = p.ax[p.axis0[l] + p.n_ty[l] + tx];
+    y0 = ay.r0; x0 = ax.r0; th = ay.rn; tw = ax.rn;
+    const int n_list = (int)min(counts[(long long)bm * bp.n_tiles + bp.tile0[l] + tile], (unsigned)bp.cap[l]);
+    c_begin = chunk * kRowChunkQueries;
+    c_end = min(n_list, c_begin + kRowChunkQueries);
+    if (c_end <= c_begin) {
+      if (chunk > 0) return;                 // nothing left for this chunk (chunk 0 still writes / zeroes the tile when it owns it alone)
+      c_end = c_begin;
+    }
+    list = lists + (long long)bm * bp.plane_entries + bp.list_off[l] + (long long)tile * bp.cap[l];
+    cands = nullptr;
+    nb.ylo = nb.xlo = nb.yhi = nb.xhi = 0;
+    by_list = true;
+  } else if (hp) {
     // planned call: ONE descriptor (msda_plan.h: RowItem)
     if (it >= hp->n_items) return;
     const RowItem d = hp->items[it];
@@ -158,7 +185,15 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
   };
   auto candidate = [&](const int j) {
     RowCandidate c{-1, 0, 0};
-    if (j < c_end) c = cands[j];
+    if (j < c_end) {
+      if (by_list) {
+        const unsigned e = list[j];
+        c.token = (int)(e & 0x0FFFFFFFu);
+        c.cy = (short)(e >> 28);             // the unit's point mask
+      } else {
+        c = cands[j];
+      }
+    }
     return c;
   };
   auto fetch = [&](const RowCandidate c) {
@@ -226,7 +261,7 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
       cells[u] = 0;
       if (cur[u].token >= 0) {
         const Tap<float> tp = make_tap<float>(lx, ly, H, W);
-        if (tp.valid && inside_bounds(tp.h_low - cur[u].cy, tp.w_low - cur[u].cx, nb)) {
+        if (tp.valid && (by_list ? (cur[u].cy >> pt & 1) != 0 : inside_bounds(tp.h_low - cur[u].cy, tp.w_low - cur[u].cx, nb))) {
           const int cy = tp.h_low - (y0 - 1), cx = tp.w_low - (x0 - 1);
           if ((unsigned)cy <= (unsigned)th && (unsigned)cx <= (unsigned)tw) {
             cells[u] = cy * cw + cx;
