@@ -63,7 +63,10 @@ struct Options {
   int scatter_reach = 6;       // its near-point reach in pixels (farther points: global atomics in the gather kernel)
   int directional = 1;         // 1 (default): per-head directional bounds measured on the call's own offsets (msda_plan.h) size the
                                // scatter's scan regions (and the windows); 0: isotropic reach / halo for every head
-  int scatter_lists = 1;       // 1 (default): exact scan lists from the saved locations (msda_bin.hip) for the saved backward
+  int scatter_lists = 0;       // 1: exact scan lists from the saved locations (msda_bin.hip) for the saved backward instead of the
+                               // geometric scan behind the directional plan.  Opt-in: measured at B = 16 the binning pass costs 273 us and
+                               // the list-driven scatter 560 us (its workgroups have ONE batch of work each: the per-workgroup load chain
+                               // dominates) against 35 + 473 us -- it only wins beyond sigma = 8 px (2.35 vs 2.65 ms)
   int scatter_bands = 1;       // 1 (default): row-band scatter (msda_backward_bands.hip) for short record lists (Lq <= 576: the decoder)
   int plan_reach = 8;          // capacity of the directional scan: |footprint - centre| beyond this many pixels is "far" in any case
   Options() {                                               // the environment is read ONCE, at first use

@@ -201,6 +201,35 @@ def test_fused_strided_operator_at_the_kitti_pyramid_vs_c_oracle(B, check, offse
         assert (got_log - g_log[b:b + 1]).abs().max() <= 1e-4 * g_log[b].abs().max(), "grad_logits[%d]" % b
 
 
+@pytest.mark.parametrize("option,value", [("scatter_lists", 1), ("directional", 0)])
+def test_saved_backward_alternative_scan_sources_compute_the_same_gradients(option, value):
+    """The saved backward's two opt-in / fallback scan sources -- exact scan lists binned from the saved locations
+    (msda_set_option("scatter_lists", 1): msda_bin.hip) and the isotropic host plan ("directional", 0) -- against the default
+    (geometric scan behind the device-side directional plan), offsets of 6.5 px so that window-outside and far points occur."""
+    MSDA = _msda()
+    from monosowa_amd import _lib
+    B = 2
+    shapes, lsi, ref, offsets, logits, value_, go = _kitti_encoder_inputs(B, 78, 6.5)
+    S, M = value_.shape[1], value_.shape[2]
+    s, i = _dev(shapes), _dev(lsi)
+    MSDA.attach_host_geometry(s, i, shapes.tolist(), lsi.tolist())
+    proj = torch.cat([_dev(offsets).reshape(B, S, M * 32), _dev(logits).reshape(B, S, M * 16)], -1).contiguous()
+    refp = _dev(np.broadcast_to(ref[None, :, None, :], (B, S, 4, 2)).copy())
+    v, g = _dev(value_), _dev(go)
+    _, loc, attw = MSDA.ms_deform_attn_fused_forward_merged_save(v, s, i, proj, refp)
+    gv_a, gp_a = MSDA.ms_deform_attn_fused_backward_merged_saved(v, s, i, loc, attw, refp, g)
+    lib = _lib.load()
+    default = {"scatter_lists": 0, "directional": 1}[option]
+    assert lib.msda_set_option(option.encode(), value) == 0
+    try:
+        gv_b, gp_b = MSDA.ms_deform_attn_fused_backward_merged_saved(v, s, i, loc, attw, refp, g)
+        torch.cuda.synchronize()
+    finally:
+        assert lib.msda_set_option(option.encode(), default) == 0
+    for name, a, b in (("grad_value", gv_a, gv_b), ("grad_proj", gp_a, gp_b)):
+        assert (a - b).abs().max() <= 2e-6 * a.abs().max(), (name, ((a - b).abs().max() / a.abs().max()).item())
+
+
 def test_saved_prologue_backward_equals_the_recomputing_backward():
     """ABI v6: msda_fused_forward_save_f32 + msda_fused_backward_saved_f32 (the backward reads the sampling locations /
     attention weights the forward stored) against the v5 pair that re-evaluates the prologue -- same output bit for bit,
