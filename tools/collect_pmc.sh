@@ -13,5 +13,8 @@ cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/calib_$C" -- "$ROOT/tools/ubench/pmc_calib" > "$OUT/calib_$C.log" 2>&1
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/msda_$C" -- python3 "$ROOT/tools/msda_fused_bench.py" --iters 3 --warmup 1 --kinds enc,550 > "$OUT/msda_$C.log" 2>&1
+  # the other BASELINE geometries (encoder shape only): config 4 = 1408x376 at B = 16 (S = 11044), config 5 = 1920x1280 at B = 4 (S = 51000)
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/c4_$C" -- python3 "$ROOT/tools/msda_fused_bench.py" --iters 3 --warmup 1 --kinds enc --resolution 1408x376 > "$OUT/c4_$C.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/c5_$C" -- python3 "$ROOT/tools/msda_fused_bench.py" --iters 3 --warmup 1 --kinds enc --resolution 1920x1280 --batch 4 > "$OUT/c5_$C.log" 2>&1
 done
 python3 "$ROOT/tools/pmc_summarize.py" "$OUT"

@@ -20,8 +20,13 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from monosowa_amd import MultiScaleDeformableAttention as MSDA  # noqa: E402
 
-LEVELS = [(48, 160), (24, 80), (12, 40), (6, 20)]
+LEVELS = [(48, 160), (24, 80), (12, 40), (6, 20)]          # 1280 x 384; --resolution WxH replaces it (strides 8, 16, 32, 64)
 HBM_PEAK = 8.0e12
+
+
+def set_resolution(res):
+    W, H = (int(x) for x in res.split("x"))
+    LEVELS[:] = [(-(-H // st), -(-W // st)) for st in (8, 16, 32, 64)]
 
 
 def make(B, kind, offsets, dev, seed=0):
@@ -29,7 +34,7 @@ def make(B, kind, offsets, dev, seed=0):
     shapes = torch.tensor(LEVELS, dtype=torch.long, device=dev)
     lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
     MSDA.attach_host_geometry(shapes, lsi, LEVELS, lsi.tolist())
-    S, M, D, L, P = 10200, 8, 32, 4, 4
+    S, M, D, L, P = sum(h * w for h, w in LEVELS), 8, 32, 4, 4
     value = torch.randn(B, S, M, D, device=dev, generator=g)
     if kind == "enc":
         Lq = S
@@ -145,11 +150,14 @@ def main():
                          "trained[:steps] (the encoder layers' projections of a model trained for that many steps on one synthetic "
                          "batch, tools/overfit_check.py's loop; default 150)")
     ap.add_argument("--sweep", default=None, help="comma-separated --offsets values: one table / JSON over all of them (encoder shape)")
+    ap.add_argument("--resolution", default=None, help="WxH of the image (default 1280x384): config 4 = 1408x376, config 5 = 1920x1280")
     ap.add_argument("--recompute", action="store_true", help="ABI v5 pair (backward re-evaluates the prologue)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     res = {}
+    if a.resolution:
+        set_resolution(a.resolution)
     if a.sweep:
         # one row per offset distribution, encoder shape: forward / backward time and what the plan sees
         for spec in a.sweep.split(","):

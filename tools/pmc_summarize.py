@@ -82,4 +82,25 @@ for op, parts in ops.items():
     res[op] = tot
     res["_source"]["kernels"][op] = used
     print("%-28s %8.1f MB per launch (fetch x%.2f + write x%.2f corrected) <- %s" % (op, tot / 1e6, f_gather, f_write, ", ".join(u.split("(")[0] for u in used)))
+# the other BASELINE geometries (collect_pmc.sh: c4_* / c5_* passes, encoder shape only): every msda:: kernel of the pass but the
+# one-off forward that produces the saved tensors is summed per direction
+for tag, key_f, key_b in (("c4", "msda_fwd_Lq11044_B16", "msda_bwd_Lq11044_B16"), ("c5", "msda_fwd_Lq51000_B4", "msda_bwd_Lq51000_B4")):
+    per = defaultdict(dict)
+    for C in ("FETCH_SIZE", "WRITE_SIZE"):
+        for (k, c), v in counters(tag + "_" + C).items():
+            if "msda::" in k:
+                per[k][c] = sum(x[1] for x in v) / len(v) * 1024.0
+    if not per:
+        continue
+    fwd = bwd = 0.0
+    used_f, used_b = [], []
+    for k, cs in per.items():
+        nbytes = cs.get("FETCH_SIZE", 0.0) * f_gather + cs.get("WRITE_SIZE", 0.0) * f_write
+        if "gather_win_kernel<false" in k:
+            fwd += nbytes; used_f.append(k)
+        else:
+            bwd += nbytes; used_b.append(k)
+    res[key_f], res[key_b] = fwd, bwd
+    res["_source"]["kernels"][key_f], res["_source"]["kernels"][key_b] = used_f, used_b
+    print("%-28s %8.1f MB   %-28s %8.1f MB per launch" % (key_f, fwd / 1e6, key_b, bwd / 1e6))
 json.dump(res, open(os.path.join(d, "msda_traffic.json"), "w"), indent=1)
