@@ -267,11 +267,22 @@ def test_optimised_train_step_reduces_the_loss_on_a_repeated_batch():
     assert min(hist[-5:]) < 0.75 * hist[0], hist
 
 
+# (backbone, W x H, per-GPU batch, mixed cameras): BASELINE config 2 at half resolution with its batch of 16, then the FULL
+# geometries of configs 4 and 5 at a small batch: ResNet-101 at 1408 x 376 (S = 11,044 tokens, a 24 x 88 depth
+# map: odd extents at every stride), and 1920 x 1280 with a mixed-camera batch (S = 51,000 tokens, 9,600 depth tokens, per-sample
+# Canonical Object Space scale and fu)
+_STEP_CONFIGS = {"config2_half": ("resnet50", (640, 192), 16, False),
+                 "config4_resnet101_1408x376": ("resnet101", (1408, 376), 2, False),
+                 "config5_1920x1280_mixed_cameras": ("resnet50", (1920, 1280), 3, True)}
+
+
 @pytest.mark.gpu
-def test_fused_training_path_tracks_the_module_by_module_path():
+@pytest.mark.parametrize("config", list(_STEP_CONFIGS))
+def test_fused_training_path_tracks_the_module_by_module_path(config):
     """Three optimizer steps (dropout 0, same initial weights and batch) with every structural optimisation switched ON
     against the same steps with all of them OFF (module-by-module autograd, PyTorch matched losses, foreach AdamW,
     unmerged projections ...): the loss sequences and the updated weights must agree to fp32 training noise."""
+    backbone_name, resolution, batch, mixed = _STEP_CONFIGS[config]
     import copy
     import yaml
     from monosowa_amd import encoder_block, ms_deform_attn, pointwise
@@ -285,7 +296,8 @@ def test_fused_training_path_tracks_the_module_by_module_path():
                 (backbone, "AFFINE_IN_KERNEL"), (backbone, "CACHE_SCALE_SHIFT"), (pointwise, "USE_RELU_MASK"),
                 (matcher, "BLOCK_COST"), (position_encoding, "CACHE_ALL_VALID")]
     cfg = yaml.safe_load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "configs", "monodetr.yaml")))
-    mcfg = dict(cfg["model"], device="cuda", dropout=0.0)
+    mcfg = dict(cfg["model"], device="cuda", dropout=0.0, backbone=backbone_name, pretrained=False,
+                depth_map_size=(resolution[0] // 16, resolution[1] // 16))
     torch.manual_seed(7)
     model0, crit = build_model(mcfg)
     for m in model0.modules():                       # the depth predictor hard-codes dropout 0.1 (depth_predictor.py:48)
@@ -294,8 +306,10 @@ def test_fused_training_path_tracks_the_module_by_module_path():
         if isinstance(m, torch.nn.MultiheadAttention):
             m.dropout = 0.0
     crit = crit.cuda().train()
-    inputs, calibs, targets, _ = make_batch(16, "cuda", seed=3, resolution=(640, 192))
+    inputs, calibs, targets, info = make_batch(batch, "cuda", seed=3, resolution=resolution, mixed_cameras=mixed)
     inputs = inputs.contiguous(memory_format=torch.channels_last)
+    if mixed:                                        # the batch really mixes cameras: three fu, three canonical scales
+        assert len(set(calibs[:, 0, 0].tolist())) == 3 and len(set(info["canonical_scale"].tolist())) == 3
 
     def run(on):
         saved = [(mod, name, getattr(mod, name)) for mod, name in switches]
@@ -308,7 +322,7 @@ def test_fused_training_path_tracks_the_module_by_module_path():
                 opt._fused_step = lambda *a, **k: False
             losses = []
             for _ in range(3):
-                tl = prepare_targets(targets, 16)
+                tl = prepare_targets(targets, batch)
                 opt.zero_grad(set_to_none=True)
                 total = criterion.weighted_total(crit(model(inputs, calibs, tl, targets["img_size"]), tl), crit.weight_dict)
                 total.backward()
