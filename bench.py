@@ -203,6 +203,19 @@ def default_conv_workload(args):
     return True
 
 
+def any_rank_says(flag, device):
+    """True on EVERY rank as soon as one rank's ``flag`` is true.  Loops whose length depends on a rank's own clock (the
+    pre-heat) end through this: a step is a set of collectives, so a rank that granted itself one step more than its
+    partners would wait for them forever."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], device=device, dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item())
+
+
 def launch_ranks(args):
     """``python bench.py --gpus N`` started plainly: start the N ranks as a FRESH child (torch.distributed.run) before this
     process has touched the GPU, relay its stdout (rank 0's JSON line) and exit with its code.  Never an exec of a
@@ -285,7 +298,7 @@ def main():
         step(batch)                       # first step: library initialisation, MIOpen kernel selection
         torch.cuda.synchronize()
         t1, n = time.time(), 0
-        while time.time() - t1 < args.preheat_seconds:
+        while not any_rank_says(time.time() - t1 >= args.preheat_seconds, device):
             step(batch)
             torch.cuda.synchronize()
             n += 1

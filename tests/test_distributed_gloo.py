@@ -156,3 +156,38 @@ def test_bench_self_launch_spawns_a_child_and_returns_its_code():
         assert "needs an MI355X" in r.stderr, r.stderr[-2000:]              # said by the rank, not by the parent
         assert r.returncode != 0                                            # ... and its failure is the parent's exit code
         assert r.stdout.strip() == ""                                       # no JSON line was invented
+
+
+def _clock_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import bench
+    steps = 0
+    # rank 1's clock runs out two steps before rank 0's: both must stop after the same number of (collective) steps
+    while not bench.any_rank_says(steps >= (5 if rank == 0 else 3), torch.device("cpu")):
+        t = torch.ones(4)
+        dist.all_reduce(t)                           # the "step": hangs if the partner has left the loop
+        steps += 1
+    out = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(out, torch.tensor([steps]))
+    if rank == 0:
+        q.put([int(x) for x in out])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_preheat_loop_ends_on_every_rank_after_the_same_number_of_steps():
+    """bench.py's pre-heat runs "for N seconds" by each rank's own clock; its steps contain collectives (DDP all-reduce,
+    num_boxes), so the ranks have to agree on the moment to stop (bench.any_rank_says) -- otherwise the N > 1 line never
+    appears."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_clock_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get() == [3, 3]
