@@ -163,6 +163,19 @@ int mono_match_cost_f32(const float *logits, const float *boxes, const long long
                         float *out, int NL, int B, int Q, int C, int N, float w_class, float w_3d, float w_bbox, float w_giou,
                         void *stream);
 
+/* The Hungarian matcher's assignments ON THE DEVICE (reference matcher.py:94-103: scipy.optimize.linear_sum_assignment per image and
+ * query group, on the host; csrc/lsap.cpp is this repo's host solver with the same contract): cost [NL, B, Q, T] as written by
+ * mono_match_cost_f32 (image b's targets in columns [0, sizes[b])); for every layer, image and group g of Q / G queries one
+ * rectangular assignment problem, solved by one wavefront with scipy's algorithm, arithmetic (double) and tie-breaks, so the
+ * pairs are the reference's.  meta [3, B] int32 = sizes | first | toff (first[b] = sum over earlier images of G min(Q / G, sizes),
+ * toff[b] = sum of earlier sizes).  out_idx [3, NL, K] int64 = (image, query, toff + target) per pair in (image, group) order, pairs
+ * of a group sorted by query, K = first[B - 1] + G min(Q / G, sizes[B - 1]) -- the flat index tensor lsap_match_flat_f32 returns.
+ * status (device int, OR-ed): 1 = a cost is NaN / -inf or a problem is infeasible (scipy raises), 2 = a problem exceeds the
+ * kernel's tables.  No host synchronisation: the caller reads `status` when it likes.
+ * Limits: Q / G <= 128, max(sizes) <= 128, min(Q / G, n) max(Q / G, n) <= 8192 per problem.  Returns -3 beyond the first limit. */
+int mono_lsap_match_flat_f32(const float *cost, int NL, int B, int Q, int T, int G, const int *meta, long long *out_idx, long long K,
+                             int *status, void *stream);
+
 /* Per-level tail of MonoDETR's detection heads (monodetr.py:238-263), one launch each way: coords [B, Q, 6] = sigmoid(tmp),
  * depth_ave [B, Q, 2] = ((1 / (sigmoid(depth_reg0) + 1e-6) - 1 + size3d0 / max((coords4 + coords5) img_h, 1) fu
  *                        + bilinear(wdepth [B, H, W]; coords0, coords1 -- F.grid_sample, align_corners, zero padding)) / 3, depth_reg1).

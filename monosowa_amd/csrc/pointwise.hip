@@ -9,6 +9,7 @@
 #include "matched_losses.hip"
 #include "ddn_loss.hip"
 #include "head_tail.hip"
+#include "lsap_device.hip"
 #include <stdint.h>
 
 namespace mono {
@@ -824,6 +825,17 @@ int mono_refine_reference_f32(const float *tmp, const float *ref, float *out, in
   if (!tmp || !ref || !out) return -1;
   if (n <= 0 || ref_dim < 1 || ref_dim > 6 || (long long)n * 6 > (1ll << 30)) return -2;
   mono::refine_reference_kernel<<<(n * 6 + 255) / 256, 256, 0, (hipStream_t)stream>>>(tmp, ref, out, n, ref_dim);
+  return (int)hipGetLastError();
+}
+
+/* The matcher's assignments on the device (csrc/lsap_device.hip): see include/monosowa_pointwise.h. */
+int mono_lsap_match_flat_f32(const float *cost, int NL, int B, int Q, int T, int G, const int *meta, long long *out_idx, long long K,
+                             int *status, void *stream) {
+  if (!cost || !meta || !out_idx || !status) return -1;
+  if (NL <= 0 || B <= 0 || Q <= 0 || T <= 0 || G <= 0 || Q % G != 0 || K < 0) return -2;
+  if (Q / G > lsapd::kMaxDim || (long long)NL * B * G > (1ll << 30)) return -3;          // the host solver keeps such shapes
+  if (K == 0) return 0;
+  lsapd::match_flat_kernel<<<NL * B * G, 64, 0, (hipStream_t)stream>>>(cost, NL, B, Q, T, G, meta, out_idx, K, status);
   return (int)hipGetLastError();
 }
 

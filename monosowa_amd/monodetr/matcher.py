@@ -23,6 +23,9 @@ def _pairwise_l1(a, b):
     return out
 
 
+DEVICE_LSAP = True     # match_layers: the assignments on the device (csrc/lsap_device.hip: scipy's algorithm, arithmetic and tie-breaks,
+                       # one wavefront per problem) -- no device -> host copy of the cost blocks, no host wait: the train step runs
+                       # without a single host synchronisation.  False: the host solver behind one copy + one wait (csrc/lsap.cpp)
 FUSED_COST = True      # ... from one HIP launch (pointwise.match_cost_blocks) instead of ~70 elementwise ones; same floats
 BLOCK_COST = True      # match_layers: per-image cost blocks only (False: full cross matrix + gather, as the reference)
 
@@ -143,6 +146,19 @@ class HungarianMatcher(nn.Module):
             C = self.cost_matrix({"pred_logits": pred_logits.flatten(0, 1), "pred_boxes": pred_boxes.flatten(0, 1)},
                                  [flat_targets]).view(NL, B, Q, T)
             blocks = torch.gather(C, 3, cols.view(1, B, 1, maxn).expand(NL, B, Q, maxn))
+        if blocks.is_cuda and DEVICE_LSAP:
+            from ..pointwise import device_lsap_match_flat, device_lsap_supported
+            blocks = blocks.contiguous()
+            if device_lsap_supported(blocks, sizes, group_num):
+                self.check_device_status()                      # an EARLIER call's flag, if its copy has landed: never a wait
+                if getattr(self, "_status", None) is None or self._status.device != blocks.device:
+                    self._status = torch.zeros((), dtype=torch.int32, device=blocks.device)
+                    self._status_host = torch.zeros((), dtype=torch.int32).pin_memory()
+                idx = device_lsap_match_flat(blocks, sizes, group_num, self._status)
+                self._status_host.copy_(self._status, non_blocking=True)
+                self._status_event = torch.cuda.Event()
+                self._status_event.record()
+                return ("device", idx), NL, B, Q, sizes, group_num
         if blocks.is_cuda:
             key = (tuple(blocks.shape), blocks.dtype)
             if getattr(self, "_pinned_key", None) != key:
@@ -153,11 +169,29 @@ class HungarianMatcher(nn.Module):
             return (self._pinned, done), NL, B, Q, sizes, group_num
         return (blocks, None), NL, B, Q, sizes, group_num
 
+    def check_device_status(self, block=False):
+        """The device solver cannot raise from a kernel: it ORs a flag into a status word whose copy to pinned memory is queued
+        behind it.  Called at the start of the next matching (and by whoever wants certainty, with ``block=True``): raises what
+        scipy raises for a cost matrix with NaN / -inf entries or without a feasible assignment."""
+        ev = getattr(self, "_status_event", None)
+        if ev is None:
+            return
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        self._status_event = None
+        if int(self._status_host) & 1:
+            self._status.zero_()
+            raise ValueError("cost matrix is infeasible")
+
     @torch.no_grad()
     def match_layers_end_flat(self, handle):
         """Second half of ``match_layers`` returning the flat int64 index array [3, NL, K] (image, query, flat target)."""
         from .. import lsap
         payload, NL, B, Q, sizes, group_num = handle
+        if payload is not None and isinstance(payload[0], str):
+            return payload[1]                                                         # already on the device: nothing to wait for
         if payload is not None and lsap.available():
             blocks, done = payload
             if done is not None:
@@ -177,6 +211,13 @@ class HungarianMatcher(nn.Module):
         if payload is None:
             e = np.empty(0, np.int64)
             return [[(e, e) for _ in range(B)] for _ in range(NL)]
+        if isinstance(payload[0], str):                                                    # list form of the device solver's pairs (tests, slow path)
+            idx = payload[1].cpu().numpy()
+            self.check_device_status(block=True)
+            g_q, offs = Q // group_num, np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+            per = [group_num * min(g_q, int(n)) for n in sizes]
+            first = np.concatenate([[0], np.cumsum(per)]).astype(np.int64)
+            return [[(idx[1, l, first[b]:first[b + 1]], idx[2, l, first[b]:first[b + 1]] - offs[b]) for b in range(B)] for l in range(NL)]
         blocks, done = payload
         if done is not None:
             done.synchronize()                                                        # the step's one host sync

@@ -3,6 +3,7 @@
 import ctypes
 import os
 
+import numpy as np
 import torch
 
 from ._lib import raw_stream, on_device
@@ -11,7 +12,7 @@ _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmono
 SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
-           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32", "mono_relu_dropout_bwd_colsum_f32", "mono_sum_slices_f32", "mono_colsum_any_blocks", "mono_colsum_any_f32", "mono_relu_grad_mask3_f32")
+           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32", "mono_relu_dropout_bwd_colsum_f32", "mono_sum_slices_f32", "mono_colsum_any_blocks", "mono_colsum_any_f32", "mono_relu_grad_mask3_f32", "mono_lsap_match_flat_f32")
 _lib = None
 
 
@@ -95,6 +96,8 @@ def load():
         lib.mono_head_tail_bwd_f32.argtypes = [P] * 12 + [I] * 4 + [P, I, P]
         lib.mono_refine_reference_f32.restype = I
         lib.mono_refine_reference_f32.argtypes = [P, P, P, I, I, P]
+        lib.mono_lsap_match_flat_f32.restype = I
+        lib.mono_lsap_match_flat_f32.argtypes = [P, I, I, I, I, I, P, P, LL, P, P]
         _lib = lib
     return _lib
 
@@ -867,6 +870,44 @@ def match_cost_blocks(logits, boxes, labels, tboxes, cols, w_class, w_3d, w_bbox
                                           raw_stream())
     if code:
         raise RuntimeError("mono_match_cost_f32 failed with code %d" % code)
+    return out
+
+
+# ---- the matcher's assignments on the device (csrc/lsap_device.hip) ------------------------------------------------------------------
+LSAP_MAX_DIM, LSAP_MAX_CELLS = 128, 8192
+
+
+def device_lsap_supported(blocks, sizes, group_num):
+    """The device solver's limits (include/monosowa_pointwise.h); anything else stays on the host solver."""
+    if not (blocks.is_cuda and blocks.dtype == torch.float32 and blocks.dim() == 4 and blocks.is_contiguous()):
+        return False
+    Q = blocks.shape[2]
+    if group_num <= 0 or Q % group_num:
+        return False
+    gq, n = Q // group_num, max(sizes) if len(sizes) else 0
+    return gq <= LSAP_MAX_DIM and n <= LSAP_MAX_DIM and min(gq, n) * max(gq, n) <= LSAP_MAX_CELLS and n <= blocks.shape[3]
+
+
+@torch.no_grad()
+def device_lsap_match_flat(blocks, sizes, group_num, status):
+    """blocks [NL, B, Q, N] float32 (``match_cost_blocks``) -> the criterion's flat index tensor [3, NL, K] int64 ON THE DEVICE
+    (image, query, flat target): the assignments of ``lsap.match_flat`` / scipy without a host round trip.  ``status``: a
+    device int32 scalar the kernel ORs its flags into (1: invalid / infeasible cost matrix, 2: unsupported shape)."""
+    NL, B, Q, N = blocks.shape
+    gq = Q // group_num
+    per = [group_num * min(gq, int(n)) for n in sizes]
+    first = np.concatenate([[0], np.cumsum(per)[:-1]])
+    toff = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    K = int(sum(per))
+    out = torch.empty((3, NL, K), dtype=torch.int64, device=blocks.device)
+    if K == 0:
+        return out
+    meta = torch.from_numpy(np.stack([np.asarray(sizes), first, toff]).astype(np.int32)).to(blocks.device, non_blocking=True)
+    with on_device(blocks.device):
+        code = load().mono_lsap_match_flat_f32(blocks.data_ptr(), NL, B, Q, N, group_num, meta.data_ptr(), out.data_ptr(), K,
+                                               status.data_ptr(), raw_stream())
+    if code:
+        raise RuntimeError("mono_lsap_match_flat_f32 failed with code %d" % code)
     return out
 
 
