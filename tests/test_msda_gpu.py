@@ -1220,7 +1220,8 @@ def test_block_cost_pass_is_bitwise_on_the_gpu_too():
             out[flag] = m.match_layers_end_flat(m.match_layers_begin(logits, boxes, flat, sizes, 11))
         finally:
             M.BLOCK_COST = True
-    assert np.array_equal(out[True], out[False])
+    to_np = lambda x: x.cpu().numpy() if torch.is_tensor(x) else np.asarray(x)      # device solver: a CUDA tensor; host solver: numpy / pinned
+    assert np.array_equal(to_np(out[True]), to_np(out[False]))
 
 
 def test_encoder_block_nodes_equal_the_module_by_module_layer():
