@@ -150,3 +150,33 @@ def test_criterion_with_the_device_matcher_equals_the_host_matcher():
     assert res[0][0] == res[1][0]
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)
+
+
+def test_shapes_beyond_the_kernels_tables_stay_on_the_host_solver():
+    """More than 128 queries per group (or targets per image): ``device_lsap_supported`` says no and the matcher takes the host
+    path (one copy, one wait) -- same contract, same pairs as scipy."""
+    import os
+    import yaml
+    from scipy.optimize import linear_sum_assignment
+    from monosowa_amd import pointwise
+    from monosowa_amd.monodetr import matcher as M
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m = M.build_matcher(yaml.safe_load(open(os.path.join(root, "configs", "monodetr.yaml")))["model"])
+    g = torch.Generator(device="cuda").manual_seed(2)
+    NL, B, Q, G, sizes = 1, 2, 300, 1, [5, 9]
+    logits = torch.randn(NL, B, Q, 3, device="cuda", generator=g)
+    boxes = torch.rand(NL, B, Q, 6, device="cuda", generator=g) * 0.4 + 0.1
+    T = sum(sizes)
+    flat = {"labels": torch.randint(0, 3, (T,), device="cuda", generator=g), "boxes_3d": torch.rand(T, 6, device="cuda", generator=g) * 0.4 + 0.1}
+    handle = m.match_layers_begin(logits, boxes, flat, sizes, G)
+    assert not isinstance(handle[0][0], str)                      # not the device solver's handle
+    assert not pointwise.device_lsap_supported(torch.empty(NL, B, Q, max(sizes), device="cuda"), sizes, G)
+    idx = m.match_layers_end_flat(handle)
+    idx = idx.cpu().numpy() if torch.is_tensor(idx) else np.asarray(idx)
+    blocks = handle[0][0].numpy()
+    pos, toff = 0, 0
+    for b in range(B):
+        r, t = linear_sum_assignment(blocks[0, b, :, :sizes[b]].astype(np.float64))
+        assert np.array_equal(idx[1, 0, pos:pos + len(r)], r) and np.array_equal(idx[2, 0, pos:pos + len(r)], t + toff)
+        pos += len(r)
+        toff += sizes[b]
