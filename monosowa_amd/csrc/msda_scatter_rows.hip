@@ -25,7 +25,8 @@
 #include "msda_bin.hip"
 
 #ifndef MSDA_ROWS_SKIP
-#define MSDA_ROWS_SKIP 0         // measurement builds only: 1 no bucket walk, 2 no appends (scan only)
+#define MSDA_ROWS_SKIP 0         // measurement builds only (bits): 1 no bucket walk, 2 no appends, 16 no grad_out row loads, 32 no tap
+                                 // arithmetic, 64 no epilogue (shifted adds + stores), 128 one batch per item (phase budget)
 #endif
 #ifndef MSDA_ROWS_STAMP
 #define MSDA_ROWS_STAMP 0        // measurement builds only: per-phase shader-clock totals (tools/debug/win_stamps.py)
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
   // Batch k takes candidates k, k + n_batches, k + 2 n_batches, ... of the chunk: a batch then samples the whole scan
   // region (a batch of NEIGHBOURS lands on a handful of cells of a coarse level and overflows their buckets).
   struct Points { float4 lg; float2 xy; float wt; RefScale rs; };
-  const int n_batches = (c_end - c_begin + kRowBatchQueries - 1) / kRowBatchQueries;
+  const int n_batches = (MSDA_ROWS_SKIP & 128) ? 1 : (c_end - c_begin + kRowBatchQueries - 1) / kRowBatchQueries;
   auto cand_index = [&](const int k, const int u) {
     return k < n_batches ? c_begin + k + (slot0 + u * (kRowThreads / 4)) * n_batches : c_end;
   };
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
 #pragma unroll
     for (int u = 0; u < kRowSub; ++u) {
       g0[u] = g1[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (cur[u].token >= 0) {
+      if (cur[u].token >= 0 && !(MSDA_ROWS_SKIP & 16)) {
         const float *gp = grad_out + (((long long)b * S + cur[u].token) * M + m) * 32 + pt * 8;
         g0[u] = ld4(gp);
         g1[u] = ld4(gp + 4);
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
         ly = loc_from_offset<4>(in[u].rs.ry, ly, in[u].rs.sy, ref_dim);
       }
       cells[u] = 0;
-      if (cur[u].token >= 0) {
+      if (cur[u].token >= 0 && (!(MSDA_ROWS_SKIP & 32) || lx == 123.456f)) {
         const Tap<float> tp = make_tap<float>(lx, ly, H, W);
         if (tp.valid && (by_list ? (cur[u].cy >> pt & 1) != 0 : inside_bounds(tp.h_low - cur[u].cy, tp.w_low - cur[u].cx, nb))) {
           const int cy = tp.h_low - (y0 - 1), cx = tp.w_low - (x0 - 1);
@@ -360,6 +361,7 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
   if ((threadIdx.x & 63) == 0)
     for (int i = 0; i < 8; ++i) atomicAdd(&g_rows_stamp[i], (unsigned long long)st_acc[i]);
 #endif
+  if ((MSDA_ROWS_SKIP & 64) && sums[0][0].x != 123.456f) return;
   // ---- corner sums -> rows: out[y, x] = S00[y, x] + S01[y, x - 1] + S10[y - 1, x] + S11[y - 1, x - 1] ---------------------------
   // three shifted adds through LDS (the grad_out buffer: every wave is past its last walk), 32 bytes per lane and round
   const int cy = cell / cw, cx = cell - cy * cw;
