@@ -92,8 +92,11 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
   // plans (optional): the directional plan (msda_plan.h) -- per head the scan runs, chunking and near-bounds; `p` then only
   // supplies the static tiling and the table capacities (the grid is sized for its isotropic worst case: surplus items exit)
   // vmask [B, S] (optional): padded value tokens -- their grad_value rows come out as zero (ms_deform_attn.py:139-140)
-  __shared__ float4 go_lds[kRowBatchQueries * 8];          // grad_out rows of the batch's candidates (this head), 32 KB
-  __shared__ float4 coef_tab[kRowBatchQueries * 4];        // per (candidate slot, point): the four corner coefficients, 16 KB
+  // one pool: the epilogue exchanges all three shifted corner sums through it at once (kRowThreads x 96 bytes)
+  __shared__ float4 lds_pool[kRowBatchQueries * 8 + kRowBatchQueries * 4];
+  float4 *const go_lds = lds_pool;                               // grad_out rows of the batch's candidates (this head), 32 KB
+  float4 *const coef_tab = lds_pool + kRowBatchQueries * 8;      // per (candidate slot, point): the four corner coefficients, 16 KB
+  static_assert(kRowThreads * 6 <= kRowBatchQueries * 12, "the epilogue's exchange fits the pool");
   __shared__ unsigned short bucket[kRowTileRows * (kRowCellCap + 1)];   // per cell: point indices (slot * 4 + point), 16.5 KB
   __shared__ unsigned count[kRowTileRows];
   __shared__ int overflow;                                 // some bucket was full: the batch needs another round
@@ -363,27 +366,31 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
 #endif
   if ((MSDA_ROWS_SKIP & 64) && sums[0][0].x != 123.456f) return;
   // ---- corner sums -> rows: out[y, x] = S00[y, x] + S01[y, x - 1] + S10[y - 1, x] + S11[y - 1, x - 1] ---------------------------
-  // three shifted adds through LDS (the grad_out buffer: every wave is past its last walk), 32 bytes per lane and round
+  // ONE exchange through LDS (the batch tables: every wave is past its last walk): each lane leaves its S01, S10, S11 (96 bytes),
+  // one barrier, each output cell's lanes pick up the three neighbours' sums.  (Three separate 32-byte exchanges cost six barriers:
+  // the epilogue was 9 % of the kernel.)
   const int cy = cell / cw, cx = cell - cy * cw;
-  auto shifted_add = [&](const int j, const int src, const bool take) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-      go_lds[(cell * 4 + quarter) * 2 + kk] = make_float4(sums[j][2 * kk].x, sums[j][2 * kk].y, sums[j][2 * kk + 1].x, sums[j][2 * kk + 1].y);
-    lds_barrier();
-    if (take) {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const float4 v = go_lds[(src * 4 + quarter) * 2 + kk];
-        sums[0][2 * kk] += (rows_v2f){v.x, v.y};
-        sums[0][2 * kk + 1] += (rows_v2f){v.z, v.w};
-      }
-    }
-    lds_barrier();
-  };
   const bool is_out = cell < n_cells && cy >= 1 && cx >= 1;
-  shifted_add(1, cell - 1, is_out);
-  shifted_add(2, cell - cw, is_out);
-  shifted_add(3, cell - cw - 1, is_out);
+  {
+    float4 *mine = lds_pool + (cell * 4 + quarter) * 6;
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        mine[(j - 1) * 2 + kk] = make_float4(sums[j][2 * kk].x, sums[j][2 * kk].y, sums[j][2 * kk + 1].x, sums[j][2 * kk + 1].y);
+    lds_barrier();
+    if (is_out) {
+      const int src[3] = {cell - 1, cell - cw, cell - cw - 1};              // S01 from the left cell, S10 from above, S11 from above-left
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const float4 v = lds_pool[(src[j] * 4 + quarter) * 6 + j * 2 + kk];
+          sums[0][2 * kk] += (rows_v2f){v.x, v.y};
+          sums[0][2 * kk + 1] += (rows_v2f){v.z, v.w};
+        }
+    }
+  }
 
   // ---- write the tile -------------------------------------------------------------------------------------------------
   float4 acc[2];
@@ -400,6 +407,7 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
     }
   } else {
     // several workgroups share the tile: full 128-byte rows of atomics (lane = channel), through LDS
+    lds_barrier();                           // every lane has picked up its neighbours' sums: the pool is free again
     float *rows_lds = reinterpret_cast<float *>(go_lds);
     if (is_out) {
 #pragma unroll
