@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 8
+#define MSDA_ABI_VERSION 9
 
 #define MSDA_E_NULLPTR (-1)   /* a required pointer is NULL                        */
 #define MSDA_E_SHAPE (-2)     /* a dimension is <= 0 or exceeds the indexing range */
@@ -195,6 +195,25 @@ int msda_fused_backward_view_f32(const float *value, int value_token_stride, con
                                  float *grad_value, float *grad_offsets, float *grad_logits, int B, int S, int M, int D, int L,
                                  int Lq, int P, int offsets_row_stride, int logits_row_stride, const int64_t *shapes_host,
                                  const int64_t *level_start_host, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ABI v9 (training): the saved backward's PLAN ahead of the backward.  What the self-attention backward launches in front of its
+ * scatter -- the directional statistics, the per-head plan and the tiles' candidate tables (msda_plan.h, ~35 us of three small
+ * dependent kernels at B = 16) -- depends on the forward's saved sampling locations only.  msda_saved_plan_f32() runs just those
+ * into `workspace` (msda_backward_workspace_bytes() bytes, laid out as the backward lays it out): called right behind the v6 / v7
+ * forward on a SIDE stream, they overlap whatever the caller's main stream does next.  msda_fused_backward_view_planned_f32() is
+ * msda_fused_backward_view_f32(saved = 1) that starts from such a workspace; the caller orders the two (an event) and keeps the
+ * workspace alive and untouched in between.  Same options (msda_set_option) at both calls.  MSDA_E_UNSUPPORTED when the call would
+ * not run on a directional plan (then msda_fused_backward_view_f32 plans for itself).  The reference has no counterpart: its
+ * backward is one kernel (ms_deform_attn_cuda.cu:88-153). */
+int msda_saved_plan_f32(const float *loc_saved, const int64_t *shapes, const int64_t *level_start, int value_token_stride, int B, int S,
+                        int M, int D, int L, int Lq, int P, int offsets_row_stride, int logits_row_stride, const int64_t *shapes_host,
+                        const int64_t *level_start_host, void *workspace, size_t workspace_bytes, void *stream);
+int msda_fused_backward_view_planned_f32(const float *value, int value_token_stride, const unsigned char *value_mask,
+                                         const int64_t *shapes, const int64_t *level_start, const float *loc_saved,
+                                         const float *attn_saved, const float *ref, int ref_dim, const float *grad_out,
+                                         float *grad_value, float *grad_offsets, float *grad_logits, int B, int S, int M, int D, int L,
+                                         int Lq, int P, int offsets_row_stride, int logits_row_stride, const int64_t *shapes_host,
+                                         const int64_t *level_start_host, void *planned_workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

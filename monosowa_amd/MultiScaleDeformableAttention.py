@@ -18,6 +18,8 @@ To make reference code that does ``import MultiScaleDeformableAttention as MSDA`
 """
 import sys
 
+import os
+
 import torch
 
 from ._lib import on_device
@@ -303,7 +305,46 @@ def _fused_forward_view(value, spatial_shapes, level_start_index, proj, referenc
     return out, loc, attw
 
 
-def _fused_backward_view(value, spatial_shapes, level_start_index, a, b, saved, reference_points, grad_output, value_mask, name):
+# Training: the saved backward's plan on a side stream right behind the forward (ABI v9).  OPT-IN (MONOSOWA_PLAN_AHEAD=1): measured
+# in same-box A/B at B = 16 it takes 32 us off every encoder backward (0.907 -> 0.875 ms: the three plan kernels leave the critical
+# path) and ADDS 1.1 ms to the step (69.1 -> 70.2 ms): three cross-stream dependencies per step (a completion signal behind each
+# forward kernel, the allocator's stream bookkeeping for the workspace) cost the main queue more than the 0.1 ms they hide.
+PLAN_AHEAD = os.environ.get("MONOSOWA_PLAN_AHEAD", "0") != "0"
+_PLAN_STREAMS = {}
+
+
+def plan_saved_backward(value, spatial_shapes, level_start_index, loc):
+    """Starts what ``ms_deform_attn_fused_backward_merged_saved`` would launch in front of its scatter -- directional statistics,
+    per-head plan, candidate tables: three small dependent kernels that need the forward's saved locations ``loc`` and nothing else
+    -- on a side stream, behind the forward kernel that wrote ``loc`` and beside whatever the main stream runs next.  Returns a
+    handle for the backward's ``plan=`` argument (workspace + event), or None when the call would not use a directional plan."""
+    if not PLAN_AHEAD or not loc.is_cuda:
+        return None
+    B, S, M, D = value.shape
+    L = P = 4
+    Lq = loc.shape[3]
+    lib = _lib.load()
+    geom = host_geometry(spatial_shapes, level_start_index)
+    ws_bytes = lib.msda_backward_workspace_bytes(B, S, M, D, L, Lq, P, 4)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
+    main = torch.cuda.current_stream(value.device)
+    side = _PLAN_STREAMS.get(value.device.index)
+    if side is None:
+        side = _PLAN_STREAMS[value.device.index] = torch.cuda.Stream(value.device)
+    side.wait_stream(main)                                   # behind the forward kernel (and the allocation of `ws`)
+    with torch.cuda.stream(side), on_device(value.device):
+        code = lib.msda_saved_plan_f32(loc.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), value.stride(1), B, S, M,
+                                       D, L, Lq, P, M * 48, M * 48, geom[0], geom[1], ws.data_ptr(), ws_bytes, _lib.raw_stream())
+        if code == 0:
+            event = side.record_event()
+    if code != 0:
+        return None                                          # (MSDA_E_UNSUPPORTED: the backward plans for itself)
+    ws.record_stream(side)                                   # freed early (no backward)? the allocator waits for the side stream
+    loc.record_stream(side)
+    return ws, event
+
+
+def _fused_backward_view(value, spatial_shapes, level_start_index, a, b, saved, reference_points, grad_output, value_mask, name, plan=None):
     B, S, M, D = value.shape
     L = P = 4
     Lq = a.shape[3] if saved else a.shape[1]
@@ -314,19 +355,29 @@ def _fused_backward_view(value, spatial_shapes, level_start_index, a, b, saved, 
     grad_value = torch.empty((B, S, M, D), dtype=value.dtype, device=value.device)         # always dense
     grad_proj = torch.empty((B, Lq, M * 48), dtype=value.dtype, device=value.device)
     ws_bytes = lib.msda_backward_workspace_bytes(B, S, M, D, L, Lq, P, 4)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
+    planned = saved and plan is not None and plan[0].numel() == ws_bytes and plan[0].device == value.device
+    ws = plan[0] if planned else torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
     timer = LaunchTimer.active
     with on_device(value.device):
+        if planned:
+            torch.cuda.current_stream().wait_event(plan[1])       # the plan kernels have run (side stream)
         stream = torch.cuda.current_stream() if timer is not None else None      # (a Stream object only for the events)
         raw = _lib.raw_stream()
         if timer is not None:
             e0, e1 = timer.bracket("bwd", (B, S, M, D, L, Lq, P))
             e0.record(stream)
-        code = lib.msda_fused_backward_view_f32(
-            value.data_ptr(), ts, mask_ptr, spatial_shapes.data_ptr(), level_start_index.data_ptr(), a.data_ptr(), b.data_ptr(),
-            1 if saved else 0, reference_points.data_ptr(), reference_points.size(3), grad_output.data_ptr(), grad_value.data_ptr(),
-            grad_proj.data_ptr(), grad_proj.data_ptr() + M * 32 * 4, B, S, M, D, L, Lq, P, M * 48, M * 48, geom[0], geom[1],
-            ws.data_ptr(), ws_bytes, raw)
+        if planned:
+            code = lib.msda_fused_backward_view_planned_f32(
+                value.data_ptr(), ts, mask_ptr, spatial_shapes.data_ptr(), level_start_index.data_ptr(), a.data_ptr(), b.data_ptr(),
+                reference_points.data_ptr(), reference_points.size(3), grad_output.data_ptr(), grad_value.data_ptr(),
+                grad_proj.data_ptr(), grad_proj.data_ptr() + M * 32 * 4, B, S, M, D, L, Lq, P, M * 48, M * 48, geom[0], geom[1],
+                ws.data_ptr(), ws_bytes, raw)
+        else:
+            code = lib.msda_fused_backward_view_f32(
+                value.data_ptr(), ts, mask_ptr, spatial_shapes.data_ptr(), level_start_index.data_ptr(), a.data_ptr(), b.data_ptr(),
+                1 if saved else 0, reference_points.data_ptr(), reference_points.size(3), grad_output.data_ptr(), grad_value.data_ptr(),
+                grad_proj.data_ptr(), grad_proj.data_ptr() + M * 32 * 4, B, S, M, D, L, Lq, P, M * 48, M * 48, geom[0], geom[1],
+                ws.data_ptr(), ws_bytes, raw)
         if timer is not None:
             e1.record(stream)
     _lib.check(code, name)
@@ -369,7 +420,8 @@ def ms_deform_attn_fused_forward_merged_save(value, spatial_shapes, level_start_
 
 
 def ms_deform_attn_fused_backward_merged_saved(value, spatial_shapes, level_start_index, loc, attw, reference_points,
-                                               grad_output, value_mask=None):
-    """-> grad_value, grad_proj [B, Lq, M*48] (grad offsets | grad logits), from the saved locations / weights."""
+                                               grad_output, value_mask=None, plan=None):
+    """-> grad_value, grad_proj [B, Lq, M*48] (grad offsets | grad logits), from the saved locations / weights.
+    ``plan``: the handle ``plan_saved_backward`` returned for these ``loc`` (or None: the backward plans for itself)."""
     return _fused_backward_view(value, spatial_shapes, level_start_index, loc, attw, True, reference_points, grad_output,
-                                value_mask, "ms_deform_attn_fused_backward_merged_saved")
+                                value_mask, "ms_deform_attn_fused_backward_merged_saved", plan=plan)

@@ -10,11 +10,11 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmonosowa_msda.so")
 SYMBOLS = ("msda_abi_version", "msda_strerror", "msda_set_option", "msda_backward_workspace_bytes",
            "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64",
            "msda_fused_forward_f32", "msda_fused_backward_f32", "msda_fused_forward_strided_f32",
-           "msda_fused_backward_strided_f32", "msda_fused_save_supported", "msda_fused_save_supported_view", "msda_fused_forward_save_f32", "msda_fused_forward_view_f32", "msda_fused_backward_view_f32",
+           "msda_fused_backward_strided_f32", "msda_fused_save_supported", "msda_fused_save_supported_view", "msda_fused_forward_save_f32", "msda_fused_forward_view_f32", "msda_fused_backward_view_f32", "msda_saved_plan_f32", "msda_fused_backward_view_planned_f32",
            "msda_fused_backward_saved_f32")
 
 _lib = None
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class MSDALibraryError(RuntimeError):
@@ -68,6 +68,10 @@ def load():
     # (value, token stride, mask, shapes, lsi, offsets|loc, logits|attn, saved, ref, ref_dim, grad_out, gv, goff, glog, B..P, ...)
     lib.msda_fused_backward_view_f32.restype = I
     lib.msda_fused_backward_view_f32.argtypes = [P, I, P, P, P, P, P, I, P, I, P, P, P, P] + [I] * 9 + [P, P, P, Z, P]
+    lib.msda_saved_plan_f32.restype = I
+    lib.msda_saved_plan_f32.argtypes = [P, P, P, I] + [I] * 7 + [I, I, P, P, P, Z, P]
+    lib.msda_fused_backward_view_planned_f32.restype = I
+    lib.msda_fused_backward_view_planned_f32.argtypes = [P, I, P, P, P, P, P, P, I, P, P, P, P] + [I] * 9 + [P, P, P, Z, P]
     if lib.msda_abi_version() != ABI_VERSION:
         raise MSDALibraryError("ABI version mismatch in %s" % LIB_PATH)
     _lib = lib

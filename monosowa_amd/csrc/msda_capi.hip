@@ -384,10 +384,14 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
                   int B, int S, int M, int D, int L, int Lq, int P, const int64_t *shapes_host,
                   const int64_t *lsi_host, void *workspace, size_t workspace_bytes, void *stream_,
                   const float *fused_ref = nullptr, int fused_ref_dim = 0, int loc_rs = 0, int aw_rs = 0, bool saved = false,
-                  ValueView vv = ValueView()) {
+                  ValueView vv = ValueView(), int plan_mode = 0) {
+  // plan_mode (saved self-attention backward, ABI v9): 0 = plan and run; 1 = PLAN ONLY -- the directional statistics, the per-head
+  // plan and the candidate tables go into `workspace` and nothing else happens (they depend on the forward's saved locations
+  // only, so the caller runs them early, on a side stream); 2 = run from the plan a mode-1 call left in `workspace`
   // saved: `loc` / `attw` are the sampling locations / attention weights the fused forward stored (contiguous); the
   // gradients still go back to raw offsets / logits through `fused_ref` and the row strides (self-attention shape only)
-  if (!value || !shapes || !lsi || !loc || !attw || !grad_out || !grad_value || !grad_loc || !grad_attw)
+  if (plan_mode == 1 ? (!loc || !shapes || !lsi) :
+      (!value || !shapes || !lsi || !loc || !attw || !grad_out || !grad_value || !grad_loc || !grad_attw))
     return MSDA_E_NULLPTR;
   if (int e = check_dims(B, S, M, D, L, Lq, P)) return e;
   hipStream_t stream = (hipStream_t)stream_;
@@ -416,6 +420,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
         msda::RowPlan rp;
         // ---- saved backward: exact scan lists (msda_bin.hip) -- one streaming pass over the saved locations bins every (query,
         // level) unit into the tiles its points fall into; the cell scatter scans exactly those, whatever the offsets look like
+        if (plan_mode && options().scatter_lists) return MSDA_E_UNSUPPORTED;      // the exact lists have no plan to run ahead
         if (saved && options().scatter_lists && msda::make_row_plan(shapes_host, lsi_host, options().scatter_reach, rp)) {
           msda::BinPlan bp{};
           int n_tiles = 0, entries = 0;
@@ -484,7 +489,8 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
           msda::RowCandidate *table = reinterpret_cast<msda::RowCandidate *>(wsp + plan_b + stats_b);
           int n_tiles = 0;
           for (int l = 0; l < 4; ++l) n_tiles += rp.n_ty[l] * rp.n_tx[l];
-          if (directional) {
+          if (plan_mode && !(directional && saved)) return MSDA_E_UNSUPPORTED;
+          if (directional && plan_mode != 2) {
             msda::DirStats *partial = reinterpret_cast<msda::DirStats *>(wsp + plan_b);
             msda::PlanGeom pg{};
             msda::WinGeom wg;
@@ -504,7 +510,9 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
                   loc, fused_ref, pg, B, loc_rs ? loc_rs : M * 32, partial);
             msda::dir_plan_kernel<<<M, 256, 0, stream>>>(partial, msda::kStatsBlocks, pg, rp, plans);
           }
-          msda::row_candidates_kernel<<<n_tiles * (directional ? M : 1), 256, 0, stream>>>(rp, table, plans, n_tiles);
+          if (plan_mode != 2)
+            msda::row_candidates_kernel<<<n_tiles * (directional ? M : 1), 256, 0, stream>>>(rp, table, plans, n_tiles);
+          if (plan_mode == 1) return launch_status();
           for (int l = 0; l < L; ++l) {          // levels shared by several workgroups are accumulated with atomics
             if (rp.n_chunks[l] == 1) continue;
             hipError_t e = hipMemset2DAsync(grad_value + (size_t)rp.start[l] * M * 32, sizeof(float) * (size_t)S * M * 32, 0,
@@ -534,7 +542,7 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
           return launch_status();
         }
       }
-      if (saved) return MSDA_E_UNSUPPORTED;          // msda_fused_save_supported() said otherwise
+      if (saved || plan_mode) return MSDA_E_UNSUPPORTED;          // msda_fused_save_supported() said otherwise
       const msda::BwdPlan plan = make_plan(shapes_host, lsi_host, L, Lq, P);
       if ((long long)Lq * P >= (1LL << (62 - msda::kFixBits))) return MSDA_E_SHAPE;   // fixed-point headroom
       const TiledWorkspace ws = tiled_workspace(B, M, L, Lq, P);
@@ -703,6 +711,44 @@ int msda_fused_backward_view_f32(const float *value, int value_token_stride, con
   return backward_impl<float>(value, shapes, level_start, offsets_or_loc, logits_or_attn, grad_out, grad_value, grad_offsets,
                               grad_logits, B, S, M, D, L, Lq, P, shapes_host, level_start_host, workspace, workspace_bytes,
                               stream, ref, ref_dim, offsets_row_stride, logits_row_stride, saved != 0, vv);
+}
+
+// ---- ABI v9: the saved backward's plan ahead of the backward ----------------------------------------------------------------------
+int msda_saved_plan_f32(const float *loc_saved, const int64_t *shapes, const int64_t *level_start, int value_token_stride, int B, int S,
+                        int M, int D, int L, int Lq, int P, int offsets_row_stride, int logits_row_stride, const int64_t *shapes_host,
+                        const int64_t *level_start_host, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!loc_saved || !shapes_host || !level_start_host || !workspace) return MSDA_E_NULLPTR;
+  if (!msda_fused_save_supported_view(S, M, D, L, Lq, P, 2, value_token_stride, offsets_row_stride, logits_row_stride, shapes_host,
+                                      level_start_host))
+    return MSDA_E_UNSUPPORTED;
+  ValueView vv;
+  vv.token_stride = value_token_stride;
+  static const float dummy_ref = 0.f;            // (a 2-d reference is what the saved path requires; never read in plan mode)
+  return backward_impl<float>(nullptr, shapes, level_start, loc_saved, nullptr, nullptr, nullptr, nullptr, nullptr, B, S, M, D, L, Lq, P,
+                              shapes_host, level_start_host, workspace, workspace_bytes, stream, &dummy_ref, 2, offsets_row_stride,
+                              logits_row_stride, true, vv, 1);
+}
+
+int msda_fused_backward_view_planned_f32(const float *value, int value_token_stride, const unsigned char *value_mask,
+                                         const int64_t *shapes, const int64_t *level_start, const float *loc_saved,
+                                         const float *attn_saved, const float *ref, int ref_dim, const float *grad_out,
+                                         float *grad_value, float *grad_offsets, float *grad_logits, int B, int S, int M, int D, int L,
+                                         int Lq, int P, int offsets_row_stride, int logits_row_stride, const int64_t *shapes_host,
+                                         const int64_t *level_start_host, void *planned_workspace, size_t workspace_bytes, void *stream) {
+  if (!ref || !shapes_host || !level_start_host || !planned_workspace) return MSDA_E_NULLPTR;
+  if (!(D == 32 && L == 4 && P == 4) || ref_dim != 2) return MSDA_E_UNSUPPORTED;
+  if (offsets_row_stride < M * 32 || logits_row_stride < M * 16 || (offsets_row_stride & 3) || (logits_row_stride & 3))
+    return MSDA_E_SHAPE;
+  if (value_token_stride < M * 32 || (value_token_stride & 3) || (long long)S * value_token_stride >= (1LL << 31)) return MSDA_E_SHAPE;
+  if (!msda_fused_save_supported_view(S, M, D, L, Lq, P, ref_dim, value_token_stride, offsets_row_stride, logits_row_stride,
+                                      shapes_host, level_start_host))
+    return MSDA_E_UNSUPPORTED;
+  ValueView vv;
+  vv.token_stride = value_token_stride;
+  vv.mask = value_mask;
+  return backward_impl<float>(value, shapes, level_start, loc_saved, attn_saved, grad_out, grad_value, grad_offsets, grad_logits, B, S, M,
+                              D, L, Lq, P, shapes_host, level_start_host, planned_workspace, workspace_bytes, stream, ref, ref_dim,
+                              offsets_row_stride, logits_row_stride, true, vv, 2);
 }
 
 int msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *level_start,

@@ -49,6 +49,7 @@ class _AttnBlock(torch.autograd.Function):
                 # keep the sampling locations / attention weights the kernel evaluated instead of the raw projection
                 # (same bytes): the backward's two kernels then skip softmax + location arithmetic (ABI v6)
                 a, off, logit = MSDA.ms_deform_attn_fused_forward_merged_save(v, shapes, lsi, proj, ref)
+                ctx.msda_plan = MSDA.plan_saved_backward(v, shapes, lsi, off)      # side stream: under the GEMMs that follow
                 proj = None
             else:
                 a = MSDA.ms_deform_attn_fused_forward_merged(v, shapes, lsi, proj, ref)
@@ -81,7 +82,8 @@ class _AttnBlock(torch.autograd.Function):
         n_off = wo.shape[0]
         if ctx.merged:
             if ctx.saved_prologue:          # `off` / `logit` hold the saved sampling locations / attention weights
-                gv, gproj = MSDA.ms_deform_attn_fused_backward_merged_saved(v, shapes, lsi, off, logit, ref, ga.contiguous())
+                gv, gproj = MSDA.ms_deform_attn_fused_backward_merged_saved(v, shapes, lsi, off, logit, ref, ga.contiguous(),
+                                                                            plan=getattr(ctx, "msda_plan", None))
             else:
                 gv, gproj = MSDA.ms_deform_attn_fused_backward_merged(v, shapes, lsi, proj, ref, ga.contiguous())
             gp2 = gproj.view(-1, gproj.shape[-1])

@@ -81,6 +81,7 @@ class MSDeformAttnFusedMergedFunction(Function):
             # (250 MB per encoder layer at B = 16) so that neither backward kernel re-evaluates softmax + location math
             output, loc, attw = MSDA.ms_deform_attn_fused_forward_merged_save(value, spatial_shapes, level_start_index, proj,
                                                                               reference_points, value_mask)
+            ctx.msda_plan = MSDA.plan_saved_backward(value, spatial_shapes, level_start_index, loc)
             ctx.save_for_backward(value, spatial_shapes, level_start_index, loc, attw, reference_points)
         else:
             output = MSDA.ms_deform_attn_fused_forward_merged(value, spatial_shapes, level_start_index, proj, reference_points,
@@ -95,7 +96,7 @@ class MSDeformAttnFusedMergedFunction(Function):
             value, shapes, lsi, loc, attw, ref = ctx.saved_tensors
             MSDA.attach_host_geometry(shapes, lsi, *_unpack_geom(ctx.host_geom))
             gv, gproj = MSDA.ms_deform_attn_fused_backward_merged_saved(value, shapes, lsi, loc, attw, ref, grad_output.contiguous(),
-                                                                        ctx.value_mask)
+                                                                        ctx.value_mask, plan=getattr(ctx, "msda_plan", None))
             return gv, None, None, gproj, None, None
         value, shapes, lsi, proj, ref = ctx.saved_tensors
         MSDA.attach_host_geometry(shapes, lsi, *_unpack_geom(ctx.host_geom))

@@ -1367,3 +1367,44 @@ def test_strided_fused_operator_reads_a_merged_projection_in_place():
     # float atomics: order-dependent in the last bits) -- equal to rounding, not bitwise
     assert (gv_m - gv_s).abs().max() <= 2e-6 * gv_s.abs().max()
     assert torch.equal(gp[..., :M * 32], goff.view(B, Lq, -1)) and torch.equal(gp[..., M * 32:], glog.view(B, Lq, -1))
+
+
+@pytest.mark.gpu
+def test_saved_backward_from_a_plan_made_ahead_on_a_side_stream_equals_the_self_planning_one():
+    """ABI v9: ``plan_saved_backward`` runs the directional statistics / plan / candidate tables right behind the forward on a side
+    stream; the backward that starts from that workspace must produce exactly what the backward that plans for itself produces
+    (same kernels on the same tables), with and without a padding mask, and a plan nobody uses must be harmless."""
+    from monosowa_amd import MultiScaleDeformableAttention as M
+    MSDA = _msda()
+    torch.manual_seed(5)
+    levels = [(48, 160), (24, 80), (12, 40), (6, 20)]
+    B, Mh, D, L, P = 2, 8, 32, 4, 4
+    shapes = torch.tensor(levels, dtype=torch.long, device="cuda")
+    lsi = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    MSDA.attach_host_geometry(shapes, lsi, levels, lsi.tolist())
+    S = int(shapes.prod(1).sum())
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h, device="cuda") + 0.5) / h, (torch.arange(w, device="cuda") + 0.5) / w,
+                                                indexing="ij")[::-1], -1).reshape(-1, 2) for h, w in levels])
+    ref = ref[None, :, None, :].expand(B, S, L, 2).contiguous()
+    value = torch.randn(B, S, Mh, D, device="cuda")
+    proj = torch.cat([torch.randn(B, S, Mh * 32, device="cuda") * 2.5, torch.randn(B, S, Mh * 16, device="cuda")], -1)
+    go = torch.randn(B, S, Mh * D, device="cuda")
+    for mask in (None, torch.rand(B, S, device="cuda") < 0.2):
+        assert M.fused_save_supported(value, shapes, lsi, S, 2)
+        out, loc, attw = M.ms_deform_attn_fused_forward_merged_save(value, shapes, lsi, proj, ref, mask)
+        was, M.PLAN_AHEAD = M.PLAN_AHEAD, True                           # (opt-in: see the module)
+        try:
+            plan = M.plan_saved_backward(value, shapes, lsi, loc)
+            unused = M.plan_saved_backward(value, shapes, lsi, loc)      # dropped without a backward
+        finally:
+            M.PLAN_AHEAD = was
+        assert plan is not None
+        del unused
+        torch.randn(1 << 22, device="cuda").sum()                        # main-stream work between the two calls
+        gv_a, gp_a = M.ms_deform_attn_fused_backward_merged_saved(value, shapes, lsi, loc, attw, ref, go, mask, plan=plan)
+        gv_b, gp_b = M.ms_deform_attn_fused_backward_merged_saved(value, shapes, lsi, loc, attw, ref, go, mask)
+        torch.cuda.synchronize()
+        assert torch.equal(gp_a, gp_b)
+        # grad_value: a cell's points are summed in the order their lanes drew bucket slots (and far points / shared coarse tiles
+        # with atomics): equal up to the order of float additions, call to call
+        assert (gv_a - gv_b).abs().max() <= 1e-5 * gv_b.abs().max()
