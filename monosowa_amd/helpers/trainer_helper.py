@@ -162,6 +162,11 @@ class Trainer(object):
                 self._log(batch_idx, loss_dict)
             bar.update()
         bar.close()
+        # the device assignment solver reports an invalid cost matrix through a status word (no exception from a kernel, no wait in
+        # the step): look at it for certain before the epoch's checkpoint is written
+        matcher = getattr(self.detr_loss, "matcher", None)
+        if matcher is not None and hasattr(matcher, "check_device_status"):
+            matcher.check_device_status(block=True)
 
     def _log(self, batch_idx, loss_dict):
         weight_dict = self.detr_loss.weight_dict
