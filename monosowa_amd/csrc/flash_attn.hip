@@ -20,6 +20,9 @@ namespace attn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef ATTN_FWD_WAVES
+#define ATTN_FWD_WAVES 4        // waves per SIMD the forward is compiled for: 128 VGPRs, no spills (2: 130 VGPRs with dropout = 3 waves; in the step 703 -> 686 us on the 1920 x 1920 launch)
+#endif
 constexpr int kBlockQ = 128;     // queries per workgroup (4 waves x 32)
 constexpr int kTileK = 64;       // keys per LDS tile
 constexpr int kKStride = 36;     // floats per K row in LDS: 16-lane ds_read_b128 phases hit 64 distinct banks
@@ -59,7 +62,7 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __bu
 
 // ---------------------------------------------------------------------------------------------- forward
 template <bool DROP>
-__global__ __launch_bounds__(256, 2) void fwd_kernel(const Args a) {
+__global__ __launch_bounds__(256, ATTN_FWD_WAVES) void fwd_kernel(const Args a) {
   __shared__ float Ks[2][kTileK * kKStride];
   __shared__ float Vs[2][kTileK * kVStride];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
