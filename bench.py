@@ -251,12 +251,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the CPU path is only the cpu_baseline leg)")
+    # rehearsal of the N > 1 path on a ONE-GPU box (tests, tools): every rank on device 0, collectives over gloo (RCCL refuses two
+    # ranks on one device).  Never set by the driver: its ranks get one GPU each and RCCL.
+    rehearsal = os.environ.get("MONOSOWA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     # with the shipped find-db MIOpen's immediate mode (benchmark off) already returns the measured winners: no search,
     # no 25 s start-up; --miopen-find runs a fresh search

@@ -270,3 +270,25 @@ def test_bench_self_launch_relays_the_same_line_as_the_plain_run():
     plain, relayed = lines
     assert relayed["n_gpus"] == 1 and relayed["metric"] == plain["metric"] and relayed["config"] == plain["config"]
     assert abs(relayed["value"] - plain["value"]) <= 0.05 * plain["value"], (plain["value"], relayed["value"])
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_on_one_gpu_prints_the_contract_line():
+    """The N > 1 control path of bench.py end to end -- self-launch of two ranks, DDP, the pre-heat's agreement on "time is up", the
+    barriers and max-over-ranks timing, the inference leg, the final barrier -- rehearsed on the box's ONE GPU: both ranks on
+    device 0, collectives over gloo (MONOSOWA_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device).  The numbers mean
+    nothing (two ranks share the GPU); what matters is that the run ends, with one JSON line that says n_gpus = 2."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MONOSOWA_BENCH_REHEARSAL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--preheat-seconds", "2",
+           "--inference-steps", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(out) == 1, r.stdout[-2000:]
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 32 and line["config"]["parallelism"] == "dp2"
+    assert line["scaling"] == "weak" and line["value"] > 0 and line["inference"]["value"] > 0
+    assert "cpu_baseline" not in line                       # rank 0 at N = 1 only
