@@ -65,6 +65,12 @@ def parse():
                     help="config 5: the batch mixes fu in {721.5, 552.6, 2055} (per-sample Canonical Object Space scale)")
     ap.add_argument("--no-inference-leg", action="store_true", help="skip the eval-mode leg of the train line")
     ap.add_argument("--inference-steps", type=int, default=20)
+    ap.add_argument("--no-dataloader-leg", action="store_true", help="skip the DataLoader-fed leg of the train line")
+    ap.add_argument("--dataloader-workers", type=int, default=4, help="reference: 4 (lib/helpers/dataloader_helper.py:21-34)")
+    ap.add_argument("--resample-from", default="",
+                    help="WxH of the RAW camera images (config 4, 'reference-resampled' variant: 1408x376): the resident batch holds them "
+                         "at that size and every step first resamples them to --resolution on the device, which is what the reference's "
+                         "loader does on the host for every image (kitti_dataset.py:37,202-206); the model then runs at --resolution")
     ap.add_argument("--no-miopen-db", action="store_true",
                     help="ignore the shipped MIOpen find results (monosowa_amd/miopen_db) and use MIOpen's heuristics")
     return ap.parse_args()
@@ -79,6 +85,21 @@ def msda_alg_bytes(kind, dims):
     if kind == "fwd":
         return 4 * B * (min(S, Lq * L * P * 4) * M * D + Lq * M * L * P * 3 + Lq * M * D)
     return 4 * B * (Lq * M * D + min(S, Lq * L * P * 4) * M * D + Lq * M * L * P * 3 + S * M * D + Lq * M * L * P * 3)
+
+
+def git_head():
+    """Short hash of the checked-out commit (+ "-dirty"), or None outside a git checkout (the GPU box's snapshot has no .git:
+    tools/collect_pmc.sh and the build step leave it in monosowa_amd/lib/BUILD_COMMIT)."""
+    import subprocess
+    try:
+        h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10)
+        if h.returncode == 0:
+            d = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True, timeout=10)
+            return h.stdout.strip() + ("-dirty" if d.stdout.strip() else "")
+    except Exception:
+        pass
+    f = os.path.join(ROOT, "monosowa_amd", "lib", "BUILD_COMMIT")
+    return open(f).read().strip() if os.path.exists(f) else None
 
 
 def dims_S(timer):
@@ -141,18 +162,71 @@ def train_step_fn(model, criterion, optimizer, accum=1):
     return step
 
 
+def dataloader_leg(args, step, device, world, rank, resolution):
+    import torch
+    from monosowa_amd.helpers.dataloader_helper import build_dataloader
+    from monosowa_amd.helpers.trainer_helper import stage_batch
+    n_warm = 2                                           # worker start-up + first batches: untimed
+    dcfg = {"type": "synthetic", "batch_size": args.batch, "train_split": "train", "test_split": "val", "resolution": resolution,
+            "num_samples": args.batch * (args.steps + n_warm), "seed_offset": rank}
+    loader, _ = build_dataloader(dcfg, workers=args.dataloader_workers, drop_last=True, test=False)
+    it = iter(loader)
+    for _ in range(n_warm):
+        step(stage_batch(next(it), device))
+    barrier_sync(device)
+    t0 = time.perf_counter()
+    n = 0
+    for raw in it:
+        step(stage_batch(raw, device))
+        n += 1
+    barrier_sync(device)
+    dt = max_over_ranks(time.perf_counter() - t0, device)
+    assert n == args.steps, (n, args.steps)
+    del it, loader
+    return {"value": args.batch * world * n / dt, "unit": "img/s", "steps": n, "ms_per_step": dt / n * 1e3,
+            "workers": args.dataloader_workers, "pin_memory": True,
+            "workload": "the same train step fed by torch DataLoader(SyntheticKITTI): %d workers, default collate, pinned buffers, "
+                        "non_blocking H2D of every key (the reference loop: dataloader_helper.py:21-34, trainer_helper.py:121-127)"
+                        % args.dataloader_workers}
+
+
 def cpu_baseline(args):
     """The CPU path (our restatement; MSDA core = the oracle's grid_sample port of the reference's only
-    CPU-capable definition, ms_deform_attn_func.py:41-61) on this host's cores, bounded sample."""
+    CPU-capable definition, ms_deform_attn_func.py:41-61) on this host's cores, bounded sample.  BASELINE.md section 2's
+    protocol: training at B = 2 (>= 3 timed steps after 1 warm-up) and at B = 16, inference (eval, 50 queries), and the share of
+    the step's wall time spent inside the MSDA core."""
     import torch
     import monosowa_amd.ms_deform_attn_func as F
     from oracle import msda_oracle as O
     from monosowa_amd.synthetic import make_batch
 
+    core = {"fwd": 0.0, "bwd": 0.0, "t_bwd": None}
+
     class _CPUFn:
         @staticmethod
         def apply(value, shapes, lsi, loc, w, step):
-            return O.msda_core_torch(value, shapes, loc, w)
+            # wall time inside the core: the forward directly; the backward between the autograd engine reaching the core's output
+            # gradient and the last of its three input gradients (the core's nodes run back to back on the engine's one CPU thread)
+            t0 = time.perf_counter()
+            out = O.msda_core_torch(value, shapes, loc, w)
+            core["fwd"] += time.perf_counter() - t0
+            if out.requires_grad:
+                def enter(g):
+                    core["t_bwd"] = time.perf_counter()
+                    core["left"] = sum(1 for t in (value, loc, w) if t.requires_grad)
+                    return g
+
+                def leave(g):
+                    core["left"] -= 1
+                    if core["left"] == 0 and core["t_bwd"] is not None:
+                        core["bwd"] += time.perf_counter() - core["t_bwd"]
+                        core["t_bwd"] = None
+                    return g
+                out.register_hook(enter)
+                for t in (value, loc, w):
+                    if t.requires_grad:
+                        t.register_hook(leave)
+            return out
 
     saved = F.MSDeformAttnFunction
     F.MSDeformAttnFunction = _CPUFn
@@ -168,15 +242,50 @@ def cpu_baseline(args):
         tw = time.time()
         step(batch)                          # 1 warm-up step, not timed
         tw = time.time() - tw
+        core["fwd"] = core["bwd"] = 0.0
         t0 = time.time()
         n = 0
         while n < 3 or (time.time() - t0 < 10.0 and n < 8):      # >= 3 timed steps
             step(batch)
             n += 1
         dt = time.time() - t0
-        return {"value": B * n / dt, "unit": "img/s", "cores": cores, "kind": "port",
-                "sample": "%d timed train steps (fwd+criterion+bwd+AdamW) after 1 warm-up step (%.1f s) at batch %d, %dx%d, "
-                          "fp32, %.1f s timed" % (n, tw, B, W, H, dt)}
+        out = {"value": B * n / dt, "unit": "img/s", "cores": cores, "kind": "port",
+               "sample": "%d timed train steps (fwd+criterion+bwd+AdamW) after 1 warm-up step (%.1f s) at batch %d, %dx%d, "
+                         "fp32, %.1f s timed" % (n, tw, B, W, H, dt),
+               "msda_share": {"value": (core["fwd"] + core["bwd"]) / dt, "forward": core["fwd"] / dt, "backward": core["bwd"] / dt,
+                              "what": "wall time inside the MSDA core (grid_sample formulation, 6 calls per step) / step wall time, "
+                                      "batch %d train steps; backward by autograd hooks on the core's output / inputs" % B}}
+        log("cpu_baseline: batch %d train %.3f img/s, MSDA core %.0f %% of the step" % (B, out["value"], 100 * out["msda_share"]["value"]))
+        # ---- inference (eval, 50 queries), batch B ---------------------------------------------------------------------------
+        model.eval()
+        with torch.no_grad():
+            model(batch[0], batch[1], None, batch[2]["img_size"])          # warm-up
+            t0 = time.time()
+            ni = 0
+            while ni < 3 or (time.time() - t0 < 6.0 and ni < 8):
+                model(batch[0], batch[1], None, batch[2]["img_size"])
+                ni += 1
+            dti = time.time() - t0
+        out["inference"] = {"value": B * ni / dti, "unit": "img/s",
+                            "sample": "%d eval forwards (%d queries) after 1 warm-up at batch %d, %.1f s timed"
+                                      % (ni, int(getattr(model, "num_queries", 50)), B, dti)}
+        log("cpu_baseline: batch %d inference %.3f img/s" % (B, out["inference"]["value"]))
+        # ---- training at the headline batch: ONE timed step, no warm-up of its own (the libraries are warm from the steps above;
+        # the B = 2 warm-up step ran 1.3x a timed one) -- bounded: skipped when the B = 2 rate predicts more than 150 s ---------------
+        model.train()
+        predicted = args.batch / out["value"]
+        if args.batch > B and predicted <= 150.0:
+            big = make_batch(args.batch, cpu, seed=445, resolution=(W, H))
+            t0 = time.time()
+            step(big)
+            dtb = time.time() - t0
+            out["b%d" % args.batch] = {"value": args.batch / dtb, "unit": "img/s",
+                                       "sample": "1 timed train step at batch %d (no warm-up step of its own: 1 + %d steps at batch %d ran "
+                                                 "before it), %.1f s" % (args.batch, n, B, dtb)}
+            log("cpu_baseline: batch %d train %.3f img/s" % (args.batch, out["b%d" % args.batch]["value"]))
+        elif args.batch > B:
+            out["b%d" % args.batch] = {"value": None, "sample": "skipped: %.0f s predicted for one step from the batch-%d rate" % (predicted, B)}
+        return out
     finally:
         F.MSDeformAttnFunction = saved
 
@@ -196,11 +305,15 @@ class _StdoutGuard:
         os.close(self.saved)
 
 
-def default_conv_workload(args):
-    """The configurations the shipped find-db / GEMM choices were measured on (monosowa_amd/miopen_db: BASELINE configs[1],
-    config 4 = ResNet-101 at 1408x376, config 5 = 1920x1280 at batch 4; tools/tune_configs.sh).  MIOpen's immediate mode falls
-    back to its heuristics for a problem the database does not hold, so any other workload still runs -- just untuned."""
-    return True
+TUNED_WORKLOADS = (("resnet50", "1280x384", 16), ("resnet101", "1408x376", 16), ("resnet50", "1920x1280", 4))
+
+
+def tuned_workload(args):
+    """Whether the shipped find-db / GEMM choices were MEASURED on this workload (monosowa_amd/miopen_db: BASELINE configs[1],
+    config 4 = ResNet-101 at 1408x376, config 5 = 1920x1280 at batch 4; tools/tune_configs.sh).  The database is offered to every
+    workload -- MIOpen's immediate mode falls back to its heuristics for a problem it does not hold -- and the line says
+    ``"tuned": false`` when the workload is not one of the three."""
+    return (args.backbone, args.resolution, args.batch) in TUNED_WORKLOADS and not args.resample_from
 
 
 def any_rank_says(flag, device):
@@ -214,6 +327,58 @@ def any_rank_says(flag, device):
     t = torch.tensor([1 if flag else 0], device=device, dtype=torch.int32)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return bool(t.item())
+
+
+def max_over_ranks(seconds, device):
+    """The slowest rank's time, on every rank (the contract's "take the MAX over ranks")."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier_sync(device):
+    """Barrier + device synchronisation: brackets every timed region on both sides."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+
+
+def timed_steps(step, batch, steps, device):
+    """EXACTLY `steps` steps between two barrier_sync()s; returns the max-over-ranks seconds."""
+    barrier_sync(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(batch)
+    barrier_sync(device)
+    return max_over_ranks(time.perf_counter() - t0, device)
+
+
+def preheat(step, batch, seconds, device, sync):
+    """Untimed steps for `seconds` of this rank's clock; every rank leaves the loop after the same number of steps."""
+    t1, n = time.time(), 0
+    while not any_rank_says(time.time() - t1 >= seconds, device):
+        step(batch)
+        sync()
+        n += 1
+    return n, time.time() - t1
+
+
+_TRACE = os.environ.get("MONOSOWA_BENCH_TRACE") == "1" or os.environ.get("MONOSOWA_BENCH_REHEARSAL") == "1"
+
+
+def trace(msg):
+    """Per-RANK progress line (rehearsals and MONOSOWA_BENCH_TRACE=1 only): which rank is where, when a multi-process run is slow or
+    stuck.  Costs nothing on the driver's path."""
+    if _TRACE:
+        sys.stderr.write("[bench %7.1fs rank %s] %s\n" % (time.time() - _T0, os.environ.get("RANK", "0"), msg))
+        sys.stderr.flush()
 
 
 def launch_ranks(args):
@@ -242,7 +407,7 @@ def main():
     # measured MIOpen kernel choices for the default workload (monosowa_amd/miopen_tuning.py); before torch loads MIOpen
     from monosowa_amd import miopen_tuning
     tuned = None
-    if not args.no_miopen_db and not args.miopen_find and default_conv_workload(args):
+    if not args.no_miopen_db and not args.miopen_find:
         tuned = miopen_tuning.use_shipped_db(int(os.environ.get("RANK", "0")))
     import torch
     import torch.distributed as dist
@@ -255,6 +420,13 @@ def main():
     # ranks on one device).  Never set by the driver: its ranks get one GPU each and RCCL.
     rehearsal = os.environ.get("MONOSOWA_BENCH_REHEARSAL") == "1"
     if rehearsal:
+        if world > 2:
+            # measured (gpurun_out/reh_b2_3.err): three ranks finish, at 23.6 s per B = 2 train step against 0.028 s per eval step of the
+            # same ranks -- the time goes into gloo's host-staged all-reduce of 150 MB of gradients from processes sharing one box's
+            # CPU quota, not into the GPU; four ranks (reh4.err, reh_b2_4.err) did not finish a step in 198 - 397 s.  Nothing about
+            # the N > 2 path is learnt that way that the world-size-8 gloo tests of the control path do not cover on the CPU.
+            raise SystemExit("MONOSOWA_BENCH_REHEARSAL=1 supports WORLD_SIZE <= 2 (more ranks on one device only measure gloo's "
+                             "host-staged all-reduce); the N > 2 control path is covered by tests/test_distributed_gloo.py")
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -283,60 +455,79 @@ def main():
     model = wrap_ddp(model, device)
     batch = make_batch(args.batch, device, seed=444 + rank, resolution=(W, H), mixed_cameras=args.mixed_cameras)
     batch = (batch[0].contiguous(memory_format=torch.channels_last),) + batch[1:]
+    resample = None
+    if args.resample_from:
+        # "reference-resampled" variant: the resident batch holds the RAW camera images; every step starts by
+        # resampling them to the network resolution (bilinear, like the reference loader's PIL affine transform,
+        # kitti_dataset.py:202-206) -- on the device, inside the timed region.  The pseudo-labels are normalised coordinates:
+        # unchanged by the resampling.
+        Wr, Hr = (int(x) for x in args.resample_from.split("x"))
+        g = torch.Generator(device=device).manual_seed(444 + rank)
+        raw = torch.randn(args.batch, 3, Hr, Wr, device=device, generator=g)
+
+        def resample(b):
+            x = torch.nn.functional.interpolate(b[0], size=(H, W), mode="bilinear", align_corners=False)
+            return (x.contiguous(memory_format=torch.channels_last),) + tuple(b[1:])
+        batch = (raw,) + batch[1:]
     accum = 1
     if args.global_batch:
         assert train and args.global_batch % (args.batch * world) == 0, "--global-batch must be a multiple of gpus * batch"
         accum = args.global_batch // (args.batch * world)
 
     if train:
-        step = train_step_fn(model, criterion, optimizer, accum)
+        step0 = train_step_fn(model, criterion, optimizer, accum)
     elif not args.graph:
-        def step(b):
+        def step0(b):
             with torch.no_grad():
                 return model(b[0], b[1], None, b[2]["img_size"])["pred_logits"]
     else:
         from monosowa_amd.helpers.tester_helper import GraphedForward
+        assert resample is None, "--graph replays a captured forward of the resident batch"
         graphed = GraphedForward(model, batch[0], batch[1], batch[2]["img_size"])
 
-        def step(b):
+        def step0(b):
             return graphed(b[0], b[1], b[2]["img_size"])["pred_logits"]
+    step = step0 if resample is None else (lambda b: step0(resample(b)))
+
+    def sync():
+        barrier_sync(device)
 
     log("model + batch ready; warm-up")
     if args.preheat_seconds > 0:
+        trace("first step: enter")
         step(batch)                       # first step: library initialisation, MIOpen kernel selection
         torch.cuda.synchronize()
-        t1, n = time.time(), 0
-        while not any_rank_says(time.time() - t1 >= args.preheat_seconds, device):
-            step(batch)
-            torch.cuda.synchronize()
-            n += 1
-        log("pre-heat: %d untimed steps in %.1f s (not counted as warm-up steps)" % (n, time.time() - t1))
+        trace("first step: done")
+        n, dt = preheat(step, batch, args.preheat_seconds, device, torch.cuda.synchronize)
+        log("pre-heat: %d untimed steps in %.1f s (not counted as warm-up steps)" % (n, dt))
     for i in range(args.warmup):
         t1 = time.time()
         step(batch)
         torch.cuda.synchronize()
         log("warm-up step %d: %.2f s" % (i, time.time() - t1))
+        trace("warm-up step %d done" % i)
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    sync()
     with MSDA.LaunchTimer() as timer:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(batch)
-        sync()
-        elapsed = time.perf_counter() - t0
+        elapsed = timed_steps(step, batch, args.steps, device)
     log("timed %d steps: %.3f s" % (args.steps, elapsed))
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    trace("timed region done")
+
+    # the device assignment solver reports an invalid / oversized cost matrix through a deferred status word: look at it for certain
+    matcher = getattr(criterion, "matcher", None)
+    if train and matcher is not None and hasattr(matcher, "check_device_status"):
+        matcher.check_device_status(block=True)
 
     global_batch = args.batch * world * accum
     value = global_batch * args.steps / elapsed
+
+    # ---- DataLoader-fed leg ("separately, with a synthetic DataLoader"): the same K train steps, every batch
+    # coming out of build_dataloader(SyntheticKITTI) -- worker processes, collate, pinned host buffers, non-blocking H2D copies --
+    # the way the reference loop is fed (lib/helpers/dataloader_helper.py:21-34: 4 workers; trainer_helper.py:121-127: per-key
+    # .to(device)).  Timed like the resident leg; `value` above stays the resident number.
+    dataloader = None
+    if train and not args.no_dataloader_leg and resample is None and accum == 1:
+        dataloader = dataloader_leg(args, step0, device, world, rank, (W, H))
+        log("dataloader leg: %d steps in %.3f s" % (args.steps, dataloader["ms_per_step"] * args.steps * 1e-3))
 
     # ---- inference leg of the train line (north_star: "training/inference throughput ... reported"): eval-mode forward of
     # the same model on the same resident batch, every rank its own images, timed like the train leg -----------------------
@@ -348,23 +539,16 @@ def main():
         def infer(b):
             with torch.no_grad():
                 return net(b[0], b[1], None, b[2]["img_size"])["pred_logits"]
+        ibatch = batch if resample is None else resample(batch)
         for _ in range(3):
-            infer(batch)
-        sync()
+            infer(ibatch)
         with MSDA.LaunchTimer() as itimer:
-            t1 = time.perf_counter()
-            for _ in range(args.inference_steps):
-                infer(batch)
-            sync()
-            i_elapsed = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([i_elapsed], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            i_elapsed = t.item()
+            i_elapsed = timed_steps(infer, ibatch, args.inference_steps, device)
+        eval_queries = int(getattr(net, "num_queries", 50))
         enc = [(dims, d) for (kind, dims), d in itimer.summary().items() if kind == "fwd" and dims[5] == dims[1]]
         inference = {"value": args.batch * world * args.inference_steps / i_elapsed, "unit": "img/s", "steps": args.inference_steps,
-                     "ms_per_step": i_elapsed / args.inference_steps * 1e3, "queries": 50,
-                     "workload": "eval forward (50 queries), per-GPU batch %d" % args.batch}
+                     "ms_per_step": i_elapsed / args.inference_steps * 1e3, "queries": eval_queries,
+                     "workload": "eval forward (%d queries), per-GPU batch %d" % (eval_queries, args.batch)}
         if enc:
             dims, d = enc[0]
             ab = msda_alg_bytes("fwd", dims)
@@ -384,13 +568,14 @@ def main():
         k = kernels[0]
         # HBM traffic per launch from the PMC counters: collected by tools/collect_pmc.sh in separate rocprofv3 --pmc passes on
         # the kernels this step runs; the file names its source profile and the kernel templates it was read from
-        traffic = traffic_src = None
+        traffic = traffic_src = traffic_at = None
         tf = os.path.join(ROOT, "profiles", "msda_traffic.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
                 traffic = tj.get("%s_Lq%d_B%d" % (k["kernel"], k["Lq"], k["B"]))
                 traffic_src = tj.get("_source")
+                traffic_at = tj.get("_collected_at")
             except Exception:
                 traffic = None
         tot_bytes = sum(x["alg_bytes"] * x["launches_per_step"] for x in kernels)
@@ -398,7 +583,10 @@ def main():
         fwd = next((x for x in kernels if x["kernel"] == "msda_fwd" and x["Lq"] == k["Lq"]), None)
         roofline = {"bound": "hbm", "kernel": "%s(B=%d,Lq=%d,S=%d,M=8,D=32,L=4,P=4)" % (k["kernel"], k["B"], k["Lq"], dims_S(timer)),
                     "achieved": k["achieved_GBps"], "peak": HBM_PEAK_BYTES_PER_S / 1e9, "unit": "GB/s",
-                    "frac": k["frac"], "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": k["avg_ms"],
+                    "frac": k["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                    # the counters come from separate rocprofv3 --pmc passes (tools/collect_pmc.sh), not from this run: the commit
+                    # whose kernels they were collected on, and the commit this line was measured at
+                    "traffic_collected_at": traffic_at, "measured_at": git_head(), "avg_launch_ms": k["avg_ms"],
                     "alg_bytes_per_launch": k["alg_bytes"],
                     "forward_same_shape": None if fwd is None else {"avg_launch_ms": fwd["avg_ms"], "achieved": fwd["achieved_GBps"],
                                                                     "frac": fwd["frac"]},
@@ -407,6 +595,9 @@ def main():
                                            "frac": tot_bytes / (tot_ms * 1e-3) / HBM_PEAK_BYTES_PER_S, "target_frac": 0.60},
                     "all_msda_kernels": kernels}
 
+    net_ = model.module if hasattr(model, "module") else model
+    eval_queries_cfg = int(getattr(net_, "num_queries", 50))
+    train_queries = eval_queries_cfg * int(getattr(net_, "group_num", 11))
     if rank == 0:
         line = {
             "metric": "MonoDETR %s img/s (KITTI %dx%d)" % ("training" if train else "inference", W, H),
@@ -416,14 +607,18 @@ def main():
             "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "MonoDETR %s KITTI %dx%d, %s step, per-GPU batch %d, synthetic images + random pseudo-labels"
-                                   % (args.backbone, W, H, "fwd+criterion+bwd+AdamW" if train else "eval fwd (50 queries)", args.batch),
+                                   % (args.backbone, W, H, ("resample %s -> " % args.resample_from if args.resample_from else "") +
+                                      ("fwd+criterion+bwd+AdamW" if train else "eval fwd (%d queries)" % eval_queries_cfg), args.batch),
                        "global_batch": global_batch, "per_gpu_batch": args.batch, "parallelism": "dp%d" % world,
                        "accumulation_micro_steps": accum, "mixed_cameras": bool(args.mixed_cameras),
-                       "queries": 550 if train else 50},
+                       "queries": train_queries if train else eval_queries_cfg, "tuned": tuned_workload(args),
+                       "resampled_from": args.resample_from or None},
             "roofline": roofline,
         }
         if inference is not None:
             line["inference"] = inference
+        if dataloader is not None:
+            line["dataloader"] = dataloader
         if dist.is_initialized():          # the CPU leg below must not meet an RCCL-only process group
             dist.barrier()
             dist.destroy_process_group()

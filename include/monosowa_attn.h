@@ -36,6 +36,21 @@ int mono_attn_backward_f32(const float *q, const float *k, const float *v, const
                            mono_attn_strides so, mono_attn_strides sdq, mono_attn_strides sdk, mono_attn_strides sdv,
                            float softmax_scale, float dropout_p, unsigned long long seed, void *stream);
 
+/* The same two operations with a key padding mask: key_padding_mask [B, Lk] bytes, non-zero = the key is padding and takes no
+ * part in any query's softmax (score -inf, exactly nn.MultiheadAttention's key_padding_mask -- the reference passes one at
+ * depthaware_transformer.py:456-459 and depth_predictor/transformer.py:57-60); dk / dv of a masked key come out as zero.  NULL =
+ * no mask (the functions above).  A query whose keys are all masked yields NaN, as torch's softmax does. */
+int mono_attn_forward_masked_f32(const float *q, const float *k, const float *v, const unsigned char *key_padding_mask, float *o,
+                                 float *lse, int B, int H, int Lq, int Lk, int head_dim, mono_attn_strides sq,
+                                 mono_attn_strides sk, mono_attn_strides sv, mono_attn_strides so, float softmax_scale,
+                                 float dropout_p, unsigned long long seed, void *stream);
+int mono_attn_backward_masked_f32(const float *q, const float *k, const float *v, const unsigned char *key_padding_mask,
+                                  const float *o, const float *lse, const float *dout, float *dq, float *dk, float *dv, float *delta,
+                                  int B, int H, int Lq, int Lk, int head_dim, mono_attn_strides sq, mono_attn_strides sk,
+                                  mono_attn_strides sv, mono_attn_strides so, mono_attn_strides sdq, mono_attn_strides sdk,
+                                  mono_attn_strides sdv, float softmax_scale, float dropout_p, unsigned long long seed,
+                                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,11 @@ const char *msda_strerror(int code);
  * computes the same function.  Returns 0, or MSDA_E_UNSUPPORTED for an unknown name / value. */
 int msda_set_option(const char *name, int value);
 
+/* Diagnostics for tests: reads AND resets a device-side event counter of the current device (synchronises the device).
+ * "scatter_overflow_rounds": extra bucket rounds of the self-attention backward's cell scatter (a cell received more points
+ * from one batch of candidates than its bucket holds).  Returns 0, MSDA_E_UNSUPPORTED for an unknown name, or a hipError_t. */
+int msda_debug_counter(const char *name, unsigned long long *out);
+
 /* Bytes of device scratch the backward needs for this geometry (0 if none); the caller allocates
  * it (any alignment >= 16) and passes it to msda_backward_*; it may be NULL when the answer is 0.
  * Contents need not be preserved between calls. */

@@ -37,6 +37,8 @@ def load():
     lib.msda_strerror.argtypes = [I]
     lib.msda_set_option.restype = I
     lib.msda_set_option.argtypes = [ctypes.c_char_p, I]
+    lib.msda_debug_counter.restype = I
+    lib.msda_debug_counter.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_ulonglong)]
     lib.msda_backward_workspace_bytes.restype = Z
     lib.msda_backward_workspace_bytes.argtypes = [I] * 8
     for suf in ("f32", "f64"):
@@ -85,6 +87,13 @@ def check(code, what):
 
 def set_option(name, value):
     check(load().msda_set_option(name.encode(), int(value)), "msda_set_option(%s, %s)" % (name, value))
+
+
+def debug_counter(name):
+    """Reads and resets a device-side diagnostic counter (include/monosowa_msda.h: msda_debug_counter); synchronises the device."""
+    out = ctypes.c_ulonglong(0)
+    check(load().msda_debug_counter(name.encode(), ctypes.byref(out)), "msda_debug_counter(%s)" % name)
+    return int(out.value)
 
 
 def raw_stream():

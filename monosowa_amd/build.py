@@ -67,7 +67,23 @@ def build_all(force=False, verbose=False):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
         built.append(out)
+    _stamp_commit()
     return built
+
+
+def _stamp_commit():
+    """lib/BUILD_COMMIT: the commit the tree was at when the libraries were last (re)checked -- the GPU box's snapshot has no .git,
+    and bench.py / tools/collect_pmc.sh record which code a measurement belongs to."""
+    try:
+        root = os.path.dirname(HERE)
+        h = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10)
+        if h.returncode != 0:
+            return
+        d = subprocess.run(["git", "-C", root, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True, timeout=10)
+        with open(os.path.join(LIBDIR, "BUILD_COMMIT"), "w") as f:
+            f.write(h.stdout.strip() + ("-dirty" if d.stdout.strip() else "") + "\n")
+    except Exception:
+        pass
 
 
 if __name__ == "__main__":

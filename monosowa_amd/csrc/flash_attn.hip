@@ -43,6 +43,7 @@ struct Args {
   unsigned drop_thr16;           // drop when the element's 16 random bits < thr (0: no dropout)
   float drop_scale;              // 1 / (1 - p)
   unsigned seed_lo, seed_hi;
+  const unsigned char *kmask;    // MASK kernels: key padding mask [B, Lk], non-zero = the key takes no part (its score is -inf)
 };
 
 __device__ __forceinline__ unsigned mix32(unsigned x) {
@@ -61,10 +62,15 @@ __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }   
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 // ---------------------------------------------------------------------------------------------- forward
-template <bool DROP>
+// MASK: a key padding mask (Args::kmask) -- the reference passes one to both attention modules (depthaware_transformer.py:456-459,
+// depth_predictor/transformer.py:57-60: key_padding_mask -> -inf before the softmax, torch.nn.functional.multi_head_attention_forward).
+// The tile's keys carry an additive bias in LDS, 0 or -inf (also for the keys past Lk of a ragged last tile): one ds_read_b128 per
+// four scores.  A query whose keys are ALL masked comes out as NaN, as it does from torch's softmax.
+template <bool DROP, bool MASK = false>
 __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void fwd_kernel(const Args a) {
   __shared__ float Ks[2][kTileK * kKStride];
   __shared__ float Vs[2][kTileK * kVStride];
+  __shared__ float Bs[2][MASK ? kTileK : 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
   const int q = blockIdx.x * kBlockQ + wave * 32 + r;
@@ -80,6 +86,7 @@ __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void fwd_kernel(const Args a) 
   const float *kb = a.k + b * a.sk.b + hd * a.sk.h, *vb = a.v + b * a.sv.b + hd * a.sv.h;
   const int n_tiles = (a.Lk + kTileK - 1) / kTileK;
   float4 kr[2], vr[2];
+  float br = 0.f;
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -87,6 +94,10 @@ __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void fwd_kernel(const Args a) 
       const bool ok = key < a.Lk;
       kr[j] = ok ? ld4(kb + (long long)key * a.sk.t + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       vr[j] = ok ? ld4(vb + (long long)key * a.sv.t + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (MASK && threadIdx.x < kTileK) {
+      const int key = kt * kTileK + threadIdx.x;
+      br = (key < a.Lk && a.kmask[(long long)b * a.Lk + key] == 0) ? 0.f : -INFINITY;
     }
   };
   auto store_tile = [&](int buf) {
@@ -96,6 +107,7 @@ __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void fwd_kernel(const Args a) 
       *reinterpret_cast<float4 *>(&Ks[buf][row * kKStride + c]) = kr[j];
       *reinterpret_cast<float4 *>(&Vs[buf][row * kVStride + c]) = vr[j];
     }
+    if (MASK && threadIdx.x < kTileK) Bs[buf][threadIdx.x] = br;
   };
   load_tile(0);
   store_tile(0);
@@ -119,7 +131,14 @@ __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void fwd_kernel(const Args a) 
       s0 = mfma(a0.w, qreg[4 * i + 3], s0); s1 = mfma(a1.w, qreg[4 * i + 3], s1);
     }
     const int key0 = kt * kTileK + 4 * h;                // + 8 (v >> 2) + (v & 3) (+ 32 for s1)
-    if (kt == n_tiles - 1 && (a.Lk & (kTileK - 1))) {
+    if (MASK) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b0 = ld4(&Bs[buf][4 * h + 8 * g]), b1 = ld4(&Bs[buf][32 + 4 * h + 8 * g]);
+        s0[4 * g] += b0.x; s0[4 * g + 1] += b0.y; s0[4 * g + 2] += b0.z; s0[4 * g + 3] += b0.w;
+        s1[4 * g] += b1.x; s1[4 * g + 1] += b1.y; s1[4 * g + 2] += b1.z; s1[4 * g + 3] += b1.w;
+      }
+    } else if (kt == n_tiles - 1 && (a.Lk & (kTileK - 1))) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int key = key0 + 8 * (v >> 2) + (v & 3);
@@ -203,10 +222,11 @@ __global__ __launch_bounds__(256) void delta_kernel(const Args a, int B) {
 
 // dQ: same decomposition as the forward (a lane owns one query); per 32-key half: S^T (recomputed), dP^T = V dO^T,
 // dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T -- 48 MFMAs.
-template <bool DROP>
+template <bool DROP, bool MASK = false>
 __global__ __launch_bounds__(256, 3) void bwd_dq_kernel(const Args a) {
   __shared__ float Ks[2][kTileK * kKStride];
   __shared__ float Vs[2][kTileK * kKStride];
+  __shared__ float Bs[2][MASK ? kTileK : 4];            // additive key bias, as in the forward
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
   const int q = blockIdx.x * kBlockQ + wave * 32 + r;
@@ -225,6 +245,7 @@ __global__ __launch_bounds__(256, 3) void bwd_dq_kernel(const Args a) {
   const float *kb = a.k + b * a.sk.b + hd * a.sk.h, *vb = a.v + b * a.sv.b + hd * a.sv.h;
   const int n_tiles = (a.Lk + kTileK - 1) / kTileK;
   float4 kr[2], vr[2];
+  float br = 0.f;
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -232,6 +253,10 @@ __global__ __launch_bounds__(256, 3) void bwd_dq_kernel(const Args a) {
       const bool ok = key < a.Lk;
       kr[j] = ok ? ld4(kb + (long long)key * a.sk.t + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       vr[j] = ok ? ld4(vb + (long long)key * a.sv.t + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (MASK && threadIdx.x < kTileK) {
+      const int key = kt * kTileK + threadIdx.x;
+      br = (key < a.Lk && a.kmask[(long long)b * a.Lk + key] == 0) ? 0.f : -INFINITY;
     }
   };
   auto store_tile = [&](int buf) {
@@ -241,6 +266,7 @@ __global__ __launch_bounds__(256, 3) void bwd_dq_kernel(const Args a) {
       *reinterpret_cast<float4 *>(&Ks[buf][row * kKStride + c]) = kr[j];
       *reinterpret_cast<float4 *>(&Vs[buf][row * kKStride + c]) = vr[j];
     }
+    if (MASK && threadIdx.x < kTileK) Bs[buf][threadIdx.x] = br;
   };
   load_tile(0);
   store_tile(0);
@@ -264,11 +290,18 @@ __global__ __launch_bounds__(256, 3) void bwd_dq_kernel(const Args a) {
         s = mfma(ka.w, qreg[4 * i + 3], s); dp = mfma(va.w, doreg[4 * i + 3], dp);
       }
       const int key0 = kt * kTileK + half * 32 + 4 * h;
+      if (MASK) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = ld4(&Bs[buf][half * 32 + 4 * h + 8 * g]);
+          s[4 * g] += b4.x; s[4 * g + 1] += b4.y; s[4 * g + 2] += b4.z; s[4 * g + 3] += b4.w;
+        }
+      }
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int key = key0 + 8 * (v >> 2) + (v & 3);
-        float p = __builtin_amdgcn_exp2f(s[v] - lse);
-        if (key >= a.Lk) p = 0.f;
+        float p = __builtin_amdgcn_exp2f(s[v] - lse);       // a masked key: exp2(-inf) = 0
+        if (!MASK && key >= a.Lk) p = 0.f;
         float dpe = dp[v];
         if (DROP) {
           const unsigned bits = drop_bits(hseed, (unsigned)q, (unsigned)key >> 1);        // CSE'd across the pair
@@ -295,7 +328,7 @@ __global__ __launch_bounds__(256, 3) void bwd_dq_kernel(const Args a) {
 
 // dK, dV: a lane owns one KEY (S = Q K^T untransposed: col = key, rows = 16 queries); per 32-query half:
 // S, dP = dO V^T, dV^T += dO^T P_drop, dK^T += Q^T dS -- 64 MFMAs.  Row statistics (lse, delta) come from LDS.
-template <bool DROP>
+template <bool DROP, bool MASK = false>
 __global__ __launch_bounds__(256, 3) void bwd_dkdv_kernel(const Args a) {
   __shared__ float Qs[2][kTileK * kKStride];
   __shared__ float Ds[2][kTileK * kKStride];
@@ -314,6 +347,8 @@ __global__ __launch_bounds__(256, 3) void bwd_dkdv_kernel(const Args a) {
     kreg[4 * i + 2] = t.z * a.scale_log2; kreg[4 * i + 3] = t.w * a.scale_log2;
     vreg[4 * i] = u.x; vreg[4 * i + 1] = u.y; vreg[4 * i + 2] = u.z; vreg[4 * i + 3] = u.w;
   }
+  // MASK: this lane's key takes no part in any softmax -- P = 0 in its whole column, dK = dV = 0
+  const bool dead = MASK && a.kmask[(long long)b * a.Lk + kc_] != 0;
   const float *qb = a.q + b * a.sq.b + hd * a.sq.h, *dob = a.dout + b * a.so.b + hd * a.so.h;
   const float *lb = a.lse + (long long)bh * a.Lq, *eb = a.delta + (long long)bh * a.Lq;
   const int n_tiles = (a.Lq + kTileK - 1) / kTileK;
@@ -371,7 +406,7 @@ __global__ __launch_bounds__(256, 3) void bwd_dkdv_kernel(const Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int v = 4 * g + j;
-          const float p = __builtin_amdgcn_exp2f(s[v] - ls[j]);
+          const float p = dead ? 0.f : __builtin_amdgcn_exp2f(s[v] - ls[j]);
           float pd = p, dpe = dp[v];
           if (DROP) {
             const unsigned bits = drop_bits(hseed, (unsigned)(q0i + 8 * g + j), (unsigned)key >> 1);
@@ -434,6 +469,14 @@ int mono_attn_forward_f32(const float *q, const float *k, const float *v, float 
                           int Lk, int head_dim, mono_attn_strides sq, mono_attn_strides sk, mono_attn_strides sv,
                           mono_attn_strides so, float softmax_scale, float dropout_p, unsigned long long seed,
                           void *stream_) {
+  return mono_attn_forward_masked_f32(q, k, v, nullptr, o, lse, B, H, Lq, Lk, head_dim, sq, sk, sv, so, softmax_scale, dropout_p,
+                                      seed, stream_);
+}
+
+int mono_attn_forward_masked_f32(const float *q, const float *k, const float *v, const unsigned char *key_padding_mask, float *o,
+                                 float *lse, int B, int H, int Lq, int Lk, int head_dim, mono_attn_strides sq,
+                                 mono_attn_strides sk, mono_attn_strides sv, mono_attn_strides so, float softmax_scale,
+                                 float dropout_p, unsigned long long seed, void *stream_) {
   if (!q || !k || !v || !o || !lse) return MONO_ATTN_E_NULLPTR;
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || head_dim != 32 || !(dropout_p >= 0.f && dropout_p < 1.f) ||
       (long long)B * H > 65535)
@@ -445,7 +488,11 @@ int mono_attn_forward_f32(const float *q, const float *k, const float *v, float 
   fill_common(a, H, Lq, Lk, softmax_scale, dropout_p, seed);
   const dim3 grid((Lq + attn::kBlockQ - 1) / attn::kBlockQ, B * H);
   hipStream_t st = (hipStream_t)stream_;
-  if (a.drop_thr16) attn::fwd_kernel<true><<<grid, 256, 0, st>>>(a);
+  a.kmask = key_padding_mask;
+  if (key_padding_mask) {
+    if (a.drop_thr16) attn::fwd_kernel<true, true><<<grid, 256, 0, st>>>(a);
+    else attn::fwd_kernel<false, true><<<grid, 256, 0, st>>>(a);
+  } else if (a.drop_thr16) attn::fwd_kernel<true><<<grid, 256, 0, st>>>(a);
   else attn::fwd_kernel<false><<<grid, 256, 0, st>>>(a);
   return (int)hipGetLastError();
 }
@@ -456,6 +503,16 @@ int mono_attn_backward_f32(const float *q, const float *k, const float *v, const
                            int Lk, int head_dim, mono_attn_strides sq, mono_attn_strides sk, mono_attn_strides sv,
                            mono_attn_strides so, mono_attn_strides sdq, mono_attn_strides sdk, mono_attn_strides sdv,
                            float softmax_scale, float dropout_p, unsigned long long seed, void *stream_) {
+  return mono_attn_backward_masked_f32(q, k, v, nullptr, o, lse, dout, dq, dk, dv, delta, B, H, Lq, Lk, head_dim, sq, sk, sv, so, sdq,
+                                       sdk, sdv, softmax_scale, dropout_p, seed, stream_);
+}
+
+int mono_attn_backward_masked_f32(const float *q, const float *k, const float *v, const unsigned char *key_padding_mask,
+                                  const float *o, const float *lse, const float *dout, float *dq, float *dk, float *dv, float *delta,
+                                  int B, int H, int Lq, int Lk, int head_dim, mono_attn_strides sq, mono_attn_strides sk,
+                                  mono_attn_strides sv, mono_attn_strides so, mono_attn_strides sdq, mono_attn_strides sdk,
+                                  mono_attn_strides sdv, float softmax_scale, float dropout_p, unsigned long long seed,
+                                  void *stream_) {
   if (!q || !k || !v || !o || !lse || !dout || !dq || !dk || !dv || !delta) return MONO_ATTN_E_NULLPTR;
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || head_dim != 32 || !(dropout_p >= 0.f && dropout_p < 1.f) ||
       (long long)B * H > 65535)
@@ -473,7 +530,14 @@ int mono_attn_backward_f32(const float *q, const float *k, const float *v, const
   const long long groups = (long long)Lq * B * H;
   attn::delta_kernel<<<(unsigned)((groups + 31) / 32), 256, 0, st>>>(a, B);
   const dim3 gq((Lq + attn::kBlockQ - 1) / attn::kBlockQ, B * H), gk((Lk + attn::kBlockQ - 1) / attn::kBlockQ, B * H);
-  if (a.drop_thr16) {
+  a.kmask = key_padding_mask;
+  if (key_padding_mask && a.drop_thr16) {
+    attn::bwd_dq_kernel<true, true><<<gq, 256, 0, st>>>(a);
+    attn::bwd_dkdv_kernel<true, true><<<gk, 256, 0, st>>>(a);
+  } else if (key_padding_mask) {
+    attn::bwd_dq_kernel<false, true><<<gq, 256, 0, st>>>(a);
+    attn::bwd_dkdv_kernel<false, true><<<gk, 256, 0, st>>>(a);
+  } else if (a.drop_thr16) {
     attn::bwd_dq_kernel<true><<<gq, 256, 0, st>>>(a);
     attn::bwd_dkdv_kernel<true><<<gk, 256, 0, st>>>(a);
   } else {

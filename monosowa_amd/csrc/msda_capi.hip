@@ -67,6 +67,8 @@ struct Options {
                                // geometric scan behind the directional plan.  Opt-in: measured at B = 16 the binning pass costs 273 us and
                                // the list-driven scatter 560 us (its workgroups have ONE batch of work each: the per-workgroup load chain
                                // dominates) against 35 + 473 us -- it only wins beyond sigma = 8 px (2.35 vs 2.65 ms)
+  int scatter_planes = 4;      // batch elements of its head a cell-scatter workgroup keeps its tile for (msda_scatter_rows.hip)
+  int scatter_lists_cap = 0;   // > 0: capacity of every exact scan list (tests: forces list overflow -> the far path); 0: sized from Lq
   int scatter_bands = 1;       // 1 (default): row-band scatter (msda_backward_bands.hip) for short record lists (Lq <= 576: the decoder)
   int plan_reach = 8;          // capacity of the directional scan: |footprint - centre| beyond this many pixels is "far" in any case
   Options() {                                               // the environment is read ONCE, at first use
@@ -83,6 +85,7 @@ struct Options {
     if (const char *e = std::getenv("MSDA_DIRECTIONAL")) directional = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSDA_SCATTER_BANDS")) scatter_bands = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSDA_SCATTER_LISTS")) scatter_lists = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MSDA_SCATTER_PLANES")) scatter_planes = std::min(64, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("MSDA_PLAN_REACH")) plan_reach = std::min(16, std::max(1, std::atoi(e)));
   }
 };
@@ -431,7 +434,10 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
             bp.tile0[l] = n_tiles;
             const int tiles = rp.n_ty[l] * rp.n_tx[l];
             // capacity: twice the share of a uniform spread (1.5 lists per unit: cells on an apron belong to two tiles), + slack
-            bp.cap[l] = (int)((3LL * Lq + tiles - 1) / tiles) + 256;
+            // (never more than the 16 chunks of kRowChunkQueries the scatter's grid scans: the excess takes the far path; `scatter_lists_cap`
+            // forces a small capacity so that tests reach that path)
+            bp.cap[l] = (int)std::min<long long>((3LL * Lq + tiles - 1) / tiles + 256, 16LL * msda::kRowChunkQueries);
+            if (options().scatter_lists_cap > 0) bp.cap[l] = std::min(bp.cap[l], options().scatter_lists_cap);
             bp.list_off[l] = entries;
             n_tiles += tiles;
             entries += tiles * bp.cap[l];
@@ -462,9 +468,8 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
                                    sizeof(float) * (size_t)rp.H[l] * rp.W[l] * M * 32, B, stream);
               if (e != hipSuccess) return (int)e;
             }
-            const int groups = (B * M + 7) / 8;
-            msda::scatter_rows_kernel<false, true><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
-                loc, attw, grad_out, grad_value, nullptr, 0, nullptr, rp, B, S, M, 0, 0, vv.mask, nullptr, lists, counts, bp);
+            msda::scatter_rows_kernel<false, true><<<8 * rp.n_items * B * ((M + 7) / 8), msda::kRowThreads, 0, stream>>>(
+                loc, attw, grad_out, grad_value, nullptr, 0, nullptr, rp, B, S, M, 0, 0, vv.mask, nullptr, lists, counts, bp, far_mask, 1);
             launch_gather<true, true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
                                             shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, 0, vv, nullptr, far_mask);
             return launch_status();
@@ -519,17 +524,22 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
                                             sizeof(float) * (size_t)rp.H[l] * rp.W[l] * M * 32, B, stream);
             if (e != hipSuccess) return (int)e;
           }
-          const int groups = (B * M + 7) / 8;
+          // a workgroup keeps its tile for `scatter_planes` batch elements of its head (msda_scatter_rows.hip)
+          const int ppw = std::max(1, std::min(options().scatter_planes, B));
+          const int rows_grid = 8 * rp.n_items * ((B + ppw - 1) / ppw) * ((M + 7) / 8);
           const int lrs = loc_rs ? loc_rs : M * 32, ars = aw_rs ? aw_rs : M * 16;
+          const msda::BinPlan no_bins{};
           if (fused_ref && !saved)
-            msda::scatter_rows_kernel<true><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
-                loc, attw, grad_out, grad_value, fused_ref, fused_ref_dim, table, rp, B, S, M, lrs, ars, vv.mask, plans);
+            msda::scatter_rows_kernel<true><<<rows_grid, msda::kRowThreads, 0, stream>>>(
+                loc, attw, grad_out, grad_value, fused_ref, fused_ref_dim, table, rp, B, S, M, lrs, ars, vv.mask, plans, nullptr, nullptr,
+                no_bins, nullptr, ppw);
           else if (saved)
-            msda::scatter_rows_kernel<false, true><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
-                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, 0, 0, vv.mask, plans);
+            msda::scatter_rows_kernel<false, true><<<rows_grid, msda::kRowThreads, 0, stream>>>(
+                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, 0, 0, vv.mask, plans, nullptr, nullptr, no_bins, nullptr, ppw);
           else
-            msda::scatter_rows_kernel<false><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
-                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, lrs, ars);
+            msda::scatter_rows_kernel<false><<<rows_grid, msda::kRowThreads, 0, stream>>>(
+                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, lrs, ars, nullptr, nullptr, nullptr, nullptr, no_bins,
+                nullptr, ppw);
           if (fused_ref && saved)
             launch_gather<true, true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
                                             shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, rp.reach, vv, plans);
@@ -630,7 +640,20 @@ int msda_set_option(const char *name, int value) {
   if (n == "scatter_bands" && (value == 0 || value == 1)) { options().scatter_bands = value; return 0; }
   if (n == "scatter_lists" && (value == 0 || value == 1)) { options().scatter_lists = value; return 0; }
   if (n == "plan_reach" && value >= 1 && value <= 16) { options().plan_reach = value; return 0; }
+  if (n == "scatter_planes" && value >= 1 && value <= 64) { options().scatter_planes = value; return 0; }
+  if (n == "scatter_lists_cap" && value >= 0) { options().scatter_lists_cap = value; return 0; }
   return MSDA_E_UNSUPPORTED;
+}
+
+int msda_debug_counter(const char *name, unsigned long long *out) {
+  if (!name || !out) return MSDA_E_NULLPTR;
+  if (std::string(name) != "scatter_overflow_rounds") return MSDA_E_UNSUPPORTED;
+  const unsigned long long zero = 0;
+  // (blocking copies on the null stream: every launch issued before this call has finished when the value is read)
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(msda::g_rows_overflow_rounds), sizeof(zero));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(msda::g_rows_overflow_rounds), &zero, sizeof(zero));
+  return (int)e;
 }
 
 const char *msda_strerror(int code) {

@@ -65,15 +65,11 @@ constexpr int kPlanMaxItems = 768;         // per head; a pyramid with more item
 
 // Everything the kernels read for one head.
 struct HeadPlan {
-  DirBounds win[kWinLevels];               // window bounds after fitting the LDS budget
+  DirBounds win[kWinLevels];               // the measured bounds (mean +- kPlanSigmas sigma, within 16 pixels of the mean): diagnostics
   DirBounds near[kWinLevels];              // scatter bounds (clamped to the host's reach): near <=> inside
-  int merged;                              // window kernels: x-adjacent tiles 2 k, 2 k + 1 are one item
-  int win_rows_max;                        // rows of the largest window set (diagnostics)
   // row-tile scatter
   int n_chunks[4], order[4], first_item[5];
   int n_items;
-  AxisSpec wax[kWinMaxAxisTiles][kWinLevels];            // [0, n_ty): rows of tiles, [n_ty, n_ty + n_tx): columns of tiles
-  AxisSpec wax2[kWinMaxAxisTiles / 2][kWinLevels];       // merged column pairs
   RowAxis rax[kRowMaxAxisTiles];
   RowItem items[kPlanMaxItems];
 };

@@ -86,29 +86,6 @@ __global__ __launch_bounds__(kStatsThreads) void dir_stats_kernel(const float *_
 }
 
 // ---- 2. per-head tables ----------------------------------------------------------------------------------------------------------
-// window extent of one axis tile at sampled level lv for bounds [dlo, dhi] of the footprint's top-left pixel
-__device__ __forceinline__ AxisSpec axis_spec_dir(const int *N, int n_t, int t0, int t1, int lv, int dlo, int dhi) {
-  // queries of tiles [t0, t1) of n_t along this axis
-  AxisSpec a;
-  a.q0 = (short)(t0 * N[lv] / n_t);
-  a.qn = (short)(t1 * N[lv] / n_t - a.q0);
-  int lo = 1 << 30, hi = -(1 << 30);
-#pragma unroll
-  for (int l = 0; l < kWinLevels; ++l) {
-    const int q0 = t0 * N[l] / n_t, q1 = t1 * N[l] / n_t;
-    if (q1 <= q0) continue;
-    lo = min(lo, plan_floor_div_dev((2 * q0 + 1) * N[lv] - N[l], 2 * N[l]));
-    hi = max(hi, plan_floor_div_dev((2 * (q1 - 1) + 1) * N[lv] - N[l], 2 * N[l]));
-  }
-  a.w0 = 0; a.wn = 0;
-  if (hi < lo) return a;
-  const int w0 = max(0, lo + dlo), w1 = min(N[lv] - 1, hi + dhi + 1);        // the footprint spans h_low, h_low + 1
-  if (w1 < w0) return a;
-  a.w0 = (short)w0;
-  a.wn = (short)(w1 - w0 + 1);
-  return a;
-}
-
 // run of query pixels c in [0, Nq) whose centre floor (in pixels of the extent-N level) lies in [lo, hi]
 __device__ __forceinline__ void scan_run_dev(int Nq, int N, int lo, int hi, short &q0, short &qn) {
   // centre floor(c) = floor(((2 c + 1) N - Nq) / (2 Nq)) is monotone in c:
@@ -126,9 +103,8 @@ __global__ __launch_bounds__(256) void dir_plan_kernel(const DirStats *__restric
   const int m = blockIdx.x, tid = threadIdx.x;
   __shared__ DirBounds s_win[4], s_near[4];
   __shared__ float s_mean[4][2];
-  __shared__ AxisSpec s_wax[kWinMaxAxisTiles][kWinLevels];
   __shared__ RowAxis s_rax[kRowMaxAxisTiles];
-  __shared__ int s_rows_max, s_cand_max[4], s_q_max;
+  __shared__ int s_cand_max[4];
   HeadPlan &hp = plans[m];
 
   // ---- A. bounds: [min, max] of the sample, cut at mean +- kPlanSigmas sigma (one stray point must not size every window) ------
@@ -182,81 +158,9 @@ __global__ __launch_bounds__(256) void dir_plan_kernel(const DirStats *__restric
   }
   __syncthreads();
 
-  // ---- B. windows: fit the LDS budget (shrink the longest extent towards the mean until every tile fits) ---------------------------
-  const int n_ty = g.win_n_ty, n_tx = g.win_n_tx, n_ax = n_ty + n_tx;
-  // (the last trip, reached only when 80 cuts did not fit the windows, takes the isotropic default the host's tiling was
-  // chosen for: the gather kernels trust this table with their LDS addressing)
-  for (int iter = 0; iter <= 80; ++iter) {
-    if (tid == 0) s_rows_max = 0;
-    if (iter == 80 && tid < 4) {
-      s_win[tid].ylo = s_win[tid].xlo = (short)-g.default_halo;
-      s_win[tid].yhi = s_win[tid].xhi = (short)(g.default_halo - 1);
-    }
-    __syncthreads();
-    for (int idx = tid; idx < n_ax * 4; idx += 256) {
-      const int t = idx >> 2, lv = idx & 3;
-      const DirBounds b = s_win[lv];
-      s_wax[t][lv] = t < n_ty ? axis_spec_dir(g.H, n_ty, t, t + 1, lv, b.ylo, b.yhi) : axis_spec_dir(g.W, n_tx, t - n_ty, t - n_ty + 1, lv, b.xlo, b.xhi);
-    }
-    __syncthreads();
-    for (int tile = tid; tile < n_ty * n_tx; tile += 256) {
-      const int ty = tile / n_tx, tx = tile - ty * n_tx;
-      int rows = 0;
-#pragma unroll
-      for (int lv = 0; lv < 4; ++lv) rows += ((int)s_wax[ty][lv].wn * (int)s_wax[n_ty + tx][lv].wn + 7) & ~7;
-      atomicMax(&s_rows_max, rows);
-    }
-    __syncthreads();
-    if (s_rows_max <= g.win_budget_rows) break;
-    if (tid == 0) {
-      // the longest extent over levels and axes loses a quarter (at least one pixel) on the side farther from the mean
-      int bl = 0, ba = 0, be = -1;
-      for (int lv = 0; lv < 4; ++lv) {
-        const int ey = s_win[lv].yhi - s_win[lv].ylo, ex = s_win[lv].xhi - s_win[lv].xlo;
-        if (ey > be) { be = ey; bl = lv; ba = 0; }
-        if (ex > be) { be = ex; bl = lv; ba = 1; }
-      }
-      if (be > 0) {
-        const int cut = max(1, be / 4);
-        short &lo = ba ? s_win[bl].xlo : s_win[bl].ylo, &hi = ba ? s_win[bl].xhi : s_win[bl].yhi;
-        for (int c = 0; c < cut && hi > lo; ++c) {
-          if ((float)hi - s_mean[bl][ba] >= s_mean[bl][ba] - (float)lo) --hi; else ++lo;
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (s_rows_max > g.win_budget_rows) {            // cannot happen with a tiling the host chose for default_halo; never overrun the LDS
-    for (int idx = tid; idx < n_ax * 4; idx += 256) s_wax[idx >> 2][idx & 3].wn = 0;
-    __syncthreads();
-  }
-  // merged column pairs: every pair's windows and queries must fit
-  if (tid == 0) { s_rows_max = 0; s_q_max = 0; }
-  __syncthreads();
-  const int n_px = n_tx / 2;
-  for (int idx = tid; idx < n_px * 4; idx += 256) {
-    const int t = idx >> 2, lv = idx & 3;
-    hp.wax2[t][lv] = axis_spec_dir(g.W, n_tx, 2 * t, 2 * t + 2, lv, s_win[lv].xlo, s_win[lv].xhi);
-  }
-  for (int tile = tid; tile < n_ty * n_px; tile += 256) {
-    const int ty = tile / n_px, tp = tile - ty * n_px;
-    int rows = 0, queries = 0;
-#pragma unroll
-    for (int lv = 0; lv < 4; ++lv) {
-      const AxisSpec a2 = axis_spec_dir(g.W, n_tx, 2 * tp, 2 * tp + 2, lv, s_win[lv].xlo, s_win[lv].xhi);
-      rows += ((int)s_wax[ty][lv].wn * (int)a2.wn + 7) & ~7;
-      queries += (int)s_wax[ty][lv].qn * (int)a2.qn;
-    }
-    atomicMax(&s_rows_max, rows);
-    atomicMax(&s_q_max, queries);
-  }
-  __syncthreads();
-  for (int idx = tid; idx < n_ax * 4; idx += 256) hp.wax[idx >> 2][idx & 3] = s_wax[idx >> 2][idx & 3];
+  // (round 3 also fitted per-head LDS windows here -- 80 shrink-and-refit trips -- which no kernel read: directional windows on the
+  // round-3 tiling measured the same time as isotropic ones; removed together with the HeadPlan fields that held them)
   if (tid < 4) { hp.win[tid] = s_win[tid]; hp.near[tid] = s_near[tid]; }
-  if (tid == 0) {
-    hp.merged = (n_px > 0 && s_rows_max <= g.win_budget_rows && s_q_max <= g.win_max_queries) ? 1 : 0;
-    hp.win_rows_max = s_rows_max;
-  }
   if (!g.want_rows) return;
 
   // ---- C. row-tile scatter: per (level, axis tile) the runs of query pixels whose points can reach it ---------------------------

@@ -24,12 +24,15 @@ def build_dataset(cfg, split):
     raise NotImplementedError("%s dataset is not supported" % cfg["type"])
 
 
-def build_dataloader(cfg, workers=4):
+def build_dataloader(cfg, workers=4, drop_last=False, test=True):
+    """``drop_last`` / ``test=False`` (no test loader: None) are extensions for bench.py's DataLoader-fed leg."""
     train_set = build_dataset(cfg, cfg["train_split"])
-    test_set = build_dataset(cfg, cfg["test_split"])
+    test_set = build_dataset(cfg, cfg["test_split"]) if test else None
     sampler = DistributedSampler(train_set, shuffle=True) if is_dist_avail_and_initialized() and get_world_size() > 1 else None
     train_loader = DataLoader(train_set, batch_size=cfg["batch_size"], num_workers=workers, worker_init_fn=my_worker_init_fn,
-                              shuffle=sampler is None, sampler=sampler, pin_memory=torch.cuda.is_available(), drop_last=False)
+                              shuffle=sampler is None, sampler=sampler, pin_memory=torch.cuda.is_available(), drop_last=drop_last)
+    if test_set is None:
+        return train_loader, None
     test_loader = DataLoader(test_set, batch_size=cfg["batch_size"], num_workers=workers, worker_init_fn=my_worker_init_fn,
                              shuffle=False, pin_memory=torch.cuda.is_available(), drop_last=False)
     return train_loader, test_loader

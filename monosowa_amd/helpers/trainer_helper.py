@@ -47,6 +47,23 @@ def wait_for_evaluation(timeout_hours=6.0):
     torch.distributed.monitored_barrier(group=_EVAL_WAIT_GROUP[0], timeout=datetime.timedelta(hours=timeout_hours))
 
 
+def stage_batch(raw, device):
+    """One collated loader batch ``(inputs, calibs, targets, info)`` onto ``device`` (reference: trainer_helper.py:121-127, a
+    per-key ``.to(device)``): non-blocking copies (pinned source buffers when the loader pins), images to channels-last for the
+    MIOpen NHWC kernels, and the object mask kept on the host next to its device copy so that ``prepare_targets`` needs no
+    device -> host synchronisation."""
+    inputs, calibs, targets, info = raw
+    inputs = inputs.to(device, non_blocking=True)
+    if inputs.is_cuda:
+        inputs = inputs.contiguous(memory_format=torch.channels_last)
+    calibs = calibs.to(device, non_blocking=True)
+    host_mask = targets["mask_2d"].numpy() if not targets["mask_2d"].is_cuda else None
+    targets = {k: v.to(device, non_blocking=True) for k, v in targets.items()}
+    if host_mask is not None:
+        attach_host_mask(targets["mask_2d"], host_mask)      # prepare_targets then needs no device sync
+    return inputs, calibs, targets, info
+
+
 class Trainer(object):
     def __init__(self, cfg, model, optimizer, train_loader, test_loader, lr_scheduler, warmup_lr_scheduler,
                  logger, loss, model_name):
@@ -148,15 +165,8 @@ class Trainer(object):
         if main:
             print(">>>>>>> Epoch:", str(epoch) + ":")
         bar = tqdm.tqdm(total=len(self.train_loader), leave=(self.epoch + 1 == self.cfg["max_epoch"]), desc="iters", disable=not main)
-        for batch_idx, (inputs, calibs, targets, info) in enumerate(self.train_loader):
-            inputs = inputs.to(self.device, non_blocking=True)
-            if inputs.is_cuda:
-                inputs = inputs.contiguous(memory_format=torch.channels_last)
-            calibs = calibs.to(self.device, non_blocking=True)
-            host_mask = targets["mask_2d"].numpy() if not targets["mask_2d"].is_cuda else None
-            targets = {k: v.to(self.device, non_blocking=True) for k, v in targets.items()}
-            if host_mask is not None:
-                attach_host_mask(targets["mask_2d"], host_mask)      # prepare_targets then needs no device sync
+        for batch_idx, raw in enumerate(self.train_loader):
+            inputs, calibs, targets, info = stage_batch(raw, self.device)
             total, loss_dict = self.train_step(inputs, calibs, targets, info)
             if batch_idx % self.log_interval == 0:
                 self._log(batch_idx, loss_dict)

@@ -181,9 +181,13 @@ class HungarianMatcher(nn.Module):
         elif not ev.query():
             return
         self._status_event = None
-        if int(self._status_host) & 1:
+        word = int(self._status_host)
+        if word & 3:
             self._status.zero_()
-            raise ValueError("cost matrix is infeasible")
+            if word & 1:
+                raise ValueError("cost matrix is infeasible")
+            # bit 2: a problem exceeded the device solver's tables and got placeholder identity pairs instead of an assignment
+            raise ValueError("assignment problem exceeds the device solver's capacity (identity pairs were emitted)")
 
     @torch.no_grad()
     def match_layers_end_flat(self, handle):

@@ -75,7 +75,7 @@ class SyntheticKITTI(Dataset):
         self.resolution = tuple(cfg.get("resolution", (1280, 384)))
         self.num_samples = int(num_samples if num_samples is not None else cfg.get("num_samples", 64))
         self.canonical_focal_length = float(cfg.get("canonical_focal_length", 500.0))
-        self.seed = seed + (0 if split == "train" else 100003)
+        self.seed = seed + int(cfg.get("seed_offset", 0)) + (0 if split == "train" else 100003)
         self.max_objs = MAX_OBJS
         self.class_name = ["Pedestrian", "Car", "Cyclist"]
         self.cls_mean_size = np.zeros((3, 3), dtype=np.float32)   # meanshape: False

@@ -191,3 +191,63 @@ def test_bench_preheat_loop_ends_on_every_rank_after_the_same_number_of_steps():
         p.join(120)
         assert p.exitcode == 0
     assert q.get() == [3, 3]
+
+
+def _control_path_worker(rank, world, port, q):
+    """bench.py's N-rank control path with a stand-in step (one all-reduce + a rank-dependent sleep): the pre-heat agreement, the
+    barriers around the timed region, the max-over-ranks reduction and the whole-job value -- the very functions main() calls."""
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import bench
+    cpu = torch.device("cpu")
+    calls = {"n": 0}
+
+    def step(batch):
+        t = torch.ones(8) * batch
+        dist.all_reduce(t)                            # a step is a set of collectives: hangs if a partner has left the loop
+        assert t[0].item() == batch * world
+        time.sleep(0.002 * (rank + 1))                # rank 7 is the slowest
+        calls["n"] += 1
+
+    # every rank's own clock would stop it at a different step; all must stop together
+    n, _ = bench.preheat(step, 1.0, 0.05 * (rank + 1), cpu, lambda: None)
+    assert calls["n"] == n
+    steps = 6
+    elapsed = bench.timed_steps(step, 1.0, steps, cpu)
+    assert calls["n"] == n + steps                    # EXACTLY K timed steps
+    out = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(out, torch.tensor([float(n), elapsed], dtype=torch.float64))
+    if rank == 0:
+        q.put([[float(x[0]), float(x[1])] for x in out])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_control_path_with_eight_ranks():
+    """N = 8 over gloo on the CPU: what the driver's 8-GPU run exercises besides RCCL itself.  Every rank ends the pre-heat after the
+    same number of steps, times exactly K steps between barriers and reports the SAME (slowest rank's) time."""
+    world = 8
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_control_path_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    rows = q.get()
+    assert len({r[0] for r in rows}) == 1 and rows[0][0] >= 1, rows          # same pre-heat step count everywhere
+    assert len({r[1] for r in rows}) == 1, rows                              # one time: the maximum over ranks
+    assert rows[0][1] >= 6 * 0.002 * world * 0.9, rows                       # ... which is at least the slowest rank's sleeps
+
+
+def test_bench_rehearsal_refuses_more_than_two_ranks():
+    """MONOSOWA_BENCH_REHEARSAL=1 (every rank on device 0, gloo) is a two-rank tool: with more ranks it only measures gloo's
+    host-staged all-reduce (round 3: 23.6 s per step at three ranks, no step in 400 s at four).  bench.py says so instead of burning
+    GPU minutes -- checked on the text, the guard sits behind the "needs an MI355X" test."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    guard = src.index("supports WORLD_SIZE <= 2")
+    assert src.rindex("if world > 2:", 0, guard) > src.index('rehearsal = os.environ.get("MONOSOWA_BENCH_REHEARSAL")')

@@ -103,4 +103,7 @@ for tag, key_f, key_b in (("c4", "msda_fwd_Lq11044_B16", "msda_bwd_Lq11044_B16")
     res[key_f], res[key_b] = fwd, bwd
     res["_source"]["kernels"][key_f], res["_source"]["kernels"][key_b] = used_f, used_b
     print("%-28s %8.1f MB   %-28s %8.1f MB per launch" % (key_f, fwd / 1e6, key_b, bwd / 1e6))
+# which code the counters were collected on (monosowa_amd/build.py leaves the commit next to the libraries: the GPU box has no .git)
+_bc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "monosowa_amd", "lib", "BUILD_COMMIT")
+res["_collected_at"] = open(_bc).read().strip() if os.path.exists(_bc) else None
 json.dump(res, open(os.path.join(d, "msda_traffic.json"), "w"), indent=1)
