@@ -67,7 +67,6 @@ struct Options {
                                // geometric scan behind the directional plan.  Opt-in: measured at B = 16 the binning pass costs 273 us and
                                // the list-driven scatter 560 us (its workgroups have ONE batch of work each: the per-workgroup load chain
                                // dominates) against 35 + 473 us -- it only wins beyond sigma = 8 px (2.35 vs 2.65 ms)
-  int scatter_planes = 4;      // batch elements of its head a cell-scatter workgroup keeps its tile for (msda_scatter_rows.hip)
   int scatter_lists_cap = 0;   // > 0: capacity of every exact scan list (tests: forces list overflow -> the far path); 0: sized from Lq
   int scatter_bands = 1;       // 1 (default): row-band scatter (msda_backward_bands.hip) for short record lists (Lq <= 576: the decoder)
   int plan_reach = 8;          // capacity of the directional scan: |footprint - centre| beyond this many pixels is "far" in any case
@@ -85,7 +84,6 @@ struct Options {
     if (const char *e = std::getenv("MSDA_DIRECTIONAL")) directional = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSDA_SCATTER_BANDS")) scatter_bands = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSDA_SCATTER_LISTS")) scatter_lists = std::atoi(e) != 0;
-    if (const char *e = std::getenv("MSDA_SCATTER_PLANES")) scatter_planes = std::min(64, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("MSDA_PLAN_REACH")) plan_reach = std::min(16, std::max(1, std::atoi(e)));
   }
 };
@@ -468,8 +466,9 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
                                    sizeof(float) * (size_t)rp.H[l] * rp.W[l] * M * 32, B, stream);
               if (e != hipSuccess) return (int)e;
             }
-            msda::scatter_rows_kernel<false, true><<<8 * rp.n_items * B * ((M + 7) / 8), msda::kRowThreads, 0, stream>>>(
-                loc, attw, grad_out, grad_value, nullptr, 0, nullptr, rp, B, S, M, 0, 0, vv.mask, nullptr, lists, counts, bp, far_mask, 1);
+            const int groups = (B * M + 7) / 8;
+            msda::scatter_rows_kernel<false, true><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
+                loc, attw, grad_out, grad_value, nullptr, 0, nullptr, rp, B, S, M, 0, 0, vv.mask, nullptr, lists, counts, bp, far_mask);
             launch_gather<true, true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
                                             shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, 0, vv, nullptr, far_mask);
             return launch_status();
@@ -524,22 +523,17 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
                                             sizeof(float) * (size_t)rp.H[l] * rp.W[l] * M * 32, B, stream);
             if (e != hipSuccess) return (int)e;
           }
-          // a workgroup keeps its tile for `scatter_planes` batch elements of its head (msda_scatter_rows.hip)
-          const int ppw = std::max(1, std::min(options().scatter_planes, B));
-          const int rows_grid = 8 * rp.n_items * ((B + ppw - 1) / ppw) * ((M + 7) / 8);
+          const int groups = (B * M + 7) / 8;
           const int lrs = loc_rs ? loc_rs : M * 32, ars = aw_rs ? aw_rs : M * 16;
-          const msda::BinPlan no_bins{};
           if (fused_ref && !saved)
-            msda::scatter_rows_kernel<true><<<rows_grid, msda::kRowThreads, 0, stream>>>(
-                loc, attw, grad_out, grad_value, fused_ref, fused_ref_dim, table, rp, B, S, M, lrs, ars, vv.mask, plans, nullptr, nullptr,
-                no_bins, nullptr, ppw);
+            msda::scatter_rows_kernel<true><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
+                loc, attw, grad_out, grad_value, fused_ref, fused_ref_dim, table, rp, B, S, M, lrs, ars, vv.mask, plans);
           else if (saved)
-            msda::scatter_rows_kernel<false, true><<<rows_grid, msda::kRowThreads, 0, stream>>>(
-                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, 0, 0, vv.mask, plans, nullptr, nullptr, no_bins, nullptr, ppw);
+            msda::scatter_rows_kernel<false, true><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
+                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, 0, 0, vv.mask, plans);
           else
-            msda::scatter_rows_kernel<false><<<rows_grid, msda::kRowThreads, 0, stream>>>(
-                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, lrs, ars, nullptr, nullptr, nullptr, nullptr, no_bins,
-                nullptr, ppw);
+            msda::scatter_rows_kernel<false><<<8 * rp.n_items * groups, msda::kRowThreads, 0, stream>>>(
+                loc, attw, grad_out, grad_value, nullptr, 0, table, rp, B, S, M, lrs, ars);
           if (fused_ref && saved)
             launch_gather<true, true, true>(value, loc, attw, grad_out, nullptr, grad_loc, grad_attw, fused_ref, fused_ref_dim,
                                             shapes_host, lsi_host, B, S, M, Lq, stream, loc_rs, aw_rs, grad_value, rp.reach, vv, plans);
@@ -640,7 +634,6 @@ int msda_set_option(const char *name, int value) {
   if (n == "scatter_bands" && (value == 0 || value == 1)) { options().scatter_bands = value; return 0; }
   if (n == "scatter_lists" && (value == 0 || value == 1)) { options().scatter_lists = value; return 0; }
   if (n == "plan_reach" && value >= 1 && value <= 16) { options().plan_reach = value; return 0; }
-  if (n == "scatter_planes" && value >= 1 && value <= 64) { options().scatter_planes = value; return 0; }
   if (n == "scatter_lists_cap" && value >= 0) { options().scatter_lists_cap = value; return 0; }
   return MSDA_E_UNSUPPORTED;
 }

@@ -91,13 +91,7 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
     const RowPlan p, int B, int S, int M, int loc_rs, int aw_rs, const unsigned char *__restrict__ vmask = nullptr,
     const HeadPlan *__restrict__ plans = nullptr, const unsigned *__restrict__ lists = nullptr,
     const unsigned *__restrict__ counts = nullptr, const BinPlan bp = BinPlan(),
-    const unsigned char *__restrict__ far_mask = nullptr, const int planes_per_wg = 1) {
-  // planes_per_wg: a workgroup owns its tile for that many consecutive BATCH elements of its head, one after the other.  The tile, its
-  // scan list and every other scalar of the item are the same for all of them (the plan is per head), so the workgroup's chain of
-  // dependent loads -- descriptor -> candidates -> points -- is paid once, and the batch loop runs straight on from one plane's last
-  // batch into the next plane's first (whose points are already in flight): a workgroup that lives for 3 - 4 batches spent a quarter
-  // of its time in that chain.  (The round-3 persistent form walked ITEMS: every item has its own scalars, and carrying a
-  // prefetched item's set beside the running one spilled.)
+    const unsigned char *__restrict__ far_mask = nullptr) {
   // lists / counts / bp (optional): EXACT scan lists (msda_bin.hip) -- a candidate entry is a query with a 4-bit mask of its points
   // that fall into this tile's cells; no bounds, no near / far classes.  `p` supplies the tiling and the (capacity-derived) chunking.
   // far_mask [B, M, L, Lq] (with the lists): points that did not fit SOME tile's list.  A point is far as a whole -- the gather kernel
@@ -115,16 +109,11 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
   __shared__ unsigned count[kRowTileRows];
   __shared__ int overflow;                                 // some bucket was full: the batch needs another round
 
-  // blockIdx -> (head, item, batch chunk); all workgroups of a head share blockIdx % 8, i.e. one XCD's L2 (speed only)
-  const int n_bchunks = (B + planes_per_wg - 1) / planes_per_wg;
-  int r_ = (int)(blockIdx.x >> 3);
-  const int it = r_ % p.n_items; r_ /= p.n_items;
-  const int bchunk = r_ % n_bchunks;
-  const int m = (r_ / n_bchunks) * 8 + (int)(blockIdx.x & 7);
-  if (m >= M) return;
-  const int b_first = bchunk * planes_per_wg, n_planes = min(planes_per_wg, B - b_first);
-  int b = b_first;
-  const int bm = b * M + m;                                // (lists: planes_per_wg == 1)
+  // blockIdx -> (batch * head, item); all items of one (batch, head) share blockIdx % 8, i.e. one XCD (speed only)
+  const int bm = (int)(blockIdx.x % 8) + 8 * (int)(blockIdx.x / (8 * p.n_items));
+  if (bm >= B * M) return;
+  const int it = (int)((blockIdx.x / 8) % p.n_items);
+  const int b = bm / M, m = bm - b * M;
   const HeadPlan *hp = plans ? plans + m : nullptr;
   int l, n_chunks, y0, th, x0, tw, c_begin, c_end;
   const RowCandidate *cands;
@@ -202,11 +191,9 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
   // Batch k takes candidates k, k + n_batches, k + 2 n_batches, ... of the chunk: a batch then samples the whole scan
   // region (a batch of NEIGHBOURS lands on a handful of cells of a coarse level and overflows their buckets).
   struct Points { float4 lg; float2 xy; float wt; RefScale rs; };
-  // (an empty scan list still takes one -- empty -- batch: the tile is written all the same)
-  const int n_batches = (MSDA_ROWS_SKIP & 128) ? 1 : max(1, (c_end - c_begin + kRowBatchQueries - 1) / kRowBatchQueries);
-  const int n_trips = n_planes * n_batches;                // the flattened (plane, batch) loop
-  auto cand_index = [&](const int t, const int u) {        // candidates of trip t: batch t % n_batches of the chunk
-    return t < n_trips ? c_begin + (t % n_batches) + (slot0 + u * (kRowThreads / 4)) * n_batches : c_end;
+  const int n_batches = (MSDA_ROWS_SKIP & 128) ? 1 : (c_end - c_begin + kRowBatchQueries - 1) / kRowBatchQueries;
+  auto cand_index = [&](const int k, const int u) {
+    return k < n_batches ? c_begin + k + (slot0 + u * (kRowThreads / 4)) * n_batches : c_end;
   };
   auto candidate = [&](const int j) {
     RowCandidate c{-1, 0, 0};
@@ -222,11 +209,11 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
     }
     return c;
   };
-  auto fetch = [&](const RowCandidate c, const int bb) {
+  auto fetch = [&](const RowCandidate c) {
     Points in{};
     if (c.token >= 0) {
-      const long long q_lin = (long long)bb * S + c.token;                         // Lq == S
-      const long long pl = (((long long)(bb * M + m) * 4 + l) * S + c.token) * 4 + pt;         // level-major point index
+      const long long q_lin = (long long)b * S + c.token;                          // Lq == S
+      const long long pl = (((long long)(b * M + m) * 4 + l) * S + c.token) * 4 + pt;          // level-major point index
       in.xy = LEVEL_MAJOR ? *reinterpret_cast<const float2 *>(loc + pl * 2)
                           : *reinterpret_cast<const float2 *>(loc + q_lin * loc_rs + ((m * 4 + l) * 4 + pt) * 2);
       if (FUSED) {
@@ -245,7 +232,7 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
 #pragma unroll
   for (int u = 0; u < kRowSub; ++u) {
     cur[u] = candidate(cand_index(0, u));
-    in[u] = fetch(cur[u], b);
+    in[u] = fetch(cur[u]);
     c_next[u] = candidate(cand_index(1, u));
   }
   lds_barrier();
@@ -253,12 +240,8 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
   long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = clock64();
 #endif
 
-  const int cy_out = cell / cw, cx_out = cell - cy_out * cw;
-  const bool is_out = cell < n_cells && cy_out >= 1 && cx_out >= 1;
-  int k = 0;                                               // batch within the plane
-  for (int t = 0; t < n_trips; ++t) {
+  for (int k = 0; k < n_batches; ++k) {
     ROWS_STAMP(0);
-    const bool last_of_plane = k + 1 == n_batches;
     // ---- 0. the batch's grad_out rows: this thread's 32 bytes of its candidates' rows ---------------------------------------
     float4 g0[kRowSub], g1[kRowSub];
 #pragma unroll
@@ -317,8 +300,8 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
         go_lds[slot * 8 + ((pt * 2 + 1) ^ (slot & 7))] = g1[u];      // read one chunk of different rows -> different banks
       }
       cur[u] = c_next[u];
-      in[u] = fetch(cur[u], last_of_plane ? b + 1 : b);    // (the candidate is invalid past the last trip: nothing is read)
-      c_next[u] = candidate(cand_index(t + 2, u));
+      in[u] = fetch(cur[u]);
+      c_next[u] = candidate(cand_index(k + 2, u));
     }
     ROWS_STAMP(1);
     // ---- 2./3. buckets and cell sums; a cell whose bucket overflows (many points on one pixel) takes more rounds -----------
@@ -383,83 +366,72 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
         lds_barrier();
       }
     } while (again);
-    ++k;
-    if (!last_of_plane) continue;
-    k = 0;
-
-    // ======== the plane's last batch is done: corner sums -> rows, write the tile, start over for the next batch element =========
-    if ((MSDA_ROWS_SKIP & 64) && sums[0][0].x != 123.456f) { ++b; continue; }
-    // ---- out[y, x] = S00[y, x] + S01[y, x - 1] + S10[y - 1, x] + S11[y - 1, x - 1] ------------------------------------------------
-    // ONE exchange through LDS (the batch tables: every wave is past its last walk): each lane leaves its S01, S10, S11 (96 bytes),
-    // one barrier, each output cell's lanes pick up the three neighbours' sums.  (Three separate 32-byte exchanges cost six barriers:
-    // the epilogue was 9 % of the kernel.)
-    {
-      float4 *mine = lds_pool + (cell * 4 + quarter) * 6;
-#pragma unroll
-      for (int j = 1; j < 4; ++j)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-          mine[(j - 1) * 2 + kk] = make_float4(sums[j][2 * kk].x, sums[j][2 * kk].y, sums[j][2 * kk + 1].x, sums[j][2 * kk + 1].y);
-      lds_barrier();
-      if (is_out) {
-        const int src[3] = {cell - 1, cell - cw, cell - cw - 1};              // S01 from the left cell, S10 from above, S11 from above-left
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) {
-            const float4 v = lds_pool[(src[j] * 4 + quarter) * 6 + j * 2 + kk];
-            sums[0][2 * kk] += (rows_v2f){v.x, v.y};
-            sums[0][2 * kk + 1] += (rows_v2f){v.z, v.w};
-          }
-      }
-    }
-
-    // ---- write the tile ---------------------------------------------------------------------------------------------------
-    float4 acc[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) acc[kk] = make_float4(sums[0][2 * kk].x, sums[0][2 * kk].y, sums[0][2 * kk + 1].x, sums[0][2 * kk + 1].y);
-    const long long tok0 = (long long)b * S + p.start[l];
-    if (n_chunks == 1) {
-      if (is_out) {
-        const long long token = tok0 + (long long)(y0 + cy_out - 1) * W + (x0 + cx_out - 1);
-        float *dst = grad_value + (token * M + m) * 32 + quarter * 8;
-        const bool padded = vmask && vmask[token];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) st4(dst + 4 * kk, padded ? make_float4(0.f, 0.f, 0.f, 0.f) : acc[kk]);
-      }
-    } else {
-      // several workgroups share the tile: full 128-byte rows of atomics (lane = channel), through LDS
-      lds_barrier();                           // every lane has picked up its neighbours' sums: the pool is free again
-      float *rows_lds = reinterpret_cast<float *>(go_lds);
-      if (is_out) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) *reinterpret_cast<float4 *>(rows_lds + cell * 32 + quarter * 8 + 4 * kk) = acc[kk];
-      }
-      lds_barrier();
-      const int ch = tid & 31;
-      for (int rr = tid >> 5; rr < n_cells; rr += kRowThreads / 32) {
-        const int ry = rr / cw, rx = rr - ry * cw;
-        if (ry < 1 || rx < 1) continue;
-        const float v = rows_lds[rr * 32 + ch];
-        const long long token = tok0 + (long long)(y0 + ry - 1) * W + (x0 + rx - 1);
-        if (v != 0.f && !(vmask && vmask[token])) atomicAdd(grad_value + (token * M + m) * 32 + ch, v);
-      }
-    }
-    if (t + 1 < n_trips) {
-      // the next plane: fresh sums; the pool goes back to the batch tables (every lane is past its reads of it)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sums[j][i] = (rows_v2f){0.f, 0.f};
-      ++b;
-      lds_barrier();
-    }
   }
+
 #if MSDA_ROWS_STAMP
   ROWS_STAMP(6);
   if ((threadIdx.x & 63) == 0)
     for (int i = 0; i < 8; ++i) atomicAdd(&g_rows_stamp[i], (unsigned long long)st_acc[i]);
 #endif
+  if ((MSDA_ROWS_SKIP & 64) && sums[0][0].x != 123.456f) return;
+  // ---- corner sums -> rows: out[y, x] = S00[y, x] + S01[y, x - 1] + S10[y - 1, x] + S11[y - 1, x - 1] ---------------------------
+  // ONE exchange through LDS (the batch tables: every wave is past its last walk): each lane leaves its S01, S10, S11 (96 bytes),
+  // one barrier, each output cell's lanes pick up the three neighbours' sums.  (Three separate 32-byte exchanges cost six barriers:
+  // the epilogue was 9 % of the kernel.)
+  const int cy = cell / cw, cx = cell - cy * cw;
+  const bool is_out = cell < n_cells && cy >= 1 && cx >= 1;
+  {
+    float4 *mine = lds_pool + (cell * 4 + quarter) * 6;
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        mine[(j - 1) * 2 + kk] = make_float4(sums[j][2 * kk].x, sums[j][2 * kk].y, sums[j][2 * kk + 1].x, sums[j][2 * kk + 1].y);
+    lds_barrier();
+    if (is_out) {
+      const int src[3] = {cell - 1, cell - cw, cell - cw - 1};              // S01 from the left cell, S10 from above, S11 from above-left
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const float4 v = lds_pool[(src[j] * 4 + quarter) * 6 + j * 2 + kk];
+          sums[0][2 * kk] += (rows_v2f){v.x, v.y};
+          sums[0][2 * kk + 1] += (rows_v2f){v.z, v.w};
+        }
+    }
+  }
+
+  // ---- write the tile -------------------------------------------------------------------------------------------------
+  float4 acc[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) acc[k] = make_float4(sums[0][2 * k].x, sums[0][2 * k].y, sums[0][2 * k + 1].x, sums[0][2 * k + 1].y);
+  const long long tok0 = (long long)b * S + p.start[l];
+  if (n_chunks == 1) {
+    if (is_out) {
+      const long long token = tok0 + (long long)(y0 + cy - 1) * W + (x0 + cx - 1);
+      float *dst = grad_value + (token * M + m) * 32 + quarter * 8;
+      const bool padded = vmask && vmask[token];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) st4(dst + 4 * k, padded ? make_float4(0.f, 0.f, 0.f, 0.f) : acc[k]);
+    }
+  } else {
+    // several workgroups share the tile: full 128-byte rows of atomics (lane = channel), through LDS
+    lds_barrier();                           // every lane has picked up its neighbours' sums: the pool is free again
+    float *rows_lds = reinterpret_cast<float *>(go_lds);
+    if (is_out) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) *reinterpret_cast<float4 *>(rows_lds + cell * 32 + quarter * 8 + 4 * k) = acc[k];
+    }
+    __syncthreads();
+    const int ch = tid & 31;
+    for (int rr = tid >> 5; rr < n_cells; rr += kRowThreads / 32) {
+      const int ry = rr / cw, rx = rr - ry * cw;
+      if (ry < 1 || rx < 1) continue;
+      const float v = rows_lds[rr * 32 + ch];
+      const long long token = tok0 + (long long)(y0 + ry - 1) * W + (x0 + rx - 1);
+      if (v != 0.f && !(vmask && vmask[token])) atomicAdd(grad_value + (token * M + m) * 32 + ch, v);
+    }
+  }
 }
 
 }  // namespace msda

@@ -10,7 +10,7 @@ from ._lib import raw_stream, on_device
 from .token_linear import linear as fast_linear
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_attn.so")
-SYMBOLS = ("mono_attn_forward_f32", "mono_attn_backward_f32")
+SYMBOLS = ("mono_attn_forward_f32", "mono_attn_backward_f32", "mono_attn_forward_masked_f32", "mono_attn_backward_masked_f32")
 _lib = None
 
 
@@ -29,6 +29,10 @@ def load():
         lib.mono_attn_forward_f32.argtypes = [P] * 5 + [I] * 5 + [_Strides] * 4 + [F, F, U, P]
         lib.mono_attn_backward_f32.restype = I
         lib.mono_attn_backward_f32.argtypes = [P] * 10 + [I] * 5 + [_Strides] * 7 + [F, F, U, P]
+        lib.mono_attn_forward_masked_f32.restype = I
+        lib.mono_attn_forward_masked_f32.argtypes = [P] * 6 + [I] * 5 + [_Strides] * 4 + [F, F, U, P]
+        lib.mono_attn_backward_masked_f32.restype = I
+        lib.mono_attn_backward_masked_f32.argtypes = [P] * 11 + [I] * 5 + [_Strides] * 7 + [F, F, U, P]
         _lib = lib
     return _lib
 
@@ -55,16 +59,28 @@ def _next_seed():
     return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _seed_counter[0] * 0xD1B54A32D192ED03 + rank * 0x94D049BB133111EB) & (2 ** 63 - 1)   # fits int64: autograd / profiler argument records
 
 
-def forward(q, k, v, scale, p, seed):
+def _mask_ptr(mask, B, Lk):
+    """key padding mask -> pointer of a contiguous [B, Lk] byte tensor (0 for None); non-zero / True = padded key"""
+    if mask is None:
+        return 0, None
+    if mask.dtype != torch.uint8:
+        mask = mask.to(torch.uint8) if mask.dtype != torch.bool else mask.view(torch.uint8)
+    mask = mask.contiguous()
+    assert tuple(mask.shape) == (B, Lk) and mask.is_cuda, "key_padding_mask must be a [B, Lk] tensor on the GPU"
+    return mask.data_ptr(), mask
+
+
+def forward(q, k, v, scale, p, seed, key_padding_mask=None):
     B, H, Lq, _ = q.shape
     o = torch.empty((B, H, Lq, 32), dtype=torch.float32, device=q.device)
     lse = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
+    mp, keep = _mask_ptr(key_padding_mask, B, k.size(2))
     with on_device(q.device):
-        code = load().mono_attn_forward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Lq,
-                                            k.size(2), 32, _strides(q), _strides(k), _strides(v), _strides(o), float(scale),
-                                            float(p), seed, raw_stream())
+        code = load().mono_attn_forward_masked_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, o.data_ptr(), lse.data_ptr(), B, H, Lq,
+                                                   k.size(2), 32, _strides(q), _strides(k), _strides(v), _strides(o), float(scale),
+                                                   float(p), seed, raw_stream())
     if code:
-        raise RuntimeError("mono_attn_forward_f32 failed with code %d" % code)
+        raise RuntimeError("mono_attn_forward_masked_f32 failed with code %d" % code)
     return o, lse
 
 
@@ -82,20 +98,21 @@ def _like_heads(t):
     return torch.empty((L, B, H * 32), dtype=torch.float32, device=t.device).view(L, B, H, 32).permute(1, 2, 0, 3)
 
 
-def backward(q, k, v, o, lse, dout, scale, p, seed):
+def backward(q, k, v, o, lse, dout, scale, p, seed, key_padding_mask=None):
     """dq, dk, dv as [B, H, L, 32] views of fresh buffers laid out like q, k, v (the layout of the MHA projections)."""
     B, H, Lq, _ = q.shape
     Lk = k.size(2)
     dq, dk, dv = _like_heads(q), _like_heads(k), _like_heads(v)
     delta = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
     assert dout.stride() == o.stride()
+    mp, keep = _mask_ptr(key_padding_mask, B, Lk)
     with on_device(q.device):
-        code = load().mono_attn_backward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), dout.data_ptr(),
-                                             dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H, Lq, Lk, 32,
-                                             _strides(q), _strides(k), _strides(v), _strides(o), _strides(dq), _strides(dk),
-                                             _strides(dv), float(scale), float(p), seed, raw_stream())
+        code = load().mono_attn_backward_masked_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, o.data_ptr(), lse.data_ptr(),
+                                                    dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H,
+                                                    Lq, Lk, 32, _strides(q), _strides(k), _strides(v), _strides(o), _strides(dq),
+                                                    _strides(dk), _strides(dv), float(scale), float(p), seed, raw_stream())
     if code:
-        raise RuntimeError("mono_attn_backward_f32 failed with code %d" % code)
+        raise RuntimeError("mono_attn_backward_masked_f32 failed with code %d" % code)
     return dq, dk, dv
 
 
@@ -103,18 +120,19 @@ class _Attention(torch.autograd.Function):
     """q, k, v: [B, H, L, 32] (strided views are fine); returns O as a [B, H, Lq, 32] view of an [Lq, B, H*32] buffer."""
 
     @staticmethod
-    def forward(ctx, q, k, v, scale, p, seed):
+    def forward(ctx, q, k, v, scale, p, seed, mask=None):
         B, H, Lq, _ = q.shape
         o = _like_heads(q)                           # [Lq, B, H*32] or, for a batch-major q, [B, Lq, H*32]
         lse = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
+        mp, mask = _mask_ptr(mask, B, k.size(2))
         with on_device(q.device):
-            code = load().mono_attn_forward_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Lq,
-                                                k.size(2), 32, _strides(q), _strides(k), _strides(v), _strides(o), float(scale),
-                                                float(p), seed, raw_stream())
+            code = load().mono_attn_forward_masked_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, o.data_ptr(), lse.data_ptr(), B, H,
+                                                       Lq, k.size(2), 32, _strides(q), _strides(k), _strides(v), _strides(o),
+                                                       float(scale), float(p), seed, raw_stream())
         if code:
-            raise RuntimeError("mono_attn_forward_f32 failed with code %d" % code)
+            raise RuntimeError("mono_attn_forward_masked_f32 failed with code %d" % code)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.scale, ctx.p, ctx.seed = scale, p, seed
+        ctx.scale, ctx.p, ctx.seed, ctx.mask = scale, p, seed, mask
         return o
 
     @staticmethod
@@ -124,23 +142,24 @@ class _Attention(torch.autograd.Function):
             d2 = _like_heads(o)
             d2.copy_(dout)
             dout = d2
-        dq, dk, dv = backward(q, k, v, o, lse, dout, ctx.scale, ctx.p, ctx.seed)
-        return dq, dk, dv, None, None, None
+        dq, dk, dv = backward(q, k, v, o, lse, dout, ctx.scale, ctx.p, ctx.seed, ctx.mask)
+        return dq, dk, dv, None, None, None, None
 
 
-def attention(q, k, v, dropout_p=0.0, scale=None, seed=None):
-    """softmax(q k^T * scale) with dropout, times v, per (batch, head); q/k/v [B, H, L, 32] float32 on the GPU."""
+def attention(q, k, v, dropout_p=0.0, scale=None, seed=None, key_padding_mask=None):
+    """softmax(q k^T * scale) with dropout, times v, per (batch, head); q/k/v [B, H, L, 32] float32 on the GPU.
+    key_padding_mask: [B, Lk] bool / uint8, True = the key is padding (nn.MultiheadAttention's convention)."""
     if not supported(q, k, v):
         raise RuntimeError("flash_attn.attention: unsupported tensors (need float32 GPU [B,H,L,32], 16-byte aligned strides)")
     scale = 1.0 / math.sqrt(q.size(-1)) if scale is None else scale
     if dropout_p > 0 and seed is None:
         seed = _next_seed()
-    return _Attention.apply(q, k, v, scale, float(dropout_p), int(seed or 0))
+    return _Attention.apply(q, k, v, scale, float(dropout_p), int(seed or 0), key_padding_mask)
 
 
-def mha_forward(mha, query, key, value):
-    """``mha(query, key, value, need_weights=False)[0]`` for an ``nn.MultiheadAttention`` with 32-channel heads, no
-    masks, [L, B, E] inputs: packed input projections, the HIP attention core on strided views (no head-major
+def mha_forward(mha, query, key, value, key_padding_mask=None):
+    """``mha(query, key, value, key_padding_mask=..., need_weights=False)[0]`` for an ``nn.MultiheadAttention`` with 32-channel
+    heads, [L, B, E] inputs (no attn_mask; the key padding mask -- [B, Lk], True = padding -- goes into the kernels): packed input projections, the HIP attention core on strided views (no head-major
     copies), output projection.  (torch.nn.functional.multi_head_attention_forward, as called at
     depth_predictor/transformer.py:59 and depthaware_transformer.py:417.)"""
     E, H = mha.embed_dim, mha.num_heads
@@ -176,7 +195,7 @@ def mha_forward(mha, query, key, value):
         (w_q, w_k, w_v), (b_q, b_k, b_v) = w.split(E), bias.split(E)
         q, k, v = lin(query, w_q, b_q), lin(key, w_k, b_k), lin(value, w_v, b_v)
     heads = lambda t, L: t.unflatten(-1, (H, 32)).permute(1, 2, 0, 3)           # [L,B,E] -> [B,H,L,32] view
-    o = attention(heads(q, Lq), heads(k, Lk), heads(v, Lk), mha.dropout if mha.training else 0.0)
+    o = attention(heads(q, Lq), heads(k, Lk), heads(v, Lk), mha.dropout if mha.training else 0.0, key_padding_mask=key_padding_mask)
     if _batch_major(o):                                 # o lies like q: out_proj on [B, Lq, E], returned as its [Lq, B, E] view
         return fast_linear(o.permute(0, 2, 1, 3).reshape(B, Lq, E), mha.out_proj.weight, mha.out_proj.bias).transpose(0, 1)
     return fast_linear(o.permute(2, 0, 1, 3).reshape(Lq, B, E), mha.out_proj.weight, mha.out_proj.bias)

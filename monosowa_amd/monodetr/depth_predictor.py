@@ -32,8 +32,8 @@ class DepthEncoderLayer(nn.Module):
 
     def forward(self, src, src_key_padding_mask, pos):
         qk = src if pos is None else src + pos
-        if src_key_padding_mask is None and mha_supported(self.self_attn, qk, qk, src):
-            attn = mha_forward(self.self_attn, qk, qk, src)          # HIP fp32 attention core
+        if mha_supported(self.self_attn, qk, qk, src):
+            attn = mha_forward(self.self_attn, qk, qk, src, key_padding_mask=src_key_padding_mask)          # HIP fp32 attention core
         else:
             attn = self.self_attn(qk, qk, value=src, key_padding_mask=src_key_padding_mask, need_weights=False)[0]
         src = dropout_add_layernorm(src, attn, self.norm1, self.dropout1)

@@ -1005,6 +1005,66 @@ def test_mha_forward_equals_nn_multiheadattention(same_qk):
         assert (a - b).abs().max() <= 2e-5 * max(b.abs().max().item(), 1e-3)
 
 
+@pytest.mark.parametrize("pattern", ["depth_encoder", "decoder_cross"])
+@pytest.mark.parametrize("train", [False, True])
+def test_mha_forward_with_padded_keys_equals_nn_multiheadattention(pattern, train):
+    """The key padding mask inside the HIP attention kernels (mono_attn_*_masked_f32): mha_forward(..., key_padding_mask) against
+    nn.MultiheadAttention(..., key_padding_mask) -- output, input and parameter gradients -- with a different number of padded
+    keys per batch element, a padded run that ends inside a 64-key tile, a ragged last tile, and one element without padding.
+    Reference call sites: depthaware_transformer.py:456-459 (decoder depth cross-attention), depth_predictor/transformer.py:57-60.
+    train = True: dropout 0 in train mode (the module's dropout path with p = 0; a random mask cannot be compared across
+    implementations -- test_attention_dropout_uses_one_mask_forward_and_backward covers it)."""
+    from monosowa_amd.flash_attn import mha_forward, mha_supported
+    torch.manual_seed(5)
+    mha = torch.nn.MultiheadAttention(256, 8, dropout=0.0).cuda().train(train)
+    B, Lk, Lq = 3, 150, 70
+    x = torch.randn(Lk, B, 256, device="cuda", requires_grad=True)
+    y = torch.randn(Lq, B, 256, device="cuda", requires_grad=True)
+    mask = torch.zeros(B, Lk, dtype=torch.bool, device="cuda")
+    mask[0, 100:] = True            # a padded tail that starts inside the second tile
+    mask[1, 5:40] = True            # ... and a padded run in the middle
+    args = (x, x, (x.detach() * 0.5).clone().requires_grad_(True)) if pattern == "depth_encoder" else (y, x, x)
+    assert mha_supported(mha, *args)
+    go = torch.randn(args[0].shape, device="cuda")
+
+    def run(fn):
+        for t in set(args):
+            t.grad = None
+        mha.zero_grad()
+        out = fn()
+        out.backward(go)
+        return [out.detach().clone()] + [t.grad.clone() for t in args if t.grad is not None] + [p_.grad.clone() for p_ in mha.parameters()]
+    ours = run(lambda: mha_forward(mha, *args, key_padding_mask=mask))
+    ref = run(lambda: mha(*args, key_padding_mask=mask, need_weights=False)[0])
+    assert len(ours) == len(ref)
+    for a, b in zip(ours, ref):
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max() <= 2e-5 * max(b.abs().max().item(), 1e-3)
+
+
+def test_masked_attention_core_matches_fp64_and_zeroes_the_padded_keys_gradients():
+    """attention(q, k, v, key_padding_mask) against an fp64 masked softmax attention; dk / dv of padded keys are exactly zero."""
+    from monosowa_amd import flash_attn as FA
+    torch.manual_seed(6)
+    B, H, Lq, Lk = 2, 8, 200, 333
+    q, k, v = (torch.randn(B, H, L, 32, device="cuda", requires_grad=True) for L in (Lq, Lk, Lk))
+    mask = torch.rand(B, Lk, device="cuda") < 0.3
+    mask[:, 0] = False
+    go = torch.randn(B, H, Lq, 32, device="cuda")
+    out = FA.attention(q, k, v, key_padding_mask=mask)
+    out.backward(go)
+    qd, kd, vd = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    s = (qd @ kd.transpose(-1, -2)) / 32 ** 0.5
+    s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    ref = torch.softmax(s, -1) @ vd
+    ref.backward(go.double())
+    assert (out.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    for name, a, b in (("dq", q.grad, qd.grad), ("dk", k.grad, kd.grad), ("dv", v.grad, vd.grad)):
+        assert (a.double() - b).abs().max() <= 1e-5 * b.abs().max(), name
+    dead = mask[:, None, :, None].expand_as(k.grad)
+    assert (k.grad[dead] == 0).all() and (v.grad[dead] == 0).all()
+
+
 def test_fused_adamw_matches_the_foreach_formulation():
     """mono_adamw_step_f32 (one launch for all parameters) against the foreach evaluation of the same update
     (itself bit-identical to the reference on the CPU, tests/test_helpers.py), over several steps, with odd sizes,
