@@ -23,6 +23,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef ATTN_FWD_WAVES
 #define ATTN_FWD_WAVES 4        // waves per SIMD the forward is compiled for: 128 VGPRs, no spills (2: 130 VGPRs with dropout = 3 waves; in the step 703 -> 686 us on the 1920 x 1920 launch)
 #endif
+#ifndef ATTN_BWD_WAVES
+#define ATTN_BWD_WAVES 3        // waves per SIMD the two backward kernels are compiled for (170 VGPRs; 2 waves / 256 VGPRs measures the same)
+#endif
+#ifndef ATTN_PREFETCH
+#define ATTN_PREFETCH 0         // measurement builds only (with ATTN_BWD_WAVES=2: 210 VGPRs): all LDS operands of a 32-row half requested at its
+                                // top instead of right in front of the MFMA that consumes them.  Measured round 4: 2.12 vs 2.09 ms on the
+                                // 1920 x 1920 backward -- the LDS round trips are not what the MFMA pipe waits for
+#endif
+#ifndef ATTN_SKIP
+#define ATTN_SKIP 0             // measurement builds only (bits, backward kernels): 1 no exp2 of the recomputed scores, 2 no dropout hash,
+                                // 4 no second-stage MFMAs (dQ / dK, dV), 8 no recomputation MFMAs (S, dP), 16 no LDS reads of the A operands
+#endif
 constexpr int kBlockQ = 128;     // queries per workgroup (4 waves x 32)
 constexpr int kTileK = 64;       // keys per LDS tile
 constexpr int kKStride = 36;     // floats per K row in LDS: 16-lane ds_read_b128 phases hit 64 distinct banks
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(256) void delta_kernel(const Args a, int B) {
 // dQ: same decomposition as the forward (a lane owns one query); per 32-key half: S^T (recomputed), dP^T = V dO^T,
 // dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T -- 48 MFMAs.
 template <bool DROP, bool MASK = false>
-__global__ __launch_bounds__(256, 3) void bwd_dq_kernel(const Args a) {
+__global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dq_kernel(const Args a) {
   __shared__ float Ks[2][kTileK * kKStride];
   __shared__ float Vs[2][kTileK * kKStride];
   __shared__ float Bs[2][MASK ? kTileK : 4];            // additive key bias, as in the forward
@@ -281,9 +293,25 @@ __global__ __launch_bounds__(256, 3) void bwd_dq_kernel(const Args a) {
     for (int half = 0; half < 2; ++half) {
       f32x16 s = zero, dp = zero;
       const float *k0 = &Ks[buf][(half * 32 + r) * kKStride + 16 * h], *v0 = &Vs[buf][(half * 32 + r) * kKStride + 16 * h];
+      const float *kc = &Ks[buf][(half * 32 + 4 * h) * kKStride + r];          // dQ^T += K^T dS^T : A = K[key(t, h)][d = r]
+#if ATTN_PREFETCH
+      float4 ka4[4], va4[4];
+      float kq[16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ka4[i] = ld4(k0 + 4 * i); va4[i] = ld4(v0 + 4 * i); }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) kq[t] = kc[(8 * (t >> 2) + (t & 3)) * kKStride];
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float4 ka = ld4(k0 + 4 * i), va = ld4(v0 + 4 * i);
+#if ATTN_PREFETCH
+        const float4 ka = ka4[i], va = va4[i];
+#else
+        const float4 ka = (ATTN_SKIP & 16) ? make_float4(qreg[0], qreg[1], qreg[2], qreg[3]) : ld4(k0 + 4 * i);
+        const float4 va = (ATTN_SKIP & 16) ? make_float4(doreg[0], doreg[1], doreg[2], doreg[3]) : ld4(v0 + 4 * i);
+#endif
+        if (ATTN_SKIP & 8) { s[i] += ka.x + ka.y + ka.z + ka.w; dp[i] += va.x + va.y + va.z + va.w; continue; }
         s = mfma(ka.x, qreg[4 * i], s);     dp = mfma(va.x, doreg[4 * i], dp);
         s = mfma(ka.y, qreg[4 * i + 1], s); dp = mfma(va.y, doreg[4 * i + 1], dp);
         s = mfma(ka.z, qreg[4 * i + 2], s); dp = mfma(va.z, doreg[4 * i + 2], dp);
@@ -300,20 +328,25 @@ __global__ __launch_bounds__(256, 3) void bwd_dq_kernel(const Args a) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int key = key0 + 8 * (v >> 2) + (v & 3);
-        float p = __builtin_amdgcn_exp2f(s[v] - lse);       // a masked key: exp2(-inf) = 0
+        float p = (ATTN_SKIP & 1) ? s[v] - lse : __builtin_amdgcn_exp2f(s[v] - lse);       // a masked key: exp2(-inf) = 0
         if (!MASK && key >= a.Lk) p = 0.f;
         float dpe = dp[v];
-        if (DROP) {
+        if (DROP && !(ATTN_SKIP & 2)) {
           const unsigned bits = drop_bits(hseed, (unsigned)q, (unsigned)key >> 1);        // CSE'd across the pair
           const unsigned mine = (key & 1) ? (bits >> 16) : (bits & 0xFFFFu);
           dpe = mine >= a.drop_thr16 ? dpe * a.drop_scale : 0.f;
         }
         s[v] = p * (dpe - delta);                                                          // dS^T
       }
-      // dQ^T += K^T dS^T : A = K[key(t, h)][d = r]
-      const float *kc = &Ks[buf][(half * 32 + 4 * h) * kKStride + r];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) dq = mfma(kc[(8 * (t >> 2) + (t & 3)) * kKStride], s[t], dq);
+      for (int t = 0; t < 16; ++t) {
+        if (ATTN_SKIP & 4) { dq[t] += s[t]; continue; }
+#if ATTN_PREFETCH
+        dq = mfma(kq[t], s[t], dq);
+#else
+        dq = mfma((ATTN_SKIP & 16) ? qreg[t] : kc[(8 * (t >> 2) + (t & 3)) * kKStride], s[t], dq);
+#endif
+      }
     }
     if (kt + 1 < n_tiles) store_tile(buf ^ 1);
     __syncthreads();
@@ -329,7 +362,7 @@ __global__ __launch_bounds__(256, 3) void bwd_dq_kernel(const Args a) {
 // dK, dV: a lane owns one KEY (S = Q K^T untransposed: col = key, rows = 16 queries); per 32-query half:
 // S, dP = dO V^T, dV^T += dO^T P_drop, dK^T += Q^T dS -- 64 MFMAs.  Row statistics (lse, delta) come from LDS.
 template <bool DROP, bool MASK = false>
-__global__ __launch_bounds__(256, 3) void bwd_dkdv_kernel(const Args a) {
+__global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dkdv_kernel(const Args a) {
   __shared__ float Qs[2][kTileK * kKStride];
   __shared__ float Ds[2][kTileK * kKStride];
   __shared__ float Ls[2][kTileK], Es[2][kTileK];          // lse, delta of the tile's queries
@@ -390,9 +423,28 @@ __global__ __launch_bounds__(256, 3) void bwd_dkdv_kernel(const Args a) {
     for (int half = 0; half < 2; ++half) {
       f32x16 s = zero, dp = zero;
       const float *q0 = &Qs[buf][(half * 32 + r) * kKStride + 16 * h], *d0 = &Ds[buf][(half * 32 + r) * kKStride + 16 * h];
+      const float *dc = &Ds[buf][(half * 32 + 4 * h) * kKStride + r], *qc = &Qs[buf][(half * 32 + 4 * h) * kKStride + r];
+#if ATTN_PREFETCH
+      float4 qa4[4], da4[4];
+      float dcv[16], qcv[16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { qa4[i] = ld4(q0 + 4 * i); da4[i] = ld4(d0 + 4 * i); }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = (8 * (t >> 2) + (t & 3)) * kKStride;
+        dcv[t] = dc[row]; qcv[t] = qc[row];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float4 qa = ld4(q0 + 4 * i), da = ld4(d0 + 4 * i);
+#if ATTN_PREFETCH
+        const float4 qa = qa4[i], da = da4[i];
+#else
+        const float4 qa = (ATTN_SKIP & 16) ? make_float4(kreg[0], kreg[1], kreg[2], kreg[3]) : ld4(q0 + 4 * i);
+        const float4 da = (ATTN_SKIP & 16) ? make_float4(vreg[0], vreg[1], vreg[2], vreg[3]) : ld4(d0 + 4 * i);
+#endif
+        if (ATTN_SKIP & 8) { s[i] += qa.x + qa.y + qa.z + qa.w; dp[i] += da.x + da.y + da.z + da.w; continue; }
         s = mfma(qa.x, kreg[4 * i], s);     dp = mfma(da.x, vreg[4 * i], dp);
         s = mfma(qa.y, kreg[4 * i + 1], s); dp = mfma(da.y, vreg[4 * i + 1], dp);
         s = mfma(qa.z, kreg[4 * i + 2], s); dp = mfma(da.z, vreg[4 * i + 2], dp);
@@ -406,9 +458,9 @@ __global__ __launch_bounds__(256, 3) void bwd_dkdv_kernel(const Args a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int v = 4 * g + j;
-          const float p = dead ? 0.f : __builtin_amdgcn_exp2f(s[v] - ls[j]);
+          const float p = dead ? 0.f : ((ATTN_SKIP & 1) ? s[v] - ls[j] : __builtin_amdgcn_exp2f(s[v] - ls[j]));
           float pd = p, dpe = dp[v];
-          if (DROP) {
+          if (DROP && !(ATTN_SKIP & 2)) {
             const unsigned bits = drop_bits(hseed, (unsigned)(q0i + 8 * g + j), (unsigned)key >> 1);
             const unsigned mine = (key & 1) ? (bits >> 16) : (bits & 0xFFFFu);
             const bool keep = mine >= a.drop_thr16;
@@ -419,12 +471,17 @@ __global__ __launch_bounds__(256, 3) void bwd_dkdv_kernel(const Args a) {
           s[v] = p * (dpe - es[j]);                            // dS       (operand of dK)
         }
       }
-      const float *dc = &Ds[buf][(half * 32 + 4 * h) * kKStride + r], *qc = &Qs[buf][(half * 32 + 4 * h) * kKStride + r];
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
+        if (ATTN_SKIP & 4) { dv[t] += dp[t]; dk[t] += s[t]; continue; }
+#if ATTN_PREFETCH
+        dv = mfma(dcv[t], dp[t], dv);
+        dk = mfma(qcv[t], s[t], dk);
+#else
         const int row = (8 * (t >> 2) + (t & 3)) * kKStride;
-        dv = mfma(dc[row], dp[t], dv);
-        dk = mfma(qc[row], s[t], dk);
+        dv = mfma((ATTN_SKIP & 16) ? vreg[t] : dc[row], dp[t], dv);
+        dk = mfma((ATTN_SKIP & 16) ? kreg[t] : qc[row], s[t], dk);
+#endif
       }
     }
     if (qt + 1 < n_tiles) store_tile(buf ^ 1);

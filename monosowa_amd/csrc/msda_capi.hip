@@ -69,6 +69,7 @@ struct Options {
                                // dominates) against 35 + 473 us -- it only wins beyond sigma = 8 px (2.35 vs 2.65 ms)
   int scatter_lists_cap = 0;   // > 0: capacity of every exact scan list (tests: forces list overflow -> the far path); 0: sized from Lq
   int scatter_bands = 1;       // 1 (default): row-band scatter (msda_backward_bands.hip) for short record lists (Lq <= 576: the decoder)
+  int plan_fused = 1;          // 1 (default): statistics + per-head plan + candidate tables in one launch (plan_fused_kernel); 0: three kernels
   int plan_reach = 8;          // capacity of the directional scan: |footprint - centre| beyond this many pixels is "far" in any case
   Options() {                                               // the environment is read ONCE, at first use
     if (const char *e = std::getenv("MSDA_GATHER")) gather = std::atoi(e);
@@ -84,6 +85,7 @@ struct Options {
     if (const char *e = std::getenv("MSDA_DIRECTIONAL")) directional = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSDA_SCATTER_BANDS")) scatter_bands = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSDA_SCATTER_LISTS")) scatter_lists = std::atoi(e) != 0;
+    if (const char *e = std::getenv("MSDA_PLAN_FUSED")) plan_fused = std::atoi(e) != 0;
     if (const char *e = std::getenv("MSDA_PLAN_REACH")) plan_reach = std::min(16, std::max(1, std::atoi(e)));
   }
 };
@@ -495,26 +497,30 @@ int backward_impl(const T *value, const int64_t *shapes, const int64_t *lsi, con
           for (int l = 0; l < 4; ++l) n_tiles += rp.n_ty[l] * rp.n_tx[l];
           if (plan_mode && !(directional && saved)) return MSDA_E_UNSUPPORTED;
           if (directional && plan_mode != 2) {
-            msda::DirStats *partial = reinterpret_cast<msda::DirStats *>(wsp + plan_b);
             msda::PlanGeom pg{};
-            msda::WinGeom wg;
-            window_tiling(shapes_host, lsi_host, options().window_halo, true, wg);      // (window_applies() above: it exists)
             for (int l = 0; l < 4; ++l) { pg.H[l] = rp.H[l]; pg.W[l] = rp.W[l]; pg.start[l] = rp.start[l]; }
             pg.S = S; pg.M = M;
-            pg.win_n_ty = wg.n_ty; pg.win_n_tx = wg.n_tx;
-            pg.win_budget_rows = msda::kWinMaxRowsBwd;
-            pg.win_max_queries = msda::kWinMaxQueries;
             pg.default_halo = options().window_halo;
             pg.reach = reach;
             pg.want_rows = 1;
-            if (saved)
-              msda::dir_stats_kernel<1><<<msda::kStatsBlocks, msda::kStatsThreads, 0, stream>>>(loc, nullptr, pg, B, 0, partial);
-            else
-              msda::dir_stats_kernel<0><<<msda::kStatsBlocks, msda::kStatsThreads, 0, stream>>>(
-                  loc, fused_ref, pg, B, loc_rs ? loc_rs : M * 32, partial);
-            msda::dir_plan_kernel<<<M, 256, 0, stream>>>(partial, msda::kStatsBlocks, pg, rp, plans);
+            if (options().plan_fused) {
+              // statistics, per-head plan and candidate tables in ONE launch (msda_plan.hip: plan_fused_kernel)
+              if (saved)
+                msda::plan_fused_kernel<1><<<M * n_tiles, 256, 0, stream>>>(loc, nullptr, pg, rp, B, 0, n_tiles, plans, table);
+              else
+                msda::plan_fused_kernel<0><<<M * n_tiles, 256, 0, stream>>>(loc, fused_ref, pg, rp, B, loc_rs ? loc_rs : M * 32, n_tiles,
+                                                                            plans, table);
+            } else {
+              msda::DirStats *partial = reinterpret_cast<msda::DirStats *>(wsp + plan_b);
+              if (saved)
+                msda::dir_stats_kernel<1><<<msda::kStatsBlocks, msda::kStatsThreads, 0, stream>>>(loc, nullptr, pg, B, 0, partial);
+              else
+                msda::dir_stats_kernel<0><<<msda::kStatsBlocks, msda::kStatsThreads, 0, stream>>>(
+                    loc, fused_ref, pg, B, loc_rs ? loc_rs : M * 32, partial);
+              msda::dir_plan_kernel<<<M, 256, 0, stream>>>(partial, msda::kStatsBlocks, pg, rp, plans);
+            }
           }
-          if (plan_mode != 2)
+          if (plan_mode != 2 && !(directional && options().plan_fused))
             msda::row_candidates_kernel<<<n_tiles * (directional ? M : 1), 256, 0, stream>>>(rp, table, plans, n_tiles);
           if (plan_mode == 1) return launch_status();
           for (int l = 0; l < L; ++l) {          // levels shared by several workgroups are accumulated with atomics
@@ -634,6 +640,7 @@ int msda_set_option(const char *name, int value) {
   if (n == "scatter_bands" && (value == 0 || value == 1)) { options().scatter_bands = value; return 0; }
   if (n == "scatter_lists" && (value == 0 || value == 1)) { options().scatter_lists = value; return 0; }
   if (n == "plan_reach" && value >= 1 && value <= 16) { options().plan_reach = value; return 0; }
+  if (n == "plan_fused" && (value == 0 || value == 1)) { options().plan_fused = value; return 0; }
   if (n == "scatter_lists_cap" && value >= 0) { options().scatter_lists_cap = value; return 0; }
   return MSDA_E_UNSUPPORTED;
 }

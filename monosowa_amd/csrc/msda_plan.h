@@ -78,9 +78,6 @@ struct HeadPlan {
 struct PlanGeom {
   int H[4], W[4], start[4];
   int S, M;
-  int win_n_ty, win_n_tx;                  // window tiling (host: choose_window_tiling)
-  int win_budget_rows;                     // LDS rows the windows of one item may take
-  int win_max_queries;                     // queries one item may hold (merged pairs)
   int default_halo;                        // bounds when a (head, level) has no valid sample: [-halo, halo - 1]
   int reach;                               // scatter: |d| <= reach at most (capacity of the candidate tables)
   int want_rows;                           // 1: also plan the row-tile scatter

@@ -21,9 +21,10 @@ class _Strides(ctypes.Structure):
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(_PATH):
-            raise RuntimeError("HIP extension %s is missing: run `python -m monosowa_amd.build`" % _PATH)
-        lib = ctypes.CDLL(_PATH)
+        path = os.environ.get("MONOSOWA_ATTN_LIB", _PATH)             # another BUILD of the same library (A/B measurements)
+        if not os.path.exists(path):
+            raise RuntimeError("HIP extension %s is missing: run `python -m monosowa_amd.build`" % path)
+        lib = ctypes.CDLL(path)
         P, I, F, U = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_ulonglong
         lib.mono_attn_forward_f32.restype = I
         lib.mono_attn_forward_f32.argtypes = [P] * 5 + [I] * 5 + [_Strides] * 4 + [F, F, U, P]

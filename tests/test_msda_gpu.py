@@ -201,11 +201,13 @@ def test_fused_strided_operator_at_the_kitti_pyramid_vs_c_oracle(B, check, offse
         assert (got_log - g_log[b:b + 1]).abs().max() <= 1e-4 * g_log[b].abs().max(), "grad_logits[%d]" % b
 
 
-@pytest.mark.parametrize("option,value", [("scatter_lists", 1), ("directional", 0)])
+@pytest.mark.parametrize("option,value", [("scatter_lists", 1), ("directional", 0), ("plan_fused", 0)])
 def test_saved_backward_alternative_scan_sources_compute_the_same_gradients(option, value):
     """The saved backward's two opt-in / fallback scan sources -- exact scan lists binned from the saved locations
     (msda_set_option("scatter_lists", 1): msda_bin.hip) and the isotropic host plan ("directional", 0) -- against the default
-    (geometric scan behind the device-side directional plan), offsets of 6.5 px so that window-outside and far points occur."""
+    (geometric scan behind the device-side directional plan, made by ONE fused launch), offsets of 6.5 px so that window-outside and
+    far points occur.  ("plan_fused", 0): the plan from the three separate kernels (larger statistics sample: the bounds may differ
+    by a pixel, the gradients may not)."""
     MSDA = _msda()
     from monosowa_amd import _lib
     B = 2
@@ -219,7 +221,7 @@ def test_saved_backward_alternative_scan_sources_compute_the_same_gradients(opti
     _, loc, attw = MSDA.ms_deform_attn_fused_forward_merged_save(v, s, i, proj, refp)
     gv_a, gp_a = MSDA.ms_deform_attn_fused_backward_merged_saved(v, s, i, loc, attw, refp, g)
     lib = _lib.load()
-    default = {"scatter_lists": 0, "directional": 1}[option]
+    default = {"scatter_lists": 0, "directional": 1, "plan_fused": 1}[option]
     assert lib.msda_set_option(option.encode(), value) == 0
     try:
         gv_b, gp_b = MSDA.ms_deform_attn_fused_backward_merged_saved(v, s, i, loc, attw, refp, g)

@@ -46,6 +46,10 @@ DEFINE_KERNEL(mul_lo, "v_mul_lo_u32 %0, %0, %1")
 DEFINE_KERNEL(mov, "v_mov_b32 %0, %1")
 DEFINE_KERNEL(cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
 DEFINE_KERNEL(cndmask_s, "v_cndmask_b32 %0, %0, %1, s[20:21]")
+DEFINE_KERNEL(cmp_cnd_vcc, "v_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc")
+DEFINE_KERNEL(cmp_cnd_sgpr, "v_cmp_gt_f32 s[20:21], %0, %1\n\tv_cndmask_b32 %0, %0, %2, s[20:21]")
+DEFINE_KERNEL(cnd_vcc_fma, "v_cndmask_b32 %0, %0, %1, vcc\n\tv_fma_f32 %0, %0, %1, %2")
+DEFINE_KERNEL(cnd_vcc_e64, "v_cndmask_b32_e64 %0, %0, %1, vcc")
 DEFINE_KERNEL(cmp, "v_cmp_gt_f32 vcc, %0, %1")
 DEFINE_KERNEL(cmp_s, "v_cmp_gt_f32 s[20:21], %0, %1")
 DEFINE_KERNEL(floor, "v_floor_f32 %0, %0")
@@ -175,7 +179,7 @@ int main(int argc, char **argv) {
   printf("device %s, %d CUs, nominal clock %.2f GHz\n", prop.name, prop.multiProcessorCount, clk_khz * 1e-6);
 #define C(NAME) {#NAME, k_##NAME, 16.0}
   Case cases[] = {C(fma), C(fmac), C(mul), C(add), C(max), C(addu), C(subu), C(xor_), C(xor_imm), C(and_), C(lshl), C(lshl_add), C(add3),
-                  C(mad24), C(mul_lo), C(mov), C(cndmask), C(cndmask_s), C(cmp), C(cmp_s), C(floor), C(cvt_i), C(cvt_f), C(exp), C(rcp),
+                  C(mad24), C(mul_lo), C(mov), C(cndmask), C(cndmask_s), {"cmp+cnd via vcc (2 instr)", k_cmp_cnd_vcc, 32.0}, {"cmp+cnd via sgpr (2 instr)", k_cmp_cnd_sgpr, 32.0}, {"cnd_vcc+fma (2 instr)", k_cnd_vcc_fma, 32.0}, C(cnd_vcc_e64), C(cmp), C(cmp_s), C(floor), C(cvt_i), C(cvt_f), C(exp), C(rcp),
                   C(mov_dpp_quad), C(mov_dpp_mirror), C(add_dpp_quad), C(add_dpp_shr), C(fmac_dpp_bcast), C(addu_dpp_bcast), C(perm), C(bfe),
                   C(and_or), C(xad), C(min_i), C(med3), C(readlane), C(s_add), C(s_mul), C(pk_fma), C(pk_mul), C(pk_add), C(pk_mov),
                   {"ds_read_b128", k_ds_read_b128, 16.0},
