@@ -74,6 +74,11 @@ const char *msda_strerror(int code);
  * computes the same function.  Returns 0, or MSDA_E_UNSUPPORTED for an unknown name / value. */
 int msda_set_option(const char *name, int value);
 
+/* A hash of the option table entries a plan made by msda_saved_plan_f32() depends on: a caller that keeps such a plan across other
+ * calls compares the stamp taken at plan time with the one at backward time and lets the backward plan for itself when they differ
+ * (msda_fused_backward_view_planned_f32 would otherwise run on tables laid out for another reach / scan source). */
+int msda_options_stamp(void);
+
 /* Diagnostics for tests: reads AND resets a device-side event counter of the current device (synchronises the device).
  * "scatter_overflow_rounds": extra bucket rounds of the self-attention backward's cell scatter (a cell received more points
  * from one batch of candidates than its bucket holds).  Returns 0, MSDA_E_UNSUPPORTED for an unknown name, or a hipError_t. */

@@ -341,7 +341,7 @@ def plan_saved_backward(value, spatial_shapes, level_start_index, loc):
         return None                                          # (MSDA_E_UNSUPPORTED: the backward plans for itself)
     ws.record_stream(side)                                   # freed early (no backward)? the allocator waits for the side stream
     loc.record_stream(side)
-    return ws, event
+    return ws, event, lib.msda_options_stamp()               # (the stamp: a plan is only good under the options it was made with)
 
 
 def _fused_backward_view(value, spatial_shapes, level_start_index, a, b, saved, reference_points, grad_output, value_mask, name, plan=None):
@@ -355,7 +355,8 @@ def _fused_backward_view(value, spatial_shapes, level_start_index, a, b, saved, 
     grad_value = torch.empty((B, S, M, D), dtype=value.dtype, device=value.device)         # always dense
     grad_proj = torch.empty((B, Lq, M * 48), dtype=value.dtype, device=value.device)
     ws_bytes = lib.msda_backward_workspace_bytes(B, S, M, D, L, Lq, P, 4)
-    planned = saved and plan is not None and plan[0].numel() == ws_bytes and plan[0].device == value.device
+    planned = saved and plan is not None and plan[0].numel() == ws_bytes and plan[0].device == value.device and \
+        (len(plan) < 3 or plan[2] == lib.msda_options_stamp())          # options changed since plan time: plan afresh
     ws = plan[0] if planned else torch.empty((ws_bytes,), dtype=torch.uint8, device=value.device)
     timer = LaunchTimer.active
     with on_device(value.device):
@@ -372,7 +373,9 @@ def _fused_backward_view(value, spatial_shapes, level_start_index, a, b, saved, 
                 reference_points.data_ptr(), reference_points.size(3), grad_output.data_ptr(), grad_value.data_ptr(),
                 grad_proj.data_ptr(), grad_proj.data_ptr() + M * 32 * 4, B, S, M, D, L, Lq, P, M * 48, M * 48, geom[0], geom[1],
                 ws.data_ptr(), ws_bytes, raw)
-        else:
+            if code == -3:                                    # MSDA_E_UNSUPPORTED: this call does not run on a directional plan after all
+                planned = False
+        if not planned:
             code = lib.msda_fused_backward_view_f32(
                 value.data_ptr(), ts, mask_ptr, spatial_shapes.data_ptr(), level_start_index.data_ptr(), a.data_ptr(), b.data_ptr(),
                 1 if saved else 0, reference_points.data_ptr(), reference_points.size(3), grad_output.data_ptr(), grad_value.data_ptr(),

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmonosowa_msda.so")
 
 # every symbol include/monosowa_msda.h declares
-SYMBOLS = ("msda_abi_version", "msda_strerror", "msda_set_option", "msda_debug_counter", "msda_backward_workspace_bytes",
+SYMBOLS = ("msda_abi_version", "msda_strerror", "msda_set_option", "msda_options_stamp", "msda_debug_counter", "msda_backward_workspace_bytes",
            "msda_forward_f32", "msda_forward_f64", "msda_backward_f32", "msda_backward_f64",
            "msda_fused_forward_f32", "msda_fused_backward_f32", "msda_fused_forward_strided_f32",
            "msda_fused_backward_strided_f32", "msda_fused_save_supported", "msda_fused_save_supported_view", "msda_fused_forward_save_f32", "msda_fused_forward_view_f32", "msda_fused_backward_view_f32", "msda_saved_plan_f32", "msda_fused_backward_view_planned_f32",
@@ -37,6 +37,8 @@ def load():
     lib.msda_strerror.argtypes = [I]
     lib.msda_set_option.restype = I
     lib.msda_set_option.argtypes = [ctypes.c_char_p, I]
+    lib.msda_options_stamp.restype = I
+    lib.msda_options_stamp.argtypes = []
     lib.msda_debug_counter.restype = I
     lib.msda_debug_counter.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_ulonglong)]
     lib.msda_backward_workspace_bytes.restype = Z

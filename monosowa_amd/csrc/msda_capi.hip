@@ -645,6 +645,17 @@ int msda_set_option(const char *name, int value) {
   return MSDA_E_UNSUPPORTED;
 }
 
+int msda_options_stamp(void) {
+  // everything a plan made by msda_saved_plan_f32 depends on besides the call's own arguments
+  const Options &o = options();
+  unsigned h = 2166136261u;
+  for (int v : {o.directional, o.scatter_lists, o.scatter_rows, o.scatter_reach, o.plan_reach, o.plan_fused, o.window, o.window_halo, o.gather}) {
+    h ^= (unsigned)v + 0x9E3779B9u;
+    h *= 16777619u;
+  }
+  return (int)(h & 0x7FFFFFFFu);
+}
+
 int msda_debug_counter(const char *name, unsigned long long *out) {
   if (!name || !out) return MSDA_E_NULLPTR;
   if (std::string(name) != "scatter_overflow_rounds") return MSDA_E_UNSUPPORTED;

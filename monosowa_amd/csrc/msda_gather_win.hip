@@ -33,6 +33,9 @@
 #ifndef MSDA_WIN_PK_FWD
 #define MSDA_WIN_PK_FWD 0        // forward row FMAs as v_pk_fma_f32
 #endif
+#ifndef MSDA_WIN_NT_SAVES
+#define MSDA_WIN_NT_SAVES 0      // 1: the saving forward writes locations / weights with non-temporal stores (A/B: see DESIGN 4.0)
+#endif
 #ifndef MSDA_WIN_SKIP
 #define MSDA_WIN_SKIP 0          // measurement builds only: 1 no fill, 2 no row reads (forward), 4 no output stores (forward), 8 no prefetch, 16 no saves
 #endif
@@ -373,8 +376,17 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
     if (!BWD && FUSED && SAVED && live && !(MSDA_WIN_SKIP & 16)) {        // hand the backward what was evaluated here (level-major)
       const long long plane = (long long)(it.b * M + it.m) * 4 * S * 4;
       const unsigned pl = q_u * 4u + saved_lane;
+#if MSDA_WIN_NT_SAVES
+      // (read again only by the backward, a whole decoder pass later: non-temporal, so that 251 MB of saves do not push the value
+      // windows' lines out of L2)
+      typedef float nt_v4 __attribute__((ext_vector_type(4)));
+      typedef float nt_v2 __attribute__((ext_vector_type(2)));
+      __builtin_nontemporal_store((nt_v4){l4.x, l4.y, l4.z, l4.w}, reinterpret_cast<nt_v4 *>(grad_loc + plane * 2 + pl * 2u));
+      __builtin_nontemporal_store((nt_v2){a2.x, a2.y}, reinterpret_cast<nt_v2 *>(grad_attw + plane + pl));
+#else
       st4(grad_loc + plane * 2 + pl * 2u, l4);
       *reinterpret_cast<float2 *>(grad_attw + plane + pl) = a2;
+#endif
     }
 
     MSDA_STAMP(4);

@@ -1470,3 +1470,13 @@ def test_saved_backward_from_a_plan_made_ahead_on_a_side_stream_equals_the_self_
         # grad_value: a cell's points are summed in the order their lanes drew bucket slots (and far points / shared coarse tiles
         # with atomics): equal up to the order of float additions, call to call
         assert (gv_a - gv_b).abs().max() <= 1e-5 * gv_b.abs().max()
+        # a plan is only good under the options it was made with: after msda_set_option the stale handle is ignored (its stamp no
+        # longer matches) and the backward plans for itself -- same gradients, no MSDA_E_UNSUPPORTED
+        from monosowa_amd import _lib
+        _lib.set_option("plan_reach", 6)
+        try:
+            gv_c, gp_c = M.ms_deform_attn_fused_backward_merged_saved(value, shapes, lsi, loc, attw, ref, go, mask, plan=plan)
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_option("plan_reach", 8)
+        assert torch.equal(gp_c, gp_b) and (gv_c - gv_b).abs().max() <= 1e-5 * gv_b.abs().max()
