@@ -33,6 +33,10 @@
 #ifndef MSDA_WIN_PK_FWD
 #define MSDA_WIN_PK_FWD 0        // forward row FMAs as v_pk_fma_f32
 #endif
+#ifndef MSDA_WIN_PARITY
+#define MSDA_WIN_PARITY 1        // 1: left / right corner reads ordered by LDS row parity (round 2: bank conflicts halved, time unchanged); 0: none
+                                 // of that per-point swap logic (A/B round 4: DESIGN 4.0)
+#endif
 #ifndef MSDA_WIN_NT_SAVES
 #define MSDA_WIN_NT_SAVES 0      // 1: the saving forward writes locations / weights with non-temporal stores (A/B: see DESIGN 4.0)
 #endif
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
       // 8 slots of its parity, and in every group exactly two lanes share a slot position (rot ^ s) -- lanes 16 apart.  The
       // left / right corners of a footprint are neighbouring rows (opposite parity): the lane with bit 4 clear reads the
       // even one first, its partner the odd one, so the two never meet (counters: every group took 2 cycles before).
-      {
+      if (MSDA_WIN_PARITY) {
         // (a point outside its window keeps its order: the fix-up pass pairs corners and weights by index)
         const bool sw_t = use && (((off[k2][0] >> 7) ^ (lane >> 4)) & 1) != 0, sw_b = use && (((off[k2][2] >> 7) ^ (lane >> 4)) & 1) != 0;
         const int o0 = off[k2][0], o1 = off[k2][1], o2 = off[k2][2], o3 = off[k2][3];
