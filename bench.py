@@ -168,7 +168,9 @@ def dataloader_leg(args, step, device, world, rank, resolution):
     from monosowa_amd.helpers.trainer_helper import stage_batch
     n_warm = 2                                           # worker start-up + first batches: untimed
     dcfg = {"type": "synthetic", "batch_size": args.batch, "train_split": "train", "test_split": "val", "resolution": resolution,
-            "num_samples": args.batch * (args.steps + n_warm), "seed_offset": rank}
+            # one dataset for the whole job: under torch.distributed build_dataloader shards it (DistributedSampler), every rank
+            # draws steps + n_warm batches of its own images
+            "num_samples": args.batch * (args.steps + n_warm) * world}
     loader, _ = build_dataloader(dcfg, workers=args.dataloader_workers, drop_last=True, test=False)
     it = iter(loader)
     for _ in range(n_warm):
@@ -525,7 +527,9 @@ def main():
     # the way the reference loop is fed (lib/helpers/dataloader_helper.py:21-34: 4 workers; trainer_helper.py:121-127: per-key
     # .to(device)).  Timed like the resident leg; `value` above stays the resident number.
     dataloader = None
-    if train and not args.no_dataloader_leg and resample is None and accum == 1:
+    # (N = 1 only, like the cpu_baseline leg: at N > 1 the line's job is the scaling curve, and 4 forked workers per rank next to RCCL
+    # add nothing to it)
+    if train and world == 1 and not args.no_dataloader_leg and resample is None and accum == 1:
         dataloader = dataloader_leg(args, step0, device, world, rank, (W, H))
         log("dataloader leg: %d steps in %.3f s" % (args.steps, dataloader["ms_per_step"] * args.steps * 1e-3))
 

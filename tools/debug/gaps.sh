@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/gaps
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --preheat-seconds 1 --no-cpu-baseline > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --preheat-seconds 1 --no-cpu-baseline --no-inference-leg --no-dataloader-leg > $OUT/bench.log 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/t/*/*kernel_trace.csv")[0]

@@ -2,9 +2,9 @@
 # MFMA utilisation of the dense kernels (GEMM / conv) in a train step: rocprofv3 --pmc on a short bench run,
 # after a warm run (MIOpen find-db).  bash tools/pmc_mfma.sh gpurun_out/pmc_mfma
 OUT=$(realpath -m "${1:-gpurun_out/pmc_mfma}"); ROOT=$(pwd); mkdir -p "$OUT"
-python bench.py --steps 2 --warmup 2 --no-cpu-baseline > /dev/null 2> "$OUT/warm.err"
+python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-inference-leg --no-dataloader-leg > /dev/null 2> "$OUT/warm.err"
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d "$OUT/run" -- python "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/run.log" 2>&1 || tail -3 "$OUT/run.log"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d "$OUT/run" -- python "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-inference-leg --no-dataloader-leg > "$OUT/run.log" 2>&1 || tail -3 "$OUT/run.log"
 python - "$OUT" <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict
