@@ -806,38 +806,44 @@ def gen_kitti_dataset():
 
 
 def _cv2_color_shim():
-    """cv2.cvtColor(float32 image, COLOR_BGR2HSV | COLOR_HSV2BGR) for pd.py:159-165, restated from OpenCV's DOCUMENTED float
-    definition (imgproc "Color conversions", RGB <-> HSV: V = max, S = (V - min) / V or 0, H = 60 (G - B) / (V - min) | 120 + 60
-    (B - R) / (V - min) | 240 + 60 (R - G) / (V - min), + 360 if negative; inverse by hue sector) -- OpenCV itself is absent
-    from this image, so the photometric fixture is pinned to the published formula, not to OpenCV's binaries."""
+    """cv2.cvtColor(float32 image, COLOR_BGR2HSV | COLOR_HSV2BGR) for pd.py:159-165.  OpenCV itself is absent from this image, so the
+    shim restates OpenCV's float KERNEL as its source reads (imgproc color_hsv: RGB2HSV_f -- S = diff / (|V| + FLT_EPSILON), H scale
+    (float)(60. / (diff + FLT_EPSILON)) -- and HSV2RGB_f: H * (6 / 360) wrapped into [0, 6), sector table), not the idealised formula
+    of its documentation: the photometric fixture is pinned to OpenCV's published source, not to its binaries (written here
+    independently of monosowa_amd/photometric.py, from the same source text)."""
     cv2 = sys.modules["cv2"]
     cv2.COLOR_BGR2HSV, cv2.COLOR_HSV2BGR = 40, 54
+    eps = np.float32(np.finfo(np.float32).eps)
 
     def cvt(img, code):
         img = np.asarray(img, dtype=np.float32)
         f = np.float32
         if code == cv2.COLOR_BGR2HSV:
+            out = np.empty_like(img)
             b, g, r = img[..., 0], img[..., 1], img[..., 2]
-            v = np.maximum(np.maximum(b, g), r)
-            d = v - np.minimum(np.minimum(b, g), r)
-            s = np.where(v != 0, d / np.where(v != 0, v, f(1)), f(0)).astype(np.float32)
-            k = (f(60) / np.where(d != 0, d, f(1))).astype(np.float32)
-            h = np.where(v == r, (g - b) * k, np.where(v == g, f(120) + (b - r) * k, f(240) + (r - g) * k))
-            h = np.where(d != 0, h, f(0)).astype(np.float32)
-            h = np.where(h < 0, h + f(360), h).astype(np.float32)
-            return np.stack([h, s, v], -1)
+            v = np.maximum(r, np.maximum(g, b))
+            vmin = np.minimum(r, np.minimum(g, b))
+            diff = (v - vmin).astype(np.float32)
+            out[..., 1] = diff / (np.abs(v) + eps)
+            scale = (np.float64(60.0) / (diff + eps).astype(np.float64)).astype(np.float32)
+            is_r, is_g = v == r, (v == g) & ~(v == r)
+            h = np.where(is_r, (g - b) * scale, np.where(is_g, (b - r) * scale + f(120), (r - g) * scale + f(240))).astype(np.float32)
+            out[..., 0] = np.where(h < 0, h + f(360), h)
+            out[..., 2] = v
+            return out
         assert code == cv2.COLOR_HSV2BGR
         h, s, v = img[..., 0], img[..., 1], img[..., 2]
-        hh = (h / f(60)).astype(np.float32)
-        hh = hh - f(6) * np.floor(hh / f(6))
-        sec = np.floor(hh)
-        fr = (hh - sec).astype(np.float32)
-        sec = sec.astype(np.int64) % 6
-        p_, q_, t_ = v * (f(1) - s), v * (f(1) - s * fr), v * (f(1) - s * (f(1) - fr))
-        r = np.choose(sec, [v, q_, p_, p_, t_, v])
-        g = np.choose(sec, [t_, v, v, q_, p_, p_])
-        b = np.choose(sec, [p_, p_, t_, v, v, q_])
-        return np.stack([b, g, r], -1).astype(np.float32)
+        hh = (h * f(6.0 / 360.0)).astype(np.float32)
+        hh = (hh - f(6) * np.floor(hh / f(6))).astype(np.float32)
+        hh = np.where(hh >= 6, hh - f(6), hh).astype(np.float32)
+        sec = np.floor(hh).astype(np.int64)
+        fr = (hh - sec.astype(np.float32)).astype(np.float32)
+        sec = np.where((sec < 0) | (sec > 5), 0, sec)
+        tab = np.stack([v, v * (f(1) - s), v * (f(1) - s * fr), v * (f(1) - s * (f(1) - fr))], 0).astype(np.float32)
+        sector_data = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])      # -> (b, g, r)
+        idx = sector_data[sec]                                                                          # [..., 3]
+        out = np.take_along_axis(tab, np.moveaxis(idx, -1, 0), 0)                                       # [3, ...]
+        return np.moveaxis(out, 0, -1).astype(np.float32)
     cv2.cvtColor = cvt
 
 
