@@ -463,3 +463,30 @@ def test_resnet_body_matches_the_published_architecture():
         width = 64 * 2 ** 3 * 4
         assert sd["layer4.%d.conv3.weight" % (blocks[3] - 1)].shape[0] == width == 2048
         assert not any(k.endswith("num_batches_tracked") for k in sd)       # FrozenBatchNorm2d drops it (backbone.py:44-52)
+
+
+def test_dataloader_fed_batches_keep_the_loop_contract():
+    """bench.py's DataLoader-fed leg and Trainer.train_one_epoch share ``build_dataloader`` + ``stage_batch`` (reference:
+    lib/helpers/dataloader_helper.py:21-34, trainer_helper.py:121-127): a collated batch keeps the (inputs, calibs, targets, info)
+    contract, drop_last / test=False behave, and the object mask stays on the host next to its staged copy so that
+    ``prepare_targets`` needs no device synchronisation."""
+    from monosowa_amd.helpers.dataloader_helper import build_dataloader
+    from monosowa_amd.helpers.trainer_helper import stage_batch
+    from monosowa_amd.synthetic import prepare_targets
+    cfg = {"type": "synthetic", "batch_size": 3, "train_split": "train", "test_split": "val", "resolution": (64, 32), "num_samples": 8}
+    loader, test_loader = build_dataloader(cfg, workers=0, drop_last=True, test=False)
+    assert test_loader is None and len(loader) == 2                       # 8 samples, batches of 3, the ragged last one dropped
+    seen = 0
+    for raw in loader:
+        inputs, calibs, targets, info = stage_batch(raw, torch.device("cpu"))
+        assert tuple(inputs.shape) == (3, 3, 32, 64) and inputs.dtype == torch.float32
+        assert tuple(calibs.shape) == (3, 3, 4) and tuple(targets["boxes_3d"].shape) == (3, 50, 6)
+        assert targets["labels"].dtype == torch.int8 and targets["heading_bin"].dtype == torch.int64 and targets["mask_2d"].dtype == torch.bool
+        host = getattr(targets["mask_2d"], "_host_mask", None)
+        assert host is not None and (host == targets["mask_2d"].numpy()).all()
+        tl = prepare_targets(targets, 3)
+        assert [t["boxes"].shape[0] for t in tl] == host.sum(1).tolist()
+        seen += 1
+    assert seen == 2
+    both = build_dataloader(cfg, workers=0)
+    assert both[1] is not None and len(both[0]) == 3                      # the reference's behaviour: nothing dropped, a test loader
