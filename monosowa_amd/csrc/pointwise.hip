@@ -321,6 +321,43 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ g
   }
 }
 
+// Column sums of a SHORT matrix in one launch (round 4): the decoder's bias gradients are [8800, 256..512] -- 2 - 4 MB, where the two-stage
+// form above spends its time in two launches' fixed costs (8 + 5.8 us for 2.25 MB).  Here a 16-wave workgroup owns a strip of four float4
+// columns (64 bytes of every row) over ALL rows: thread = (row lane of 256, column of 4), 8 rows in flight per thread, then the 256 row
+// lanes are folded by wave shuffles and one LDS exchange -- no partial rows, no second launch.  C / 16 workgroups; the strips of one row
+// share its 128-byte lines through L2 (the matrix is read from HBM once).
+#ifndef MONO_COLSUM_STRIP_ROWS
+#define MONO_COLSUM_STRIP_ROWS 12288
+#endif
+constexpr long long kColsumStripRows = MONO_COLSUM_STRIP_ROWS;        // up to here mono_colsum_f32 takes the one-launch strip kernel
+__global__ __launch_bounds__(1024) void colsum_strip_kernel(const float *__restrict__ g, float *__restrict__ out, long long rows, int C) {
+  __shared__ float4 red[16][4];
+  const int col = threadIdx.x & 3, rl = threadIdx.x >> 2, wave = threadIdx.x >> 6;
+  const int c4 = blockIdx.x * 4 + col;                      // this thread's float4 column
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 * 4 < C) {
+    const float *base = g + (long long)c4 * 4;
+#pragma unroll 8
+    for (long long r = rl; r < rows; r += 256) {
+      const float4 v = *reinterpret_cast<const float4 *>(base + r * C);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  // fold the wave's 16 row lanes (lanes with equal `col`: lane ^ 4, 8, 16, 32)
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) {
+    acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o); acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
+  }
+  if ((threadIdx.x & 63) < 4) red[wave][col] = acc;
+  __syncthreads();
+  if (threadIdx.x < 4 && c4 * 4 < C) {
+    float4 a = red[0][col];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) { const float4 b = red[w][col]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    *reinterpret_cast<float4 *>(out + c4 * 4) = a;
+  }
+}
+
 // Column sums for ANY C <= 1024 (81 depth bins, 3 classes ...): thread = column (+ 256, + 512, ...), a workgroup walks its rows;
 // the partial rows are added by partial_sum_scalar_kernel.  (ATen's reduction takes 308 us for [30720, 81].)
 __global__ __launch_bounds__(256) void colsum_scalar_kernel(const float *__restrict__ g, float *__restrict__ partials, long long rows,
@@ -616,6 +653,12 @@ int mono_colsum_f32(const float *g, float *out, float *partials, long long rows,
   if (!g || !out || !partials) return -1;
   if (rows <= 0 || C <= 0 || C % 4 || C > 1024) return -2;
   hipStream_t st = (hipStream_t)stream_;
+  // short and not too wide (measured, round 4: [8800, 256] 7.6 against 10.3 us, [8800, 384] 8.0 / 12.4, [2200, 256] 8.3 / 11.0; [8800, 512]
+  // 18.8 / 16.8 and [16384, 256] 11.4 / 11.4 stay on the two stages): one launch, no partial rows (`partials` unused)
+  if (rows <= mono::kColsumStripRows && C <= 384) {
+    mono::colsum_strip_kernel<<<(C / 4 + 3) / 4, 1024, 0, st>>>(g, out, rows, C);
+    return (int)hipGetLastError();
+  }
   const int grid = mono_reduce_blocks(rows);
   const int rpb = (int)((rows + grid - 1) / grid + 63) / 64 * 64;
   if (C <= 256) mono::colsum_kernel<1><<<grid, 256, 0, st>>>(g, partials, rows, C, rpb, rows, 0);

@@ -19,9 +19,10 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(_PATH):
-            raise RuntimeError("HIP extension %s is missing: run `python -m monosowa_amd.build`" % _PATH)
-        lib = ctypes.CDLL(_PATH)
+        path = os.environ.get("MONOSOWA_POINTWISE_LIB", _PATH)        # another BUILD of the same library (A/B measurements)
+        if not os.path.exists(path):
+            raise RuntimeError("HIP extension %s is missing: run `python -m monosowa_amd.build`" % path)
+        lib = ctypes.CDLL(path)
         P, I, LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
         lib.mono_bias_act_f32.restype = I
         lib.mono_bias_act_f32.argtypes = [P, P, P, LL, I, I, P]
