@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 9
+#define MSDA_ABI_VERSION 10
 
 #define MSDA_E_NULLPTR (-1)   /* a required pointer is NULL                        */
 #define MSDA_E_SHAPE (-2)     /* a dimension is <= 0 or exceeds the indexing range */

@@ -14,7 +14,7 @@ SYMBOLS = ("msda_abi_version", "msda_strerror", "msda_set_option", "msda_options
            "msda_fused_backward_saved_f32")
 
 _lib = None
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class MSDALibraryError(RuntimeError):
