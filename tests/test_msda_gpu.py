@@ -947,31 +947,47 @@ def test_attention_matches_fp64_softmax_attention(B, H, Lq, Lk):
         assert (a.double() - b).abs().max() <= 1e-5 * max(b.abs().max().item(), 1e-3), name
 
 
-def test_attention_dropout_uses_one_mask_forward_and_backward():
+@pytest.mark.parametrize("masked", [False, True], ids=["nomask", "keypad"])
+def test_attention_dropout_uses_one_mask_forward_and_backward(masked):
     """The dropped probabilities are recovered with one-hot V; the kernel gradients must equal float64 autograd through
-    exactly that mask, the kept fraction must match p, and a different seed must give a different mask."""
+    exactly that mask, the kept fraction must match p, and a different seed must give a different mask.  With a key padding
+    mask (the depth-aware decoder's cross attention over the padded image memory) the padded keys carry no probability and the
+    dropout mask is the one the unmasked kernels draw."""
     import math
     from monosowa_amd import flash_attn as FA
     torch.manual_seed(1)
     B, H, Lq, Lk, p, seed = 2, 3, 70, 64, 0.3, 99
     q, k, v, go = _heads(Lq, B, H), _heads(Lk, B, H), _heads(Lk, B, H), _heads(Lq, B, H)
+    kpm = None
+    if masked:
+        kpm = torch.zeros(B, Lk, dtype=torch.bool, device="cuda")
+        kpm[0, 50:] = True
+        kpm[1, ::7] = True
     scale = 1 / math.sqrt(32)
     eye = torch.eye(64, device="cuda")
-    recover = lambda sd: torch.cat([FA.forward(q, k, eye[:, i * 32:(i + 1) * 32].expand(B, H, 64, 32).contiguous(), scale, p, sd)[0]
-                                    for i in range(2)], -1)
+    recover = lambda sd: torch.cat([FA.forward(q, k, eye[:, i * 32:(i + 1) * 32].expand(B, H, 64, 32).contiguous(), scale, p, sd,
+                                               key_padding_mask=kpm)[0] for i in range(2)], -1)
     pd = recover(seed)
+    live = torch.ones(B, 1, 1, Lk, device="cuda", dtype=torch.bool) if kpm is None else ~kpm[:, None, None, :]
+    assert (pd[~live.expand_as(pd)] == 0).all(), "padded keys must carry no probability"
     mask = (pd != 0).double()
-    assert abs(mask.mean().item() - (1 - p)) < 0.02
+    kept = mask[live.expand_as(mask)].mean().item()
+    assert abs(kept - (1 - p)) < 0.02
     assert not torch.equal(recover(seed + 1) != 0, pd != 0)
     qd, kd, vd = (t.detach().double().requires_grad_(True) for t in (q, k, v))
     keep_scale = 65536.0 / (65536.0 - round(p * 65536))
-    pr = torch.softmax((qd @ kd.transpose(-1, -2)) * scale, -1) * mask * keep_scale
+    logits = (qd @ kd.transpose(-1, -2)) * scale
+    if kpm is not None:
+        logits = logits.masked_fill(~live, float("-inf"))
+    pr = torch.softmax(logits, -1) * mask * keep_scale
     assert (pd.double() - pr).abs().max() < 1e-6
     (pr @ vd).backward(go.double())
     qg, kg, vg = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
-    FA.attention(qg, kg, vg, dropout_p=p, seed=seed).backward(go)
+    FA.attention(qg, kg, vg, dropout_p=p, seed=seed, key_padding_mask=kpm).backward(go)
     for name, a, b in (("dq", qg.grad, qd.grad), ("dk", kg.grad, kd.grad), ("dv", vg.grad, vd.grad)):
         assert (a.double() - b).abs().max() <= 1e-5 * b.abs().max(), name
+    if kpm is not None:
+        assert (kg.grad[kpm[:, None, :, None].expand_as(kg.grad)] == 0).all() and (vg.grad[kpm[:, None, :, None].expand_as(vg.grad)] == 0).all()
 
 
 @pytest.mark.parametrize("same_qk", [True, False, None])
