@@ -125,9 +125,10 @@ __global__ __launch_bounds__(1024) void k_rowmix(float *out, float a, float b) {
   float acc[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) acc[i] = 0.f;
-  // lane -> a row of its own; rotation by lane so that the XOR form is conflict-free; the immediate form reads slot k of 64 rows at
+  // lane -> a row of its own; rotation by lane PAIR (row parity = lane parity picks the bank half, the rotation the slot: the 16 lanes
+  // of an LDS group land on 16 different bank slots) so that the XOR form is conflict-free; the immediate form reads slot k of 64 rows at
   // a pitch of 144 bytes (conflict-free for consecutive rows)
-  unsigned o = XOR ? (unsigned)(size_t)reinterpret_cast<char *>(buf) + (threadIdx.x & 63) * 128 + (threadIdx.x & 7) * 16
+  unsigned o = XOR ? (unsigned)(size_t)reinterpret_cast<char *>(buf) + (threadIdx.x & 63) * 128 + ((threadIdx.x >> 1) & 7) * 16
                    : (unsigned)(size_t)reinterpret_cast<char *>(buf) + (threadIdx.x & 63) * 144;
   float w = a;
 #pragma unroll 1
