@@ -170,3 +170,44 @@ def test_exact_scan_lists_with_a_forced_small_capacity_vs_c_oracle():
     B = 2
     data = _inputs(KITTI, B, 311, lambda rng, shp: rng.uniform(-4, 4, shp))
     _run_saved_pair_vs_oracle(KITTI, *data, check=range(B), set_options=(("scatter_lists", 1, 0), ("scatter_lists_cap", 64, 0)))
+
+
+@pytest.mark.parametrize("levels,B", [(KITTI, 16), (CONFIG4, 16), (CONFIG5, 4)], ids=["config2-B16", "config4-B16", "config5-B4"])
+def test_fused_saved_pair_full_size_properties(levels, B):
+    """The training pair at the batch sizes bench.py runs (BASELINE configs 2, 4, 5), where the C oracle would take minutes: properties
+    that do not depend on the size.  (1) the forward is linear in value; (2) <grad_out, J v> == <J^T grad_out, v>: grad_value is the
+    adjoint of the forward's value path (sums in float64); (3) the logits' gradient against a central difference of <grad_out, out>
+    along a random direction (the forward is smooth in the logits; the offsets' kinks at pixel borders are left to the oracle tests)."""
+    MSDA = _msda()
+    gen = torch.Generator(device="cuda").manual_seed(1000 + B + levels[0][0])
+    S = sum(h * w for h, w in levels)
+    shapes = np.array(levels, dtype=np.int64)
+    lsi = O.level_start_index(shapes)
+    s, i = _dev(shapes), _dev(lsi)
+    MSDA.attach_host_geometry(s, i, [tuple(x) for x in levels], lsi.tolist())
+    rnd = lambda *shape: torch.randn(*shape, device="cuda", generator=gen)
+    offsets = (torch.rand(B, S, M * 32, device="cuda", generator=gen) * 8 - 4)
+    logits = rnd(B, S, M * 16)
+    refp = _dev(np.broadcast_to(_pixel_centres(levels)[None, :, None, :], (B, S, 4, 2)).copy())
+    v1, v2, go = rnd(B, S, M, D), rnd(B, S, M, D), rnd(B, S, M * D)
+    assert MSDA.fused_save_supported(v1, s, i, S)
+    proj = torch.cat([offsets, logits], -1).contiguous()
+    fwd = lambda v, pj: MSDA.ms_deform_attn_fused_forward_merged_save(v, s, i, pj, refp)
+    o1, loc, attw = fwd(v1, proj)
+    o2 = fwd(v2, proj)[0]
+    o12 = fwd(v1 + 2 * v2, proj)[0]
+    assert (o12 - (o1 + 2 * o2)).abs().max() <= 1e-4 * o12.abs().max(), "linearity in value"
+    gv, gproj = MSDA.ms_deform_attn_fused_backward_merged_saved(v1, s, i, loc, attw, refp, go)
+    lhs = (go.double() * o1.reshape(B, S, M * D).double()).sum()
+    rhs = (gv.double() * v1.double()).sum()
+    assert abs(lhs - rhs) <= 1e-6 * abs(lhs), "adjoint identity of the value path: %r vs %r" % (lhs.item(), rhs.item())
+    direction = rnd(B, S, M * 16)
+    eps = 1e-2
+    dot = lambda pj: (go.double() * fwd(v1, pj)[0].reshape(B, S, M * D).double()).sum()
+    plus = dot(torch.cat([offsets, logits + eps * direction], -1).contiguous())
+    minus = dot(torch.cat([offsets, logits - eps * direction], -1).contiguous())
+    numeric = (plus - minus) / (2 * eps)
+    analytic = (gproj[:, :, M * 32:].double() * direction.double()).sum()
+    scale = (gproj[:, :, M * 32:].double().abs() * direction.double().abs()).sum()        # the size of the terms that cancel in `analytic`
+    print("adjoint rel %.2e; logit gradient: |numeric - analytic| / scale = %.2e" % (abs(lhs - rhs) / abs(lhs), abs(numeric - analytic) / scale))
+    assert abs(numeric - analytic) <= 1e-6 * scale, "logit gradient vs central difference: %r vs %r (scale %r)" % (numeric.item(), analytic.item(), scale.item())
