@@ -1083,6 +1083,24 @@ def test_masked_attention_core_matches_fp64_and_zeroes_the_padded_keys_gradients
     assert (k.grad[dead] == 0).all() and (v.grad[dead] == 0).all()
 
 
+def test_masked_attention_with_every_key_of_one_image_padded_is_nan_there_like_torch_and_exact_elsewhere():
+    """A batch element whose keys are ALL padded has no softmax (torch: NaN rows, F.multi_head_attention_forward's masked_fill(-inf) ->
+    softmax); the kernels say the same instead of inventing a value, and the other batch elements do not notice."""
+    from monosowa_amd import flash_attn as FA
+    torch.manual_seed(8)
+    B, H, Lq, Lk = 3, 8, 70, 130
+    q, k, v = (torch.randn(B, H, L, 32, device="cuda") for L in (Lq, Lk, Lk))
+    mask = torch.zeros(B, Lk, dtype=torch.bool, device="cuda")
+    mask[1] = True
+    mask[2, 100:] = True
+    out = FA.attention(q, k, v, key_padding_mask=mask)
+    s = (q.double() @ k.double().transpose(-1, -2)) / 32 ** 0.5
+    ref = torch.softmax(s.masked_fill(mask[:, None, None, :], float("-inf")), -1) @ v.double()
+    assert torch.isnan(ref[1]).all() and torch.isnan(out[1]).all()
+    for b in (0, 2):
+        assert (out[b].double() - ref[b]).abs().max() <= 1e-5 * ref[b].abs().max()
+
+
 def test_fused_adamw_matches_the_foreach_formulation():
     """mono_adamw_step_f32 (one launch for all parameters) against the foreach evaluation of the same update
     (itself bit-identical to the reference on the CPU, tests/test_helpers.py), over several steps, with odd sizes,
