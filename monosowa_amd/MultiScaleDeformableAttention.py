@@ -107,6 +107,8 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     _assert(sampling_loc.dtype == value.dtype and attn_weight.dtype == value.dtype, "dtype mismatch")
     lib = _lib.load()
     out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    if Lq == 0:        # the reference returns its (empty) at::zeros output: its launch of zero blocks fails and is only printed (cuh:948-952)
+        return out
     fn = lib.msda_forward_f32 if value.dtype == torch.float32 else lib.msda_forward_f64
     if host_geom is None:      # only a pre-attached copy is used here: the forward never synchronises for it
         host_geom = getattr(spatial_shapes, "_msda_host_geometry", None) or (None, None)
@@ -157,6 +159,8 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     B, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, attn_weight)
     _assert(grad_output.numel() == B * Lq * M * D and grad_output.dtype == value.dtype, "grad_output shape/dtype mismatch")
     lib = _lib.load()
+    if Lq == 0:        # no query: nothing is added to the reference's zero-initialised gradients (cu:121-123)
+        return [torch.zeros_like(value), torch.zeros_like(sampling_loc), torch.zeros_like(attn_weight)]
     grad_value = torch.empty_like(value)
     grad_loc = torch.empty_like(sampling_loc)
     grad_w = torch.empty_like(attn_weight)

@@ -432,6 +432,12 @@ def test_preconditions_on_gpu():
         MSDA.ms_deform_attn_forward(v, shapes.cpu(), lsi, loc, w, 64)
     out = MSDA.ms_deform_attn_forward(v, shapes, lsi, loc, w, 3)
     assert out.shape == (3, 1, 4) and not out.any()
+    # no queries at all: the reference hands back its empty output / untouched zero gradients (cu:54, 121-123)
+    loc0, w0 = torch.zeros(3, 0, 1, 1, 1, 2).cuda(), torch.zeros(3, 0, 1, 1, 1).cuda()
+    out = MSDA.ms_deform_attn_forward(v, shapes, lsi, loc0, w0, 3)
+    assert out.shape == (3, 0, 4)
+    gv, gl, gw = MSDA.ms_deform_attn_backward(torch.ones_like(v), shapes, lsi, loc0, w0, torch.zeros(3, 0, 4).cuda(), 3)
+    assert gv.shape == v.shape and not gv.any() and gl.shape == loc0.shape and gw.shape == w0.shape
 
 
 def test_all_points_outside_and_nan_locations():
