@@ -83,9 +83,16 @@ for it in range(2):                            # second iteration: bucket views 
     wa = dict(plain.named_parameters()); wb = dict(wrapped_core.named_parameters()); wc = dict(twin.named_parameters())
     dw = max((wa[n] - wb[n]).abs().max().item() for n in ga)
     dw_noise = max((wa[n] - wc[n]).abs().max().item() for n in ga)
-    # Adam's first steps move every weight by ~lr (2e-4) whatever the gradient's size: sign flips of noise-level
-    # gradients are the bound, measured by the unwrapped twin
-    assert dw <= 1e-6 + 3 * dw_noise, (dw, dw_noise)
+    # Adam's first steps move every weight by ~lr (2e-4) whatever the gradient's size: ONE noise-level gradient entry that changes
+    # sign between two runs puts 2 lr per step between their weights -- and whether the unwrapped twin happens to show such a flip in
+    # the same run is chance (a run with dw = 4.0e-4 = 2 lr against a twin at 6.8e-5 failed the former `dw <= 3 dw_noise`).  The
+    # largest deviation is therefore bounded by the flips Adam allows; that DDP loses no update is the job of the L2 check below:
+    # flips are a handful of entries, a tensor that missed its update is off by lr in every entry.
+    lr = opt_a.param_groups[0]["lr"]
+    assert dw <= 1e-6 + max(3 * dw_noise, 2.05 * lr * (it + 1)), (dw, dw_noise, lr)
+    n_w = sum(wa[n].numel() for n in ga)
+    wdist = lambda x, y: (torch.cat([(x[n] - y[n]).reshape(-1) for n in ga]).norm() / (lr * n_w ** 0.5)).item()
+    assert wdist(wa, wb) <= 1e-3 + 3 * wdist(wa, wc), (wdist(wa, wb), wdist(wa, wc))
     print("iteration %d: loss %.5f, gradient deviation ddp %.2e / twin %.2e, weight deviation ddp %.2e / twin %.2e"
           % (it, la.item(), worst, noise, dw, dw_noise))
 torch.cuda.synchronize()
