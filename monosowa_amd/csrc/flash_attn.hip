@@ -33,7 +33,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 #ifndef ATTN_SKIP
 #define ATTN_SKIP 0             // measurement builds only (bits, backward kernels): 1 no exp2 of the recomputed scores, 2 no dropout hash,
-                                // 4 no second-stage MFMAs (dQ / dK, dV), 8 no recomputation MFMAs (S, dP), 16 no LDS reads of the A operands
+                                // 4 no second-stage MFMAs (dQ / dK, dV), 8 no recomputation MFMAs (S, dP), 16 no LDS reads of the A operands,
+                                // 32 the hash's input word in place of the hash (NOT a usable mask: prices a mask of ~4 instructions per key pair)
 #endif
 constexpr int kBlockQ = 128;     // queries per workgroup (4 waves x 32)
 constexpr int kTileK = 64;       // keys per LDS tile
@@ -64,6 +65,7 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
 }
 // 32 random bits for the key pair (2 kp, 2 kp + 1) of query q; element (q, key) uses half key & 1.
 __device__ __forceinline__ unsigned drop_bits(unsigned head_seed, unsigned q, unsigned kp) {
+  if (ATTN_SKIP & 32) return head_seed + q * 0x9E3779B1u + kp * 0x85EBCA77u;      // measurement build: what a mask that costs ~4 instructions per pair would buy
   return mix32(head_seed + q * 0x9E3779B1u + kp * 0x85EBCA77u);
 }
 __device__ __forceinline__ unsigned head_seed_of(const Args &a, unsigned bh) {
