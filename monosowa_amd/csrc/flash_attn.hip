@@ -57,7 +57,15 @@ struct Args {
   float drop_scale;              // 1 / (1 - p)
   unsigned seed_lo, seed_hi;
   const unsigned char *kmask;    // MASK kernels: key padding mask [B, Lk], non-zero = the key takes no part (its score is -inf)
+  unsigned *keep;                // dropout keep bits (optional): written by the forward, read by the backward kernels instead of
+                                 // re-hashing.  One word per (forward lane, key tile): [B*H][ceil(Lq/128)][ceil(Lk/64)][256 threads];
+                                 // bit 16 * half + v = the lane's score register v of the tile's 32-key half (key = 64 kt + 32 half +
+                                 // 4 (lane >> 5) + 8 (v >> 2) + (v & 3))
 };
+__device__ __forceinline__ long long keep_index(const Args &a, int bh, int q_block, int k_tile, int slot) {
+  const int n_qb = (a.Lq + 127) >> 7, n_kt = (a.Lk + 63) >> 6;
+  return (((long long)bh * n_qb + q_block) * n_kt + k_tile) * 256 + slot;
+}
 
 __device__ __forceinline__ unsigned mix32(unsigned x) {
   x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
@@ -80,7 +88,7 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __bu
 // depth_predictor/transformer.py:57-60: key_padding_mask -> -inf before the softmax, torch.nn.functional.multi_head_attention_forward).
 // The tile's keys carry an additive bias in LDS, 0 or -inf (also for the keys past Lk of a ragged last tile): one ds_read_b128 per
 // four scores.  A query whose keys are ALL masked comes out as NaN, as it does from torch's softmax.
-template <bool DROP, bool MASK = false>
+template <bool DROP, bool MASK = false, bool BITS = false>       // BITS (with DROP): also store the keep bits (Args::keep)
 __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void fwd_kernel(const Args a) {
   __shared__ float Ks[2][kTileK * kKStride];
   __shared__ float Vs[2][kTileK * kVStride];
@@ -178,18 +186,24 @@ __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void fwd_kernel(const Args a) 
 #pragma unroll
     for (int v = 0; v < 16; ++v) o[v] *= alpha;
     if (DROP) {
+      unsigned word = 0;                                  // this lane's 32 keep bits of the tile (Args::keep)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
           const unsigned kp = (unsigned)(key0 + 8 * g + 2 * pr) >> 1;
           const unsigned b0 = drop_bits(hseed, (unsigned)q, kp), b1 = drop_bits(hseed, (unsigned)q, kp + 16u);
-          s0[4 * g + 2 * pr] = (b0 & 0xFFFFu) >= a.drop_thr16 ? s0[4 * g + 2 * pr] * a.drop_scale : 0.f;
-          s0[4 * g + 2 * pr + 1] = (b0 >> 16) >= a.drop_thr16 ? s0[4 * g + 2 * pr + 1] * a.drop_scale : 0.f;
-          s1[4 * g + 2 * pr] = (b1 & 0xFFFFu) >= a.drop_thr16 ? s1[4 * g + 2 * pr] * a.drop_scale : 0.f;
-          s1[4 * g + 2 * pr + 1] = (b1 >> 16) >= a.drop_thr16 ? s1[4 * g + 2 * pr + 1] * a.drop_scale : 0.f;
+          const int v = 4 * g + 2 * pr;
+          const bool k00 = (b0 & 0xFFFFu) >= a.drop_thr16, k01 = (b0 >> 16) >= a.drop_thr16;
+          const bool k10 = (b1 & 0xFFFFu) >= a.drop_thr16, k11 = (b1 >> 16) >= a.drop_thr16;
+          s0[v] = k00 ? s0[v] * a.drop_scale : 0.f;
+          s0[v + 1] = k01 ? s0[v + 1] * a.drop_scale : 0.f;
+          s1[v] = k10 ? s1[v] * a.drop_scale : 0.f;
+          s1[v + 1] = k11 ? s1[v + 1] * a.drop_scale : 0.f;
+          if (BITS) word |= (k00 ? 1u << v : 0u) | (k01 ? 2u << v : 0u) | (k10 ? 0x10000u << v : 0u) | (k11 ? 0x20000u << v : 0u);
         }
       }
+      if (BITS) a.keep[keep_index(a, bh, blockIdx.x, kt, threadIdx.x)] = word;
     }
     // O^T += V^T P^T
     const float *v0 = &Vs[buf][(4 * h) * kVStride + r], *v1 = v0 + 32 * kVStride;
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(256) void delta_kernel(const Args a, int B) {
 
 // dQ: same decomposition as the forward (a lane owns one query); per 32-key half: S^T (recomputed), dP^T = V dO^T,
 // dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T -- 48 MFMAs.
-template <bool DROP, bool MASK = false>
+template <bool DROP, bool MASK = false, bool BITS = false>       // BITS (with DROP): the forward's keep bits instead of the hash
 __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dq_kernel(const Args a) {
   __shared__ float Ks[2][kTileK * kKStride];
   __shared__ float Vs[2][kTileK * kKStride];
@@ -260,6 +274,8 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dq_kernel(const Args 
   const int n_tiles = (a.Lk + kTileK - 1) / kTileK;
   float4 kr[2], vr[2];
   float br = 0.f;
+  constexpr bool saved_bits = DROP && BITS;              // the forward's keep bits instead of the hash (the same mask)
+  unsigned word_next = 0;                                // this lane's keep word of the tile being loaded (the forward's lane layout)
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -272,6 +288,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dq_kernel(const Args 
       const int key = kt * kTileK + threadIdx.x;
       br = (key < a.Lk && a.kmask[(long long)b * a.Lk + key] == 0) ? 0.f : -INFINITY;
     }
+    if (saved_bits) word_next = a.keep[keep_index(a, bh, blockIdx.x, kt, threadIdx.x)];
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
@@ -290,6 +307,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dq_kernel(const Args 
   f32x16 dq = zero;
   for (int kt = 0; kt < n_tiles; ++kt) {
     const int buf = kt & 1;
+    const unsigned word = word_next;
     if (kt + 1 < n_tiles) load_tile(kt + 1);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -334,9 +352,13 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dq_kernel(const Args 
         if (!MASK && key >= a.Lk) p = 0.f;
         float dpe = dp[v];
         if (DROP && !(ATTN_SKIP & 2)) {
-          const unsigned bits = drop_bits(hseed, (unsigned)q, (unsigned)key >> 1);        // CSE'd across the pair
-          const unsigned mine = (key & 1) ? (bits >> 16) : (bits & 0xFFFFu);
-          dpe = mine >= a.drop_thr16 ? dpe * a.drop_scale : 0.f;
+          bool keep;
+          if (saved_bits) keep = (word & (1u << (16 * half + v))) != 0;
+          else {
+            const unsigned bits = drop_bits(hseed, (unsigned)q, (unsigned)key >> 1);      // CSE'd across the pair
+            keep = ((key & 1) ? (bits >> 16) : (bits & 0xFFFFu)) >= a.drop_thr16;
+          }
+          dpe = keep ? dpe * a.drop_scale : 0.f;
         }
         s[v] = p * (dpe - delta);                                                          // dS^T
       }
@@ -363,11 +385,13 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dq_kernel(const Args 
 
 // dK, dV: a lane owns one KEY (S = Q K^T untransposed: col = key, rows = 16 queries); per 32-query half:
 // S, dP = dO V^T, dV^T += dO^T P_drop, dK^T += Q^T dS -- 64 MFMAs.  Row statistics (lse, delta) come from LDS.
-template <bool DROP, bool MASK = false>
+template <bool DROP, bool MASK = false, bool BITS = false>
 __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dkdv_kernel(const Args a) {
   __shared__ float Qs[2][kTileK * kKStride];
   __shared__ float Ds[2][kTileK * kKStride];
   __shared__ float Ls[2][kTileK], Es[2][kTileK];          // lse, delta of the tile's queries
+  // saved keep bits (Args::keep) of the tile's 64 queries against this workgroup's two 64-key tiles: [key tile][forward lane half][query]
+  __shared__ unsigned Ws[2][DROP && BITS ? 256 : 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
   const int key = blockIdx.x * kBlockQ + wave * 32 + r;
@@ -389,6 +413,13 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dkdv_kernel(const Arg
   const int n_tiles = (a.Lq + kTileK - 1) / kTileK;
   float4 qr[2], dr[2];
   float lr = 0.f, er = 0.f;
+  constexpr bool saved_bits = DROP && BITS;              // the forward's keep bits instead of the hash (the same mask)
+  unsigned wr = 0;
+  // this lane's key in the forward's layout: key tile, lane half and bit of the word the forward lane of a query wrote
+  const int key_in_tile = (wave & 1) * 32 + r;
+  const int my_half_f = (r >> 2) & 1, my_bit = 16 * (wave & 1) + 4 * (r >> 3) + (r & 3), my_ktl = wave >> 1;
+  const int n_ktiles = (a.Lk + kTileK - 1) / kTileK;
+  (void)key_in_tile;
   auto load_tile = [&](int qt) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -402,6 +433,12 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dkdv_kernel(const Arg
       lr = qq < a.Lq ? lb[qq] : INFINITY;               // exp2(s - inf) = 0: padded queries contribute nothing
       er = qq < a.Lq ? eb[qq] : 0.f;
     }
+    if (saved_bits) {
+      // thread -> (key tile of this workgroup, forward lane half, query of the tile): the word of the forward lane that owned the query
+      const int ktl = threadIdx.x >> 7, half_f = (threadIdx.x >> 6) & 1, qq = qt * kTileK + (threadIdx.x & 63);
+      const int kt_f = min(2 * (int)blockIdx.x + ktl, n_ktiles - 1);                     // (a key tile past Lk: its lanes store nothing)
+      wr = a.keep[keep_index(a, bh, qq >> 7, kt_f, ((qq & 127) >> 5) * 64 + half_f * 32 + (qq & 31))];
+    }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
@@ -411,6 +448,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dkdv_kernel(const Arg
       *reinterpret_cast<float4 *>(&Ds[buf][row * kKStride + c]) = dr[j];
     }
     if (threadIdx.x < kTileK) { Ls[buf][threadIdx.x] = lr; Es[buf][threadIdx.x] = er; }
+    if (saved_bits) Ws[buf][threadIdx.x] = wr;
   };
   load_tile(0);
   store_tile(0);
@@ -457,15 +495,21 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dkdv_kernel(const Arg
       for (int g = 0; g < 4; ++g) {
         const float4 l4 = ld4(&Ls[buf][half * 32 + 4 * h + 8 * g]), e4 = ld4(&Es[buf][half * 32 + 4 * h + 8 * g]);
         const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, es[4] = {e4.x, e4.y, e4.z, e4.w};
+        uint4 w4 = make_uint4(0u, 0u, 0u, 0u);           // the keep words of the four queries of this group
+        if (saved_bits) w4 = *reinterpret_cast<const uint4 *>(&Ws[buf][my_ktl * 128 + my_half_f * 64 + half * 32 + 4 * h + 8 * g]);
+        const unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int v = 4 * g + j;
           const float p = dead ? 0.f : ((ATTN_SKIP & 1) ? s[v] - ls[j] : __builtin_amdgcn_exp2f(s[v] - ls[j]));
           float pd = p, dpe = dp[v];
           if (DROP && !(ATTN_SKIP & 2)) {
-            const unsigned bits = drop_bits(hseed, (unsigned)(q0i + 8 * g + j), (unsigned)key >> 1);
-            const unsigned mine = (key & 1) ? (bits >> 16) : (bits & 0xFFFFu);
-            const bool keep = mine >= a.drop_thr16;
+            bool keep;
+            if (saved_bits) keep = ((ws[j] >> my_bit) & 1u) != 0;
+            else {
+              const unsigned bits = drop_bits(hseed, (unsigned)(q0i + 8 * g + j), (unsigned)key >> 1);
+              keep = ((key & 1) ? (bits >> 16) : (bits & 0xFFFFu)) >= a.drop_thr16;
+            }
             pd = keep ? p * a.drop_scale : 0.f;
             dpe = keep ? dpe * a.drop_scale : 0.f;
           }
@@ -536,6 +580,19 @@ int mono_attn_forward_masked_f32(const float *q, const float *k, const float *v,
                                  float *lse, int B, int H, int Lq, int Lk, int head_dim, mono_attn_strides sq,
                                  mono_attn_strides sk, mono_attn_strides sv, mono_attn_strides so, float softmax_scale,
                                  float dropout_p, unsigned long long seed, void *stream_) {
+  return mono_attn_forward_keep_f32(q, k, v, key_padding_mask, nullptr, o, lse, B, H, Lq, Lk, head_dim, sq, sk, sv, so, softmax_scale,
+                                    dropout_p, seed, stream_);
+}
+
+long long mono_attn_keep_words(int B, int H, int Lq, int Lk) {
+  if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return 0;
+  return (long long)B * H * ((Lq + 127) / 128) * ((Lk + 63) / 64) * 256;
+}
+
+int mono_attn_forward_keep_f32(const float *q, const float *k, const float *v, const unsigned char *key_padding_mask,
+                               unsigned *keep_bits, float *o, float *lse, int B, int H, int Lq, int Lk, int head_dim,
+                               mono_attn_strides sq, mono_attn_strides sk, mono_attn_strides sv, mono_attn_strides so,
+                               float softmax_scale, float dropout_p, unsigned long long seed, void *stream_) {
   if (!q || !k || !v || !o || !lse) return MONO_ATTN_E_NULLPTR;
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || head_dim != 32 || !(dropout_p >= 0.f && dropout_p < 1.f) ||
       (long long)B * H > 65535)
@@ -548,10 +605,13 @@ int mono_attn_forward_masked_f32(const float *q, const float *k, const float *v,
   const dim3 grid((Lq + attn::kBlockQ - 1) / attn::kBlockQ, B * H);
   hipStream_t st = (hipStream_t)stream_;
   a.kmask = key_padding_mask;
+  a.keep = a.drop_thr16 ? keep_bits : nullptr;
   if (key_padding_mask) {
-    if (a.drop_thr16) attn::fwd_kernel<true, true><<<grid, 256, 0, st>>>(a);
+    if (a.keep) attn::fwd_kernel<true, true, true><<<grid, 256, 0, st>>>(a);
+    else if (a.drop_thr16) attn::fwd_kernel<true, true><<<grid, 256, 0, st>>>(a);
     else attn::fwd_kernel<false, true><<<grid, 256, 0, st>>>(a);
-  } else if (a.drop_thr16) attn::fwd_kernel<true><<<grid, 256, 0, st>>>(a);
+  } else if (a.keep) attn::fwd_kernel<true, false, true><<<grid, 256, 0, st>>>(a);
+  else if (a.drop_thr16) attn::fwd_kernel<true><<<grid, 256, 0, st>>>(a);
   else attn::fwd_kernel<false><<<grid, 256, 0, st>>>(a);
   return (int)hipGetLastError();
 }
@@ -572,6 +632,16 @@ int mono_attn_backward_masked_f32(const float *q, const float *k, const float *v
                                   mono_attn_strides sv, mono_attn_strides so, mono_attn_strides sdq, mono_attn_strides sdk,
                                   mono_attn_strides sdv, float softmax_scale, float dropout_p, unsigned long long seed,
                                   void *stream_) {
+  return mono_attn_backward_keep_f32(q, k, v, key_padding_mask, nullptr, o, lse, dout, dq, dk, dv, delta, B, H, Lq, Lk, head_dim, sq, sk,
+                                     sv, so, sdq, sdk, sdv, softmax_scale, dropout_p, seed, stream_);
+}
+
+int mono_attn_backward_keep_f32(const float *q, const float *k, const float *v, const unsigned char *key_padding_mask,
+                                const unsigned *keep_bits, const float *o, const float *lse, const float *dout, float *dq, float *dk,
+                                float *dv, float *delta, int B, int H, int Lq, int Lk, int head_dim, mono_attn_strides sq,
+                                mono_attn_strides sk, mono_attn_strides sv, mono_attn_strides so, mono_attn_strides sdq,
+                                mono_attn_strides sdk, mono_attn_strides sdv, float softmax_scale, float dropout_p,
+                                unsigned long long seed, void *stream_) {
   if (!q || !k || !v || !o || !lse || !dout || !dq || !dk || !dv || !delta) return MONO_ATTN_E_NULLPTR;
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0 || head_dim != 32 || !(dropout_p >= 0.f && dropout_p < 1.f) ||
       (long long)B * H > 65535)
@@ -590,7 +660,14 @@ int mono_attn_backward_masked_f32(const float *q, const float *k, const float *v
   attn::delta_kernel<<<(unsigned)((groups + 31) / 32), 256, 0, st>>>(a, B);
   const dim3 gq((Lq + attn::kBlockQ - 1) / attn::kBlockQ, B * H), gk((Lk + attn::kBlockQ - 1) / attn::kBlockQ, B * H);
   a.kmask = key_padding_mask;
-  if (key_padding_mask && a.drop_thr16) {
+  a.keep = a.drop_thr16 ? const_cast<unsigned *>(keep_bits) : nullptr;
+  if (key_padding_mask && a.keep) {
+    attn::bwd_dq_kernel<true, true, true><<<gq, 256, 0, st>>>(a);
+    attn::bwd_dkdv_kernel<true, true, true><<<gk, 256, 0, st>>>(a);
+  } else if (a.keep) {
+    attn::bwd_dq_kernel<true, false, true><<<gq, 256, 0, st>>>(a);
+    attn::bwd_dkdv_kernel<true, false, true><<<gk, 256, 0, st>>>(a);
+  } else if (key_padding_mask && a.drop_thr16) {
     attn::bwd_dq_kernel<true, true><<<gq, 256, 0, st>>>(a);
     attn::bwd_dkdv_kernel<true, true><<<gk, 256, 0, st>>>(a);
   } else if (key_padding_mask) {

@@ -10,7 +10,8 @@ from ._lib import raw_stream, on_device
 from .token_linear import linear as fast_linear
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_attn.so")
-SYMBOLS = ("mono_attn_forward_f32", "mono_attn_backward_f32", "mono_attn_forward_masked_f32", "mono_attn_backward_masked_f32")
+SYMBOLS = ("mono_attn_forward_f32", "mono_attn_backward_f32", "mono_attn_forward_masked_f32", "mono_attn_backward_masked_f32",
+           "mono_attn_keep_words", "mono_attn_forward_keep_f32", "mono_attn_backward_keep_f32")
 _lib = None
 
 
@@ -34,6 +35,12 @@ def load():
         lib.mono_attn_forward_masked_f32.argtypes = [P] * 6 + [I] * 5 + [_Strides] * 4 + [F, F, U, P]
         lib.mono_attn_backward_masked_f32.restype = I
         lib.mono_attn_backward_masked_f32.argtypes = [P] * 11 + [I] * 5 + [_Strides] * 7 + [F, F, U, P]
+        lib.mono_attn_keep_words.restype = ctypes.c_longlong
+        lib.mono_attn_keep_words.argtypes = [I] * 4
+        lib.mono_attn_forward_keep_f32.restype = I
+        lib.mono_attn_forward_keep_f32.argtypes = [P] * 7 + [I] * 5 + [_Strides] * 4 + [F, F, U, P]
+        lib.mono_attn_backward_keep_f32.restype = I
+        lib.mono_attn_backward_keep_f32.argtypes = [P] * 12 + [I] * 5 + [_Strides] * 7 + [F, F, U, P]
         _lib = lib
     return _lib
 
@@ -52,6 +59,9 @@ def supported(q, k, v):
 
 
 _seed_counter = [0]
+# the training forward hands its dropout mask to the backward as 1 bit per score (59 MB for the 1920 x 1920 depth-encoder call at B = 16)
+# instead of the backward re-hashing it; MONOSOWA_ATTN_KEEP_BITS=0: regenerate (the same mask)
+SAVE_KEEP_BITS = os.environ.get("MONOSOWA_ATTN_KEEP_BITS", "1") != "0"
 
 
 def _next_seed():
@@ -71,17 +81,26 @@ def _mask_ptr(mask, B, Lk):
     return mask.data_ptr(), mask
 
 
-def forward(q, k, v, scale, p, seed, key_padding_mask=None):
+def keep_bits_like(q, k, p):
+    """The buffer the forward leaves its dropout keep bits in for the backward (None without dropout): include/monosowa_attn.h."""
+    if not p > 0:
+        return None
+    B, H, Lq, _ = q.shape
+    return torch.empty(load().mono_attn_keep_words(B, H, Lq, k.size(2)), dtype=torch.int32, device=q.device)
+
+
+def forward(q, k, v, scale, p, seed, key_padding_mask=None, keep_bits=None):
+    """-> (o, lse); keep_bits (``keep_bits_like``): also filled with the dropout mask, for ``backward(..., keep_bits=)``."""
     B, H, Lq, _ = q.shape
     o = torch.empty((B, H, Lq, 32), dtype=torch.float32, device=q.device)
     lse = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
     mp, keep = _mask_ptr(key_padding_mask, B, k.size(2))
     with on_device(q.device):
-        code = load().mono_attn_forward_masked_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, o.data_ptr(), lse.data_ptr(), B, H, Lq,
-                                                   k.size(2), 32, _strides(q), _strides(k), _strides(v), _strides(o), float(scale),
-                                                   float(p), seed, raw_stream())
+        code = load().mono_attn_forward_keep_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, keep_bits.data_ptr() if keep_bits is not None else 0,
+                                                 o.data_ptr(), lse.data_ptr(), B, H, Lq, k.size(2), 32, _strides(q), _strides(k), _strides(v),
+                                                 _strides(o), float(scale), float(p), seed, raw_stream())
     if code:
-        raise RuntimeError("mono_attn_forward_masked_f32 failed with code %d" % code)
+        raise RuntimeError("mono_attn_forward_keep_f32 failed with code %d" % code)
     return o, lse
 
 
@@ -99,8 +118,9 @@ def _like_heads(t):
     return torch.empty((L, B, H * 32), dtype=torch.float32, device=t.device).view(L, B, H, 32).permute(1, 2, 0, 3)
 
 
-def backward(q, k, v, o, lse, dout, scale, p, seed, key_padding_mask=None):
-    """dq, dk, dv as [B, H, L, 32] views of fresh buffers laid out like q, k, v (the layout of the MHA projections)."""
+def backward(q, k, v, o, lse, dout, scale, p, seed, key_padding_mask=None, keep_bits=None):
+    """dq, dk, dv as [B, H, L, 32] views of fresh buffers laid out like q, k, v (the layout of the MHA projections).
+    keep_bits: the forward's dropout mask (else it is regenerated from the seed: the same mask, 14 % more backward time)."""
     B, H, Lq, _ = q.shape
     Lk = k.size(2)
     dq, dk, dv = _like_heads(q), _like_heads(k), _like_heads(v)
@@ -108,12 +128,12 @@ def backward(q, k, v, o, lse, dout, scale, p, seed, key_padding_mask=None):
     assert dout.stride() == o.stride()
     mp, keep = _mask_ptr(key_padding_mask, B, Lk)
     with on_device(q.device):
-        code = load().mono_attn_backward_masked_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, o.data_ptr(), lse.data_ptr(),
-                                                    dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), B, H,
-                                                    Lq, Lk, 32, _strides(q), _strides(k), _strides(v), _strides(o), _strides(dq),
-                                                    _strides(dk), _strides(dv), float(scale), float(p), seed, raw_stream())
+        code = load().mono_attn_backward_keep_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, keep_bits.data_ptr() if keep_bits is not None else 0,
+                                                  o.data_ptr(), lse.data_ptr(), dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                                  delta.data_ptr(), B, H, Lq, Lk, 32, _strides(q), _strides(k), _strides(v), _strides(o),
+                                                  _strides(dq), _strides(dk), _strides(dv), float(scale), float(p), seed, raw_stream())
     if code:
-        raise RuntimeError("mono_attn_backward_masked_f32 failed with code %d" % code)
+        raise RuntimeError("mono_attn_backward_keep_f32 failed with code %d" % code)
     return dq, dk, dv
 
 
@@ -126,14 +146,15 @@ class _Attention(torch.autograd.Function):
         o = _like_heads(q)                           # [Lq, B, H*32] or, for a batch-major q, [B, Lq, H*32]
         lse = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
         mp, mask = _mask_ptr(mask, B, k.size(2))
+        bits = keep_bits_like(q, k, p) if SAVE_KEEP_BITS else None      # 1 bit per score, kept until the backward
         with on_device(q.device):
-            code = load().mono_attn_forward_masked_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, o.data_ptr(), lse.data_ptr(), B, H,
-                                                       Lq, k.size(2), 32, _strides(q), _strides(k), _strides(v), _strides(o),
-                                                       float(scale), float(p), seed, raw_stream())
+            code = load().mono_attn_forward_keep_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, bits.data_ptr() if bits is not None else 0,
+                                                     o.data_ptr(), lse.data_ptr(), B, H, Lq, k.size(2), 32, _strides(q), _strides(k),
+                                                     _strides(v), _strides(o), float(scale), float(p), seed, raw_stream())
         if code:
-            raise RuntimeError("mono_attn_forward_masked_f32 failed with code %d" % code)
+            raise RuntimeError("mono_attn_forward_keep_f32 failed with code %d" % code)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.scale, ctx.p, ctx.seed, ctx.mask = scale, p, seed, mask
+        ctx.scale, ctx.p, ctx.seed, ctx.mask, ctx.bits = scale, p, seed, mask, bits
         return o
 
     @staticmethod
@@ -143,7 +164,7 @@ class _Attention(torch.autograd.Function):
             d2 = _like_heads(o)
             d2.copy_(dout)
             dout = d2
-        dq, dk, dv = backward(q, k, v, o, lse, dout, ctx.scale, ctx.p, ctx.seed, ctx.mask)
+        dq, dk, dv = backward(q, k, v, o, lse, dout, ctx.scale, ctx.p, ctx.seed, ctx.mask, ctx.bits)
         return dq, dk, dv, None, None, None, None
 
 

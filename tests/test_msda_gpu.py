@@ -996,6 +996,32 @@ def test_attention_dropout_uses_one_mask_forward_and_backward(masked):
         assert (kg.grad[kpm[:, None, :, None].expand_as(kg.grad)] == 0).all() and (vg.grad[kpm[:, None, :, None].expand_as(vg.grad)] == 0).all()
 
 
+@pytest.mark.parametrize("masked", [False, True], ids=["nomask", "keypad"])
+@pytest.mark.parametrize("B,H,Lq,Lk", [(2, 8, 550, 1920), (1, 3, 70, 130), (2, 2, 300, 64), (1, 8, 1920, 1920), (3, 2, 1, 5)])
+def test_attention_backward_from_saved_keep_bits_is_the_rehashed_backward(B, H, Lq, Lk, masked):
+    """The training path hands the forward's dropout mask to the backward as one bit per score (mono_attn_*_keep_f32) instead of
+    re-hashing it there: the three gradients must be BIT-identical to the re-hashing backward (same mask, same arithmetic), for
+    ragged query / key counts, with and without a key padding mask."""
+    from monosowa_amd import flash_attn as FA
+    torch.manual_seed(Lq + Lk)
+    q, k, v, go = _heads(Lq, B, H), _heads(Lk, B, H), _heads(Lk, B, H), _heads(Lq, B, H)
+    kpm = None
+    if masked:
+        kpm = torch.rand(B, Lk, device="cuda") < 0.2
+        kpm[:, 0] = False
+    p, seed, scale = 0.1, 4242, 1 / 32 ** 0.5
+    bits = FA.keep_bits_like(q, k, p)
+    bits.fill_(-1)
+    o1, lse1 = FA.forward(q, k, v, scale, p, seed, key_padding_mask=kpm, keep_bits=bits)
+    o2, lse2 = FA.forward(q, k, v, scale, p, seed, key_padding_mask=kpm)
+    assert torch.equal(o1, o2) and torch.equal(lse1, lse2)
+    go = torch.empty_like(o1).copy_(go)                        # (the backward wants dout laid out like o)
+    with_bits = FA.backward(q, k, v, o1, lse1, go, scale, p, seed, key_padding_mask=kpm, keep_bits=bits)
+    rehashed = FA.backward(q, k, v, o1, lse1, go, scale, p, seed, key_padding_mask=kpm)
+    for name, a, b in zip(("dq", "dk", "dv"), with_bits, rehashed):
+        assert torch.equal(a, b), "%s: max difference %.3e" % (name, (a - b).abs().max().item())
+
+
 @pytest.mark.parametrize("same_qk", [True, False, None])
 def test_mha_forward_equals_nn_multiheadattention(same_qk):
     """mha_forward (packed projections + HIP core) against nn.MultiheadAttention in eval mode: output and all

@@ -29,5 +29,12 @@ for B, H, Lq, Lk in [(16, 8, 1920, 1920), (16, 8, 550, 1920)]:
     goc = go.contiguous()
     tb = timeit(lambda: FA.backward(q, k, v, o, lse, goc, scale, 0.1, 5))
     flops = 4.0 * B * H * Lq * Lk * 32
-    out.append("%dx%d: fwd %.3f ms (%.0f TF) bwd %.3f ms (%.0f TF at 3.5x)" % (Lq, Lk, tf, flops / tf / 1e9, tb, 3.5 * flops / tb / 1e9))
+    line = "%dx%d: fwd %.3f ms (%.0f TF) bwd %.3f ms (%.0f TF at 3.5x)" % (Lq, Lk, tf, flops / tf / 1e9, tb, 3.5 * flops / tb / 1e9)
+    if hasattr(FA, "keep_bits_like"):               # the training path: the forward saves the dropout mask, the backward reads it
+        bits = FA.keep_bits_like(q, k, 0.1)
+        FA.forward(q, k, v, scale, 0.1, 5, keep_bits=bits)
+        tf2 = timeit(lambda: FA.forward(q, k, v, scale, 0.1, 5, keep_bits=bits))
+        tb2 = timeit(lambda: FA.backward(q, k, v, o, lse, goc, scale, 0.1, 5, keep_bits=bits))
+        line += "; with saved keep bits: fwd %.3f, bwd %.3f ms" % (tf2, tb2)
+    out.append(line)
 print(" | ".join(out))
