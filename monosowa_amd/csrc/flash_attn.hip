@@ -233,21 +233,6 @@ __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void fwd_kernel(const Args a) 
 
 
 // ---------------------------------------------------------------------------------------------- backward
-// delta[bh][q] = sum_d dO[q][d] * O[q][d]; 8 lanes x float4 per (batch, head, query), heads fastest so that the
-// [L, B, H*32] projections are read in contiguous runs.
-__global__ __launch_bounds__(256) void delta_kernel(const Args a, int B) {
-  const long long g = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
-  const int sub = threadIdx.x & 7;
-  const long long n = (long long)a.Lq * B * a.H;
-  if (g >= n) return;
-  const int hd = (int)(g % a.H), b = (int)((g / a.H) % B), q = (int)(g / ((long long)a.H * B));
-  const long long off = b * a.so.b + hd * a.so.h + (long long)q * a.so.t + sub * 4;
-  const float4 x = ld4(a.dout + off), y = ld4(a.o + off);
-  float d = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-  d += __shfl_xor(d, 4); d += __shfl_xor(d, 2); d += __shfl_xor(d, 1);
-  if (sub == 0) const_cast<float *>(a.delta)[((long long)b * a.H + hd) * a.Lq + q] = d;
-}
-
 // dQ: same decomposition as the forward (a lane owns one query); per 32-key half: S^T (recomputed), dP^T = V dO^T,
 // dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T -- 48 MFMAs.
 template <bool DROP, bool MASK = false, bool BITS = false>       // BITS (with DROP): the forward's keep bits instead of the hash
@@ -261,15 +246,22 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dq_kernel(const Args 
   const int qc = min(q, a.Lq - 1);
   const float *qp = a.q + b * a.sq.b + hd * a.sq.h + (long long)qc * a.sq.t + 16 * h;
   const float *dop = a.dout + b * a.so.b + hd * a.so.h + (long long)qc * a.so.t + 16 * h;
+  // delta[q] = sum_d dO[q][d] O[q][d] is evaluated here (the lane holds its half of the dO row anyway) and left in Args::delta
+  // for bwd_dkdv, which runs behind this kernel on the same stream: no separate pass over dO and O
+  const float *op = a.o + b * a.so.b + hd * a.so.h + (long long)qc * a.so.t + 16 * h;
   float qreg[16], doreg[16];
+  float delta = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float4 t = ld4(qp + 4 * i), u = ld4(dop + 4 * i);
+    const float4 t = ld4(qp + 4 * i), u = ld4(dop + 4 * i), w = ld4(op + 4 * i);
     qreg[4 * i] = t.x * a.scale_log2; qreg[4 * i + 1] = t.y * a.scale_log2;
     qreg[4 * i + 2] = t.z * a.scale_log2; qreg[4 * i + 3] = t.w * a.scale_log2;
     doreg[4 * i] = u.x; doreg[4 * i + 1] = u.y; doreg[4 * i + 2] = u.z; doreg[4 * i + 3] = u.w;
+    delta += u.x * w.x + u.y * w.y + u.z * w.z + u.w * w.w;
   }
-  const float lse = a.lse[(long long)bh * a.Lq + qc], delta = a.delta[(long long)bh * a.Lq + qc];
+  delta += xhalf(delta);
+  if (h == 0 && q < a.Lq) const_cast<float *>(a.delta)[(long long)bh * a.Lq + q] = delta;
+  const float lse = a.lse[(long long)bh * a.Lq + qc];
   const float *kb = a.k + b * a.sk.b + hd * a.sk.h, *vb = a.v + b * a.sv.b + hd * a.sv.h;
   const int n_tiles = (a.Lk + kTileK - 1) / kTileK;
   float4 kr[2], vr[2];
@@ -656,8 +648,6 @@ int mono_attn_backward_keep_f32(const float *q, const float *k, const float *v, 
   a.sdq = cvt(sdq); a.sdk = cvt(sdk); a.sdv = cvt(sdv);
   fill_common(a, H, Lq, Lk, softmax_scale, dropout_p, seed);
   hipStream_t st = (hipStream_t)stream_;
-  const long long groups = (long long)Lq * B * H;
-  attn::delta_kernel<<<(unsigned)((groups + 31) / 32), 256, 0, st>>>(a, B);
   const dim3 gq((Lq + attn::kBlockQ - 1) / attn::kBlockQ, B * H), gk((Lk + attn::kBlockQ - 1) / attn::kBlockQ, B * H);
   a.kmask = key_padding_mask;
   a.keep = a.drop_thr16 ? const_cast<unsigned *>(keep_bits) : nullptr;
