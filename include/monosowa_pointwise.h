@@ -13,6 +13,9 @@ extern "C" {
 
 /* y[r, c] = act(y[r, c] + bias[c] (+ residual[r, c])) in place; residual may be NULL; relu != 0 applies max(., 0). */
 int mono_bias_act_f32(float *y, const float *bias, const float *residual, long long rows, int C, int relu, void *stream);
+/* The frozen stem (reference backbone.py:72-74, 83; torchvision's ResNet stem): out = max_pool2d(relu(y + bias), 3, stride 2, padding 1)
+ * in one pass over the channels-last convolution output y [N, H, W, C]; out [N, (H-1)/2+1, (W-1)/2+1, C].  Forward only. */
+int mono_bias_relu_maxpool_nhwc_f32(const float *y, const float *bias, float *out, int N, int H, int W, int C, void *stream);
 
 /* grad_in[i] = y[i] > 0 ? grad_out[i] : 0   (n % 4 == 0; grad_in may alias grad_out). */
 int mono_relu_grad_f32(const float *grad_out, const float *y, float *grad_in, long long n, void *stream);

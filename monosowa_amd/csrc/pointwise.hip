@@ -32,6 +32,37 @@ __global__ __launch_bounds__(256) void bias_act_kernel(float *__restrict__ y, co
   }
 }
 
+// The frozen stem of the backbone (backbone.py:72-74 of the reference freezes conv1 / layer1): relu(y + bias) followed by the 3 x 3 /
+// stride 2 / padding 1 max-pool, in ONE pass over the convolution's output -- relu(max(y) + b) = max(relu(y + b)): both are monotonic and
+// the bias is constant over a window.  Channels-last; a thread owns 4 channels of one output pixel (9 float4 loads, neighbours' windows
+// overlap in L2).  Forward only: nothing below layer 2 receives a gradient.
+__global__ __launch_bounds__(256) void bias_relu_maxpool_kernel(const float *__restrict__ y, const float *__restrict__ bias,
+                                                                float *__restrict__ out, int N, int H, int W, int c_vec, int OH, int OW) {
+  const long long n_items = (long long)N * OH * OW * c_vec, stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += stride) {
+    const int c = (int)(i % c_vec);
+    long long t = i / c_vec;
+    const int ox = (int)(t % OW);
+    t /= OW;
+    const int oy = (int)(t % OH), n = (int)(t / OH);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = 2 * oy - 1 + dy;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = 2 * ox - 1 + dx;
+        if (ix < 0 || ix >= W) continue;
+        const float4 v = reinterpret_cast<const float4 *>(y)[(((long long)n * H + iy) * W + ix) * c_vec + c];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    const float4 b = reinterpret_cast<const float4 *>(bias)[c];
+    reinterpret_cast<float4 *>(out)[i] = make_float4(fmaxf(m.x + b.x, 0.f), fmaxf(m.y + b.y, 0.f), fmaxf(m.z + b.z, 0.f), fmaxf(m.w + b.w, 0.f));
+  }
+}
+
 // ReLU variants with a BYTE MASK per float4 (bit k = element k positive): the forward writes 1 B per 16 B of output, the
 // backward reads that instead of y (4 B per element from HBM: y was written long before its backward runs).
 template <bool RES>
@@ -467,6 +498,17 @@ int mono_bias_act_f32(float *y, const float *bias, const float *residual, long l
   else if (relu) mono::bias_act_kernel<true, false><<<g, 256, 0, stream>>>(y, bias, nullptr, n_vec, C / 4);
   else if (residual) mono::bias_act_kernel<false, true><<<g, 256, 0, stream>>>(y, bias, residual, n_vec, C / 4);
   else mono::bias_act_kernel<false, false><<<g, 256, 0, stream>>>(y, bias, nullptr, n_vec, C / 4);
+  return (int)hipGetLastError();
+}
+
+// out [N, OH, OW, C] = max_pool2d(relu(y + bias), kernel 3, stride 2, padding 1) of the channels-last y [N, H, W, C] (C % 4 == 0):
+// OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1.
+int mono_bias_relu_maxpool_nhwc_f32(const float *y, const float *bias, float *out, int N, int H, int W, int C, void *stream_) {
+  if (!y || !bias || !out) return -1;
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)out & 15)) return -2;
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long n_items = (long long)N * OH * OW * (C / 4);
+  mono::bias_relu_maxpool_kernel<<<mono::grid_for_vec(n_items), 256, 0, (hipStream_t)stream_>>>(y, bias, out, N, H, W, C / 4, OH, OW);
   return (int)hipGetLastError();
 }
 

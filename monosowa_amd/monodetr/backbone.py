@@ -12,11 +12,14 @@ its weights/bias (one pass over the activation instead of two; exact in real ari
 fp32) and the fold is differentiated through for the trainable stages.  The dense convolutions go
 to MIOpen (MFMA); nothing here is hand-written.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..pointwise import affine_relu, affine_relu_supported, bias_act, bias_act_fork
+from ..pointwise import (affine_relu, affine_relu_supported, bias_act, bias_act_fork, bias_relu_maxpool,
+                         bias_relu_maxpool_supported)
 from .misc import NestedTensor
 from .position_encoding import build_position_encoding
 
@@ -124,6 +127,24 @@ def conv_bn(x, conv, bn, residual=None, relu=True):
     return F.relu(y, inplace=True) if relu else y
 
 
+FUSED_STEM = os.environ.get("MONOSOWA_FUSED_STEM", "1") != "0"      # A/B switch (tools): 0 = in-place bias + ReLU pass, then F.max_pool2d
+
+
+def stem(x, conv, bn):
+    """max_pool(relu(bn1(conv1(x))), 3, 2, 1) (torchvision's ResNet stem behind backbone.py:83 of the reference).  The stem is frozen
+    (backbone.py:72-74): when nothing asks for a gradient the BN shift, the ReLU and the pooling are one pass over the convolution's
+    output (pointwise.bias_relu_maxpool) instead of an in-place pass plus a pooling pass over the largest activation of the network."""
+    if isinstance(bn, FrozenBatchNorm2d):
+        scale, shift = bn.scale_shift()
+        w = folded_weight(conv, bn, scale)
+        if not (w.requires_grad and torch.is_grad_enabled()):
+            y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if FUSED_STEM and bias_relu_maxpool_supported(y, shift):
+                return bias_relu_maxpool(y, shift)
+            return F.max_pool2d(bias_act(y, shift, None, True), kernel_size=3, stride=2, padding=1)
+    return F.max_pool2d(conv_bn(x, conv, bn), kernel_size=3, stride=2, padding=1)
+
+
 class Bottleneck(nn.Module):
     """ResNet v1.5 bottleneck: 1x1 -> 3x3 (carries the stride) -> 1x1 (x4), residual add, ReLU."""
     expansion = 4
@@ -184,8 +205,7 @@ class ResNetBody(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = conv_bn(x, self.conv1, self.bn1)
-        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        x = stem(x, self.conv1, self.bn1)
         # blocks hand (a, b) pairs to each other (one tensor object per consumer, see Bottleneck.forward); the stage
         # outputs that leave the body are the first members
         # a stage output that also leaves the body (layer2 / layer3 with intermediate layers) has a third consumer: its last block

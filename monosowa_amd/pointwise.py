@@ -9,7 +9,7 @@ import torch
 from ._lib import raw_stream, on_device
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
-SYMBOLS = ("mono_bias_act_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
+SYMBOLS = ("mono_bias_act_f32", "mono_bias_relu_maxpool_nhwc_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
            "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32", "mono_relu_dropout_bwd_colsum_f32", "mono_sum_slices_f32", "mono_colsum_any_blocks", "mono_colsum_any_f32", "mono_relu_grad_mask3_f32", "mono_lsap_match_flat_f32")
@@ -26,6 +26,8 @@ def load():
         P, I, LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
         lib.mono_bias_act_f32.restype = I
         lib.mono_bias_act_f32.argtypes = [P, P, P, LL, I, I, P]
+        lib.mono_bias_relu_maxpool_nhwc_f32.restype = I
+        lib.mono_bias_relu_maxpool_nhwc_f32.argtypes = [P, P, P, I, I, I, I, P]
         lib.mono_relu_grad_f32.restype = I
         lib.mono_relu_grad_f32.argtypes = [P, P, P, LL, P]
         lib.mono_bias_relu_mask_f32.restype = I
@@ -244,6 +246,23 @@ class _BiasActFork(torch.autograd.Function):
         if code:
             raise RuntimeError("mono_relu_grad(2)_f32 failed with code %d" % code)
         return g, (g.sum((0, 2, 3)) if ctx.bias_grad else None), g, None
+
+
+def bias_relu_maxpool_supported(y, bias):
+    """The one-pass frozen stem applies when nothing upstream wants a gradient (conv1 / bn1 frozen, images are data)."""
+    return _nhwc_ok(y) and bias.is_cuda and bias.dtype == torch.float32 and bias.data_ptr() % 16 == 0 and bias.numel() == y.size(1) \
+        and not (torch.is_grad_enabled() and (y.requires_grad or bias.requires_grad))
+
+
+def bias_relu_maxpool(y, bias):
+    """``F.max_pool2d(relu(y + bias[None, :, None, None]), kernel_size=3, stride=2, padding=1)`` in one pass (channels-last)."""
+    N, C, H, W = y.shape
+    out = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=y.device, memory_format=torch.channels_last)
+    with on_device(y.device):
+        code = load().mono_bias_relu_maxpool_nhwc_f32(y.data_ptr(), bias.data_ptr(), out.data_ptr(), N, H, W, C, raw_stream())
+    if code:
+        raise RuntimeError("mono_bias_relu_maxpool_nhwc_f32 failed with code %d" % code)
+    return out
 
 
 def bias_act_fork(y, bias, residual, n_out=2):

@@ -123,3 +123,21 @@ def test_backbone_joiner_and_projections_equal_a_plain_float64_evaluation(name, 
         body = model.backbone[0].body
         assert body.layer2[0].conv1.weight.grad is not None and torch.isfinite(body.layer4[-1].conv3.weight.grad).all()
         assert body.conv1.weight.grad is None and body.layer1[0].conv1.weight.grad is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 192, 640), (1, 8, 7, 9), (3, 64, 1, 1), (2, 12, 10, 5)])
+def test_frozen_stem_pass_equals_bias_relu_maxpool(N, C, H, W):
+    """mono_bias_relu_maxpool_nhwc_f32 (the frozen stem: BN shift + ReLU + 3x3 / 2 max-pool in one pass) against the three PyTorch
+    ops, bit for bit (max and add commute exactly here), odd extents and borders included."""
+    from monosowa_amd import pointwise as PW
+    torch.manual_seed(N + C + H + W)
+    y = (torch.randn(N, C, H, W, device="cuda") * 3).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(C, device="cuda")
+    assert PW.bias_relu_maxpool_supported(y, bias)
+    got = PW.bias_relu_maxpool(y, bias)
+    want = torch.nn.functional.max_pool2d(torch.relu(y + bias.view(1, -1, 1, 1)), kernel_size=3, stride=2, padding=1)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
+    y.requires_grad_(True)
+    assert not PW.bias_relu_maxpool_supported(y, bias), "a stem that is trained keeps its autograd path"
