@@ -357,8 +357,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ g
 // columns (64 bytes of every row) over ALL rows: thread = (row lane of 256, column of 4), 8 rows in flight per thread, then the 256 row
 // lanes are folded by wave shuffles and one LDS exchange -- no partial rows, no second launch.  C / 16 workgroups; the strips of one row
 // share its 128-byte lines through L2 (the matrix is read from HBM once).
+// OFF by default (0): back to back on one L2-warm matrix it wins ([8800, 256]: 7.6 against 10.3 us), but inside the train step, where its
+// input has just been written by a GEMM on other CUs, it loses -- 17.2 us per call against 7.9 + 5.8 for the two stages (16 workgroups pull
+// the 9 MB through 16 CUs, and two strips share every 128-byte line from different XCDs); the step measured 68.45 / 68.38 ms with it and
+// 68.25 / 68.09 ms without, in alternating same-box runs.  -DMONO_COLSUM_STRIP_ROWS=12288 brings it back (tools/debug/colsum_time.py).
 #ifndef MONO_COLSUM_STRIP_ROWS
-#define MONO_COLSUM_STRIP_ROWS 12288
+#define MONO_COLSUM_STRIP_ROWS 0
 #endif
 constexpr long long kColsumStripRows = MONO_COLSUM_STRIP_ROWS;        // up to here mono_colsum_f32 takes the one-launch strip kernel
 __global__ __launch_bounds__(1024) void colsum_strip_kernel(const float *__restrict__ g, float *__restrict__ out, long long rows, int C) {
@@ -695,8 +699,7 @@ int mono_colsum_f32(const float *g, float *out, float *partials, long long rows,
   if (!g || !out || !partials) return -1;
   if (rows <= 0 || C <= 0 || C % 4 || C > 1024) return -2;
   hipStream_t st = (hipStream_t)stream_;
-  // short and not too wide (measured, round 4: [8800, 256] 7.6 against 10.3 us, [8800, 384] 8.0 / 12.4, [2200, 256] 8.3 / 11.0; [8800, 512]
-  // 18.8 / 16.8 and [16384, 256] 11.4 / 11.4 stay on the two stages): one launch, no partial rows (`partials` unused)
+  // (one-launch strip kernel: disabled by default, see MONO_COLSUM_STRIP_ROWS)
   if (rows <= mono::kColsumStripRows && C <= 384) {
     mono::colsum_strip_kernel<<<(C / 4 + 3) / 4, 1024, 0, st>>>(g, out, rows, C);
     return (int)hipGetLastError();
