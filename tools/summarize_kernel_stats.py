@@ -41,10 +41,11 @@ def cat(n):
 
 def rows_from_trace(path, steps):
     """Per-kernel totals over the LAST `steps` train steps of a rocprofv3 *_kernel_trace.csv (steps are delimited by
-    the backbone's single max-pool forward), i.e. without warm-up, MIOpen's find phase and JIT effects."""
+    the backbone's single stem-pooling launch), i.e. without warm-up, MIOpen's find phase and JIT effects."""
     trace = list(csv.DictReader(open(path)))
     trace.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(trace) if "max_pool_forward" in r["Kernel_Name"]]
+    # (one launch per train step: the stem's pooling -- the one-pass stem kernel since round 4, torch's max-pool before)
+    marks = [i for i, r in enumerate(trace) if "bias_relu_maxpool_kernel" in r["Kernel_Name"] or "max_pool_forward" in r["Kernel_Name"]]
     if len(marks) < steps:
         raise SystemExit("only %d steps in the trace" % len(marks))
     first = marks[-int(steps)]
