@@ -95,13 +95,29 @@ def folded_weight(conv, bn, scale):
     return cached[1]
 
 
-def conv_bn_fork(x, conv, bn, residual, n_out=2):
+def _summed_shift(bn, other):
+    """shift(bn) + shift(other) of two frozen norms (constant during training: kept)."""
+    a, b = bn.scale_shift()[1], other.scale_shift()[1]
+    key = (a.data_ptr(), a._version, b.data_ptr(), b._version)
+    cached = bn.__dict__.get("_summed_shift")
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            cached = bn.__dict__["_summed_shift"] = (key, a + b)
+    return cached[1]
+
+
+def conv_bn_fork(x, conv, bn, residual, n_out=2, residual_bn=None):
     """``conv_bn(x, conv, bn, residual)`` returned as a pair for its two consumers (next block's first convolution and
-    identity branch): their gradients are added inside the fused ReLU backward (``pointwise.bias_act_fork``)."""
+    identity branch): their gradients are added inside the fused ReLU backward (``pointwise.bias_act_fork``).
+    residual_bn: the residual is a downsample convolution's RAW output (scale folded into its weights, shift not yet added) -- its
+    frozen norm's shift joins this norm's shift, so the downsample branch needs no pass of its own over its output."""
     if isinstance(bn, FrozenBatchNorm2d):
         scale, shift = bn.scale_shift()
+        if residual_bn is not None:
+            shift = _summed_shift(bn, residual_bn)
         y = F.conv2d(x, folded_weight(conv, bn, scale), None, conv.stride, conv.padding, conv.dilation, conv.groups)
         return bias_act_fork(y, shift, residual, n_out)
+    assert residual_bn is None
     out = conv_bn(x, conv, bn, residual)
     return (out,) * n_out
 
@@ -127,6 +143,7 @@ def conv_bn(x, conv, bn, residual=None, relu=True):
     return F.relu(y, inplace=True) if relu else y
 
 
+FOLD_DOWNSAMPLE_SHIFT = os.environ.get("MONOSOWA_FOLD_DS_SHIFT", "1") != "0"   # A/B switch (tools)
 FUSED_STEM = os.environ.get("MONOSOWA_FUSED_STEM", "1") != "0"      # A/B switch (tools): 0 = in-place bias + ReLU pass, then F.max_pool2d
 
 
@@ -164,8 +181,18 @@ class Bottleneck(nn.Module):
         xa, xb = x if isinstance(x, tuple) else (x, x)
         out = conv_bn(xa, self.conv1, self.bn1)
         out = conv_bn(out, self.conv2, self.bn2)
-        identity = xb if self.downsample is None else conv_bn(xb, self.downsample[0], self.downsample[1], relu=False)
-        return conv_bn_fork(out, self.conv3, self.bn3, identity, getattr(self, "n_out", 2))
+        n_out = getattr(self, "n_out", 2)
+        if self.downsample is None:
+            return conv_bn_fork(out, self.conv3, self.bn3, xb, n_out)
+        ds_conv, ds_bn = self.downsample[0], self.downsample[1]
+        if FOLD_DOWNSAMPLE_SHIFT and isinstance(ds_bn, FrozenBatchNorm2d) and isinstance(self.bn3, FrozenBatchNorm2d):
+            # relu(y3 + shift3 + (y_ds + shift_ds)) = relu(y3 + (shift3 + shift_ds) + y_ds): the downsample's output is only ever this
+            # residual, so its shift rides on bn3's and the branch is the bare convolution (no bias pass over its output)
+            identity = F.conv2d(xb, folded_weight(ds_conv, ds_bn, ds_bn.scale_shift()[0]), None, ds_conv.stride, ds_conv.padding,
+                                ds_conv.dilation, ds_conv.groups)
+            return conv_bn_fork(out, self.conv3, self.bn3, identity, n_out, residual_bn=ds_bn)
+        identity = conv_bn(xb, ds_conv, ds_bn, relu=False)
+        return conv_bn_fork(out, self.conv3, self.bn3, identity, n_out)
 
 
 _DEPTHS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}
