@@ -796,7 +796,7 @@ int mono_groupnorm_nhwc_bwd_f32(const float *gy, const float *x, const float *pr
 
 
 // ---- DDN depth-map loss (ddn_loss.hip) ---------------------------------------------------------------------------------
-int mono_ddn_loss_blocks(int B, int H, int W) { return (B * H * W + 255) / 256; }
+int mono_ddn_loss_blocks(int B, int H, int W) { return (B * H * W * mono::kDdnLanes + 255) / 256; }
 
 static mono::DdnParams ddn_params(int B, int C, int H, int W, int N, long long sb, long long sc, long long sp, float alpha,
                                   float gamma, float fg_weight, float bg_weight, float depth_min, float depth_max) {
@@ -837,7 +837,7 @@ int mono_depth_expect_fwd_f32(const float *logits, const float *values, float *o
   if (!logits || !values || !out) return -1;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return -2;
   const int n = B * H * W;
-  mono::depth_expect_fwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(logits, values, out, n, H * W, C, sb, sc, sp);
+  mono::depth_expect_fwd_kernel<<<(n * mono::kDdnLanes + 255) / 256, 256, 0, (hipStream_t)stream>>>(logits, values, out, n, H * W, C, sb, sc, sp);
   return (int)hipGetLastError();
 }
 
@@ -846,7 +846,7 @@ int mono_depth_expect_bwd_f32(const float *logits, const float *values, const fl
   if (!logits || !values || !expect || !grad_out || !grad_logits) return -1;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return -2;
   const int n = B * H * W;
-  mono::depth_expect_bwd_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(logits, values, expect, grad_out, grad_logits, n,
+  mono::depth_expect_bwd_kernel<<<(n * mono::kDdnLanes + 255) / 256, 256, 0, (hipStream_t)stream>>>(logits, values, expect, grad_out, grad_logits, n,
                                                                                H * W, C, sb, sc, sp);
   return (int)hipGetLastError();
 }
