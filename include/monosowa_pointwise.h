@@ -16,6 +16,11 @@ int mono_bias_act_f32(float *y, const float *bias, const float *residual, long l
 /* The frozen stem (reference backbone.py:72-74, 83; torchvision's ResNet stem): out = max_pool2d(relu(y + bias), 3, stride 2, padding 1)
  * in one pass over the channels-last convolution output y [N, H, W, C]; out [N, (H-1)/2+1, (W-1)/2+1, C].  Forward only. */
 int mono_bias_relu_maxpool_nhwc_f32(const float *y, const float *bias, float *out, int N, int H, int W, int C, void *stream);
+/* The tail of a FROZEN bottleneck (torchvision Bottleneck behind reference backbone.py:72-74, 83) in one pass:
+ * y[M, 256] = relu(relu(x[M, 64] + b_in) w[64, 256] + b_out + res[M, 256]) -- x the 3 x 3 convolution's raw output, w conv3's weight
+ * as [K][N] with bn3's scale folded in, rows = channels-last pixels.  K must be 64, N 256.  Forward only; y may alias res. */
+int mono_conv1x1_tail_f32(const float *x, const float *b_in, const float *w, const float *b_out, const float *res, float *y,
+                          long long M, int K, int N, void *stream);
 
 /* grad_in[i] = y[i] > 0 ? grad_out[i] : 0   (n % 4 == 0; grad_in may alias grad_out). */
 int mono_relu_grad_f32(const float *grad_out, const float *y, float *grad_in, long long n, void *stream);

@@ -10,7 +10,9 @@
 #include "ddn_loss.hip"
 #include "head_tail.hip"
 #include "lsap_device.hip"
+#include "conv1x1_fused.hip"
 #include <stdint.h>
+#include <algorithm>
 
 namespace mono {
 
@@ -513,6 +515,19 @@ int mono_bias_relu_maxpool_nhwc_f32(const float *y, const float *bias, float *ou
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   const long long n_items = (long long)N * OH * OW * (C / 4);
   mono::bias_relu_maxpool_kernel<<<mono::grid_for_vec(n_items), 256, 0, (hipStream_t)stream_>>>(y, bias, out, N, H, W, C / 4, OH, OW);
+  return (int)hipGetLastError();
+}
+
+// Y[M, 256] = relu(relu(X[M, 64] + b_in) W[64, 256] + b_out + R[M, 256]): the tail of a frozen bottleneck in one pass (conv1x1_fused.hip).
+// Rows are channels-last pixels; w is [K][N] (the 1 x 1 convolution's weight, transposed, norm scale folded in).  y may be res.
+int mono_conv1x1_tail_f32(const float *x, const float *b_in, const float *w, const float *b_out, const float *res, float *y,
+                          long long M, int K, int N, void *stream_) {
+  if (!x || !b_in || !w || !b_out || !res || !y) return -1;
+  if (M <= 0 || K != mono::kC1K || N != mono::kC1N) return -2;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)res & 15) || ((uintptr_t)y & 15)) return -2;
+  const long long strips = (M + 31) / 32, per_wg = mono::kC1Threads / 64;
+  const int grid = (int)std::min<long long>(512, (strips + per_wg - 1) / per_wg);
+  mono::conv1x1_tail_kernel<<<grid, mono::kC1Threads, 0, (hipStream_t)stream_>>>(x, b_in, w, b_out, res, y, M);
   return (int)hipGetLastError();
 }
 

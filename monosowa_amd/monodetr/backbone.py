@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..pointwise import (affine_relu, affine_relu_supported, bias_act, bias_act_fork, bias_relu_maxpool,
-                         bias_relu_maxpool_supported)
+                         bias_relu_maxpool_supported, conv1x1_tail, conv1x1_tail_supported)
 from .misc import NestedTensor
 from .position_encoding import build_position_encoding
 
@@ -144,6 +144,7 @@ def conv_bn(x, conv, bn, residual=None, relu=True):
 
 
 FOLD_DOWNSAMPLE_SHIFT = os.environ.get("MONOSOWA_FOLD_DS_SHIFT", "1") != "0"   # A/B switch (tools)
+FUSED_FROZEN_TAIL = os.environ.get("MONOSOWA_FUSED_FROZEN_TAIL", "1") != "0"   # A/B switch (tools)
 FUSED_STEM = os.environ.get("MONOSOWA_FUSED_STEM", "1") != "0"      # A/B switch (tools): 0 = in-place bias + ReLU pass, then F.max_pool2d
 
 
@@ -180,8 +181,11 @@ class Bottleneck(nn.Module):
         """x: a tensor, or the (a, b) pair a previous block returned (same values; one per consumer).  Returns a pair."""
         xa, xb = x if isinstance(x, tuple) else (x, x)
         out = conv_bn(xa, self.conv1, self.bn1)
-        out = conv_bn(out, self.conv2, self.bn2)
         n_out = getattr(self, "n_out", 2)
+        tail = self._frozen_tail(out, xb, n_out) if FUSED_FROZEN_TAIL else None
+        if tail is not None:
+            return tail
+        out = conv_bn(out, self.conv2, self.bn2)
         if self.downsample is None:
             return conv_bn_fork(out, self.conv3, self.bn3, xb, n_out)
         ds_conv, ds_bn = self.downsample[0], self.downsample[1]
@@ -193,6 +197,40 @@ class Bottleneck(nn.Module):
             return conv_bn_fork(out, self.conv3, self.bn3, identity, n_out, residual_bn=ds_bn)
         identity = conv_bn(xb, ds_conv, ds_bn, relu=False)
         return conv_bn_fork(out, self.conv3, self.bn3, identity, n_out)
+
+
+    def _frozen_tail(self, h1, xb, n_out):
+        """conv2 .. the block's output when the block is frozen (layer1: backbone.py:72-74 of the reference) and 64 -> 256 channels wide:
+        the 3 x 3 convolution runs bare, and its shift + ReLU, conv3, bn3's shift, the identity and the final ReLU are ONE pass
+        (pointwise.conv1x1_tail) instead of three over the largest activations of the network.  None: not applicable."""
+        bn2, bn3, ds = self.bn2, self.bn3, self.downsample
+        if self.conv3.weight.shape[:2] != (256, 64) or not h1.is_cuda or not isinstance(bn2, FrozenBatchNorm2d) \
+                or not isinstance(bn3, FrozenBatchNorm2d) or (ds is not None and not isinstance(ds[1], FrozenBatchNorm2d)):
+            return None
+        if torch.is_grad_enabled() and (h1.requires_grad or xb.requires_grad or self.conv2.weight.requires_grad
+                                        or self.conv3.weight.requires_grad or (ds is not None and ds[0].weight.requires_grad)):
+            return None
+        (scale2, shift2), (scale3, shift3) = bn2.scale_shift(), bn3.scale_shift()
+        w3 = folded_weight(self.conv3, bn3, scale3)                       # frozen: the folded weight is a kept tensor
+        cached = self.__dict__.get("_tail_w")
+        if cached is None or cached[0] is not w3:
+            with torch.no_grad():
+                cached = self.__dict__["_tail_w"] = (w3, w3.reshape(256, 64).t().contiguous())      # [in, out]
+        w_kn = cached[1]
+        conv2 = self.conv2
+        raw2 = F.conv2d(h1, folded_weight(conv2, bn2, scale2), None, conv2.stride, conv2.padding, conv2.dilation, conv2.groups)
+        if ds is None:
+            identity, b_out = xb, shift3
+        else:
+            identity = F.conv2d(xb, folded_weight(ds[0], ds[1], ds[1].scale_shift()[0]), None, ds[0].stride, ds[0].padding,
+                                ds[0].dilation, ds[0].groups)
+            b_out = _summed_shift(bn3, ds[1])
+        if not conv1x1_tail_supported(raw2, w_kn, identity):
+            # (not channels-last on this path, ...): the three passes on the tensors already computed
+            out = bias_act(raw2, shift2, None, True)
+            y = F.conv2d(out, w3, None, self.conv3.stride, self.conv3.padding, self.conv3.dilation, self.conv3.groups)
+            return (bias_act(y, b_out, identity, True),) * n_out
+        return (conv1x1_tail(raw2, shift2, w_kn, b_out, identity),) * n_out
 
 
 _DEPTHS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}

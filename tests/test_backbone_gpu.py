@@ -141,3 +141,24 @@ def test_frozen_stem_pass_equals_bias_relu_maxpool(N, C, H, W):
     assert torch.equal(got, want)
     y.requires_grad_(True)
     assert not PW.bias_relu_maxpool_supported(y, bias), "a stem that is trained keeps its autograd path"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W", [(2, 96, 320), (1, 5, 7), (3, 1, 1), (1, 33, 31)])
+def test_frozen_bottleneck_tail_equals_the_three_passes(N, H, W):
+    """mono_conv1x1_tail_f32 (bias + ReLU on the 3x3 convolution's output, the 1x1 convolution on the exact-f32 matrix cores, shift +
+    identity + ReLU: one pass) against the PyTorch ops evaluated in float64; pixel counts that are not a multiple of 32 included."""
+    from monosowa_amd import pointwise as PW
+    torch.manual_seed(N * 1000 + H + W)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    x = cl(torch.randn(N, 64, H, W, device="cuda"))
+    res = cl(torch.randn(N, 256, H, W, device="cuda"))
+    w = torch.randn(256, 64, 1, 1, device="cuda") / 8
+    b_in, b_out = torch.randn(64, device="cuda"), torch.randn(256, device="cuda")
+    w_kn = w.view(256, 64).t().contiguous()
+    assert PW.conv1x1_tail_supported(x, w_kn, res)
+    got = PW.conv1x1_tail(x, b_in, w_kn, b_out, res)
+    h = torch.relu(x.double() + b_in.double().view(1, -1, 1, 1))
+    want = torch.relu(F.conv2d(h, w.double()) + b_out.double().view(1, -1, 1, 1) + res.double())
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert (got.double() - want).abs().max() <= 1e-5 * want.abs().max()
