@@ -21,6 +21,8 @@ int mono_bias_relu_maxpool_nhwc_f32(const float *y, const float *bias, float *ou
  * as [K][N] with bn3's scale folded in, rows = channels-last pixels.  K must be 64, N 256.  Forward only; y may alias res. */
 int mono_conv1x1_tail_f32(const float *x, const float *b_in, const float *w, const float *b_out, const float *res, float *y,
                           long long M, int K, int N, void *stream);
+/* The head of a frozen bottleneck in one pass: y[M, 64] = relu(x[M, K] w[K, 64] + b_out), K = 64 or 256 (conv1 + bn1 + ReLU). */
+int mono_conv1x1_head_f32(const float *x, const float *w, const float *b_out, float *y, long long M, int K, int N, void *stream);
 
 /* grad_in[i] = y[i] > 0 ? grad_out[i] : 0   (n % 4 == 0; grad_in may alias grad_out). */
 int mono_relu_grad_f32(const float *grad_out, const float *y, float *grad_in, long long n, void *stream);

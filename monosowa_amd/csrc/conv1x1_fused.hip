@@ -71,4 +71,59 @@ __global__ __launch_bounds__(kC1Threads) void conv1x1_tail_kernel(const float *_
   }
 }
 
+// The head of a FROZEN bottleneck: H[m, n] = relu( sum_k X[m, k] W[k, n] + b[n] ),  K = 256 (64 for the first block), N = 64 --
+// conv1 + bn1 + ReLU in one pass over the block's input (the library's 1 x 1 convolution plus a bias + ReLU pass over its output
+// before).  Same mapping as the tail kernel, with the contraction in chunks of 64 (a lane holds 32 inputs of its pixel at a time:
+// k = (K / 2) kh + 32 chunk + s) and both 32-channel accumulators alive across the chunks.
+template <int K>
+__global__ __launch_bounds__(kC1Threads) void conv1x1_head_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                                  const float *__restrict__ b_out, float *__restrict__ y, long long M) {
+  constexpr int N = 64;
+  __shared__ float Ws[K * N];                            // W[k][n]
+  __shared__ float Bo[N];
+  for (int i = threadIdx.x; i < K * N / 4; i += kC1Threads)
+    reinterpret_cast<float4 *>(Ws)[i] = reinterpret_cast<const float4 *>(w)[i];
+  if (threadIdx.x < N) Bo[threadIdx.x] = b_out[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m_l = lane & 31, kh = lane >> 5;
+  const long long n_strips = (M + 31) / 32, strip_stride = (long long)gridDim.x * (kC1Threads / 64);
+  for (long long strip = (long long)blockIdx.x * (kC1Threads / 64) + wave; strip < n_strips; strip += strip_stride) {
+    const long long m = strip * 32 + m_l;
+    const bool live = m < M;
+    const long long mc = live ? m : M - 1;
+    const float *xp = x + mc * K + (K / 2) * kh;
+    c1_f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    float4 xv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xv[i] = *reinterpret_cast<const float4 *>(xp + 4 * i);
+#pragma unroll 1
+    for (int c = 0; c < K / 64; ++c) {
+      float xr[32];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { xr[4 * i] = xv[i].x; xr[4 * i + 1] = xv[i].y; xr[4 * i + 2] = xv[i].z; xr[4 * i + 3] = xv[i].w; }
+      if (c + 1 < K / 64) {                                // the next chunk's inputs: in flight under this chunk's products
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[i] = *reinterpret_cast<const float4 *>(xp + 32 * (c + 1) + 4 * i);
+      }
+      const float *wp = &Ws[((K / 2) * kh + 32 * c) * N + m_l];         // A operand: W[k][n = lane % 32 (+ 32)]
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[s * N], xr[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[s * N + 32], xr[s], acc1, 0, 0, 0);
+      }
+    }
+    float *yp = y + mc * N + 4 * kh;
+    if (live) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b0 = *reinterpret_cast<const float4 *>(&Bo[8 * g + 4 * kh]), b1 = *reinterpret_cast<const float4 *>(&Bo[32 + 8 * g + 4 * kh]);
+        *reinterpret_cast<float4 *>(yp + 8 * g) = make_float4(fmaxf(acc0[4 * g] + b0.x, 0.f), fmaxf(acc0[4 * g + 1] + b0.y, 0.f),
+                                                              fmaxf(acc0[4 * g + 2] + b0.z, 0.f), fmaxf(acc0[4 * g + 3] + b0.w, 0.f));
+        *reinterpret_cast<float4 *>(yp + 32 + 8 * g) = make_float4(fmaxf(acc1[4 * g] + b1.x, 0.f), fmaxf(acc1[4 * g + 1] + b1.y, 0.f),
+                                                                   fmaxf(acc1[4 * g + 2] + b1.z, 0.f), fmaxf(acc1[4 * g + 3] + b1.w, 0.f));
+      }
+    }
+  }
+}
+
 }  // namespace mono

@@ -531,6 +531,18 @@ int mono_conv1x1_tail_f32(const float *x, const float *b_in, const float *w, con
   return (int)hipGetLastError();
 }
 
+// H[M, 64] = relu(X[M, K] W[K, 64] + b): the head of a frozen bottleneck in one pass (conv1x1_fused.hip); K = 64 or 256, w is [K][64].
+int mono_conv1x1_head_f32(const float *x, const float *w, const float *b_out, float *y, long long M, int K, int N, void *stream_) {
+  if (!x || !w || !b_out || !y) return -1;
+  if (M <= 0 || (K != 64 && K != 256) || N != 64) return -2;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return -2;
+  const long long strips = (M + 31) / 32, per_wg = mono::kC1Threads / 64;
+  const int grid = (int)std::min<long long>(512, (strips + per_wg - 1) / per_wg);
+  if (K == 64) mono::conv1x1_head_kernel<64><<<grid, mono::kC1Threads, 0, (hipStream_t)stream_>>>(x, w, b_out, y, M);
+  else mono::conv1x1_head_kernel<256><<<grid, mono::kC1Threads, 0, (hipStream_t)stream_>>>(x, w, b_out, y, M);
+  return (int)hipGetLastError();
+}
+
 // y = relu(y + bias (+ residual)) in place, and mask[i] (one byte per 4 consecutive elements) = their sign bits.
 int mono_bias_relu_mask_f32(float *y, const float *bias, const float *residual, unsigned char *mask, long long rows, int C,
                             void *stream_) {

@@ -19,7 +19,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..pointwise import (affine_relu, affine_relu_supported, bias_act, bias_act_fork, bias_relu_maxpool,
-                         bias_relu_maxpool_supported, conv1x1_tail, conv1x1_tail_supported)
+                         bias_relu_maxpool_supported, conv1x1_head, conv1x1_head_supported, conv1x1_tail,
+                         conv1x1_tail_supported)
 from .misc import NestedTensor
 from .position_encoding import build_position_encoding
 
@@ -180,11 +181,11 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         """x: a tensor, or the (a, b) pair a previous block returned (same values; one per consumer).  Returns a pair."""
         xa, xb = x if isinstance(x, tuple) else (x, x)
-        out = conv_bn(xa, self.conv1, self.bn1)
         n_out = getattr(self, "n_out", 2)
-        tail = self._frozen_tail(out, xb, n_out) if FUSED_FROZEN_TAIL else None
-        if tail is not None:
-            return tail
+        whole = self._frozen_block(xa, xb, n_out) if FUSED_FROZEN_TAIL else None
+        if whole is not None:
+            return whole
+        out = conv_bn(xa, self.conv1, self.bn1)
         out = conv_bn(out, self.conv2, self.bn2)
         if self.downsample is None:
             return conv_bn_fork(out, self.conv3, self.bn3, xb, n_out)
@@ -199,17 +200,32 @@ class Bottleneck(nn.Module):
         return conv_bn_fork(out, self.conv3, self.bn3, identity, n_out)
 
 
-    def _frozen_tail(self, h1, xb, n_out):
-        """conv2 .. the block's output when the block is frozen (layer1: backbone.py:72-74 of the reference) and 64 -> 256 channels wide:
-        the 3 x 3 convolution runs bare, and its shift + ReLU, conv3, bn3's shift, the identity and the final ReLU are ONE pass
-        (pointwise.conv1x1_tail) instead of three over the largest activations of the network.  None: not applicable."""
-        bn2, bn3, ds = self.bn2, self.bn3, self.downsample
-        if self.conv3.weight.shape[:2] != (256, 64) or not h1.is_cuda or not isinstance(bn2, FrozenBatchNorm2d) \
+    def _frozen_block(self, xa, xb, n_out):
+        """The whole block when it is frozen (layer1: backbone.py:72-74 of the reference) and 64 -> 256 channels wide: conv1 + bn1 + ReLU
+        is one pass (pointwise.conv1x1_head), the 3 x 3 convolution runs bare, and its shift + ReLU, conv3, bn3's shift, the identity and
+        the final ReLU are ONE pass (pointwise.conv1x1_tail) instead of three over the largest activations of the network.
+        None: not applicable."""
+        bn1, bn2, bn3, ds = self.bn1, self.bn2, self.bn3, self.downsample
+        if self.conv3.weight.shape[:2] != (256, 64) or not xa.is_cuda or not isinstance(bn2, FrozenBatchNorm2d) \
                 or not isinstance(bn3, FrozenBatchNorm2d) or (ds is not None and not isinstance(ds[1], FrozenBatchNorm2d)):
             return None
-        if torch.is_grad_enabled() and (h1.requires_grad or xb.requires_grad or self.conv2.weight.requires_grad
-                                        or self.conv3.weight.requires_grad or (ds is not None and ds[0].weight.requires_grad)):
+        if torch.is_grad_enabled() and (xa.requires_grad or xb.requires_grad or self.conv1.weight.requires_grad
+                                        or self.conv2.weight.requires_grad or self.conv3.weight.requires_grad
+                                        or (ds is not None and ds[0].weight.requires_grad)):
             return None
+        h1 = None
+        conv1 = self.conv1
+        if isinstance(bn1, FrozenBatchNorm2d) and conv1.kernel_size == (1, 1) and conv1.stride == (1, 1) and conv1.weight.shape[0] == 64:
+            scale1, shift1 = bn1.scale_shift()
+            w1 = folded_weight(conv1, bn1, scale1)
+            cached = self.__dict__.get("_head_w")
+            if cached is None or cached[0] is not w1:
+                with torch.no_grad():
+                    cached = self.__dict__["_head_w"] = (w1, w1.reshape(64, -1).t().contiguous())           # [in, out]
+            if conv1x1_head_supported(xa, cached[1]):
+                h1 = conv1x1_head(xa, cached[1], shift1)
+        if h1 is None:
+            h1 = conv_bn(xa, conv1, bn1)
         (scale2, shift2), (scale3, shift3) = bn2.scale_shift(), bn3.scale_shift()
         w3 = folded_weight(self.conv3, bn3, scale3)                       # frozen: the folded weight is a kept tensor
         cached = self.__dict__.get("_tail_w")

@@ -162,3 +162,20 @@ def test_frozen_bottleneck_tail_equals_the_three_passes(N, H, W):
     want = torch.relu(F.conv2d(h, w.double()) + b_out.double().view(1, -1, 1, 1) + res.double())
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert (got.double() - want).abs().max() <= 1e-5 * want.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,N,H,W", [(256, 2, 96, 320), (64, 2, 96, 320), (256, 1, 5, 7), (64, 3, 1, 1)])
+def test_frozen_bottleneck_head_equals_conv_bias_relu(K, N, H, W):
+    """mono_conv1x1_head_f32 (conv1 + bn1 shift + ReLU in one pass, K = 64 / 256 -> 64 channels) against float64."""
+    from monosowa_amd import pointwise as PW
+    torch.manual_seed(K + N + H + W)
+    x = torch.randn(N, K, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = torch.randn(64, K, 1, 1, device="cuda") / K ** 0.5
+    b = torch.randn(64, device="cuda")
+    w_kn = w.view(64, K).t().contiguous()
+    assert PW.conv1x1_head_supported(x, w_kn)
+    got = PW.conv1x1_head(x, w_kn, b)
+    want = torch.relu(F.conv2d(x.double(), w.double()) + b.double().view(1, -1, 1, 1))
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert (got.double() - want).abs().max() <= 1e-5 * want.abs().max()
