@@ -12,12 +12,12 @@ def cat(n):
         return "gemm (hipBLASLt)"
     if "batched_transpose" in n:
         return "MIOpen layout transpose"
-    if any(k in n for k in ("igemm", "Conv", "conv", "miopen", "gtc", "Sp3Asm", "xdlops")):
-        return "conv (MIOpen/CK)"
     if "attn::" in n:
         return "attention (this repo)"
     if "mono::" in n:
         return "pointwise / norms (this repo)"
+    if any(k in n for k in ("igemm", "Conv", "conv", "miopen", "gtc", "Sp3Asm", "xdlops")):
+        return "conv (MIOpen/CK)"
     if "attn_fwd" in n or "bwd_kernel" in n:
         return "attention (aotriton)"
     if "layer_norm" in n or "GammaBeta" in n or "GradInput" in n or "roupNorm" in n or "RowwiseMoments" in n or "group_norm" in n:
