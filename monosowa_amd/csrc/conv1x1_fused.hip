@@ -13,7 +13,7 @@
 // (lane = (pixel m, half kh): the 32 contiguous floats X[m][32 kh ..], i.e. MFMA step s contracts k = s and k = 32 + s), W sits in LDS
 // for the whole workgroup (64 KB), and the product is evaluated TRANSPOSED per 32-channel block -- D[n][m] = sum_k W[k][n] X[m][k],
 // v_mfma_f32_32x32x2_f32, exact f32 -- so that a lane ends up with 4 CONSECUTIVE channels of its pixel per accumulator quad: the
-// epilogue reads R and writes Y as float4.  One accumulator (16 registers) is live at a time.
+// epilogue reads R and writes Y as float4.  One accumulator (16 registers) is live at a time (142 VGPRs).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -49,12 +49,20 @@ __global__ __launch_bounds__(kC1Threads) void conv1x1_tail_kernel(const float *_
     }
     const float *rp = res + mc * kC1N + 4 * kh;
     float *yp = y + mc * kC1N + 4 * kh;
+    // the identity's 16 values of a channel block are requested one block AHEAD: the wait in front of their use then leaves the
+    // previous block's stores in flight (loads and stores return through one in-order counter); 304 -> 276 us at [16, 96, 320]
+    float4 r_next[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) r_next[g] = *reinterpret_cast<const float4 *>(rp + 8 * g);
 #pragma unroll 1
     for (int nb = 0; nb < kC1N / 32; ++nb) {
-      // the identity's 16 values of this channel block: requested before the products, consumed behind them
       float4 r4[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) r4[g] = *reinterpret_cast<const float4 *>(rp + nb * 32 + 8 * g);
+      for (int g = 0; g < 4; ++g) r4[g] = r_next[g];
+      if (nb + 1 < kC1N / 32) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) r_next[g] = *reinterpret_cast<const float4 *>(rp + (nb + 1) * 32 + 8 * g);
+      }
       c1_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const float *wp = &Ws[(32 * kh) * kC1N + nb * 32 + m_l];          // A operand: W[k = 32 kh + s][n = 32 nb + lane % 32]
 #pragma unroll
