@@ -21,6 +21,10 @@ int mono_bias_relu_maxpool_nhwc_f32(const float *y, const float *bias, float *ou
  * as [K][N] with bn3's scale folded in, rows = channels-last pixels.  K must be 64, N 256.  Forward only; y may alias res. */
 int mono_conv1x1_tail_f32(const float *x, const float *b_in, const float *w, const float *b_out, const float *res, float *y,
                           long long M, int K, int N, void *stream);
+/* The tail of a stage's FIRST frozen bottleneck: as mono_conv1x1_tail_f32 with the identity = the stride-1 1 x 1 downsample convolution of
+ * the block's input x0 [M, 64] (wd [64][256], its norm's scale folded in, its shift inside b_out), evaluated into the same accumulator. */
+int mono_conv1x1_tail_ds_f32(const float *x, const float *b_in, const float *w, const float *x0, const float *wd, const float *b_out,
+                             float *y, long long M, int K, int N, void *stream);
 /* The head of a frozen bottleneck in one pass: y[M, 64] = relu(x[M, K] w[K, 64] + b_out), K = 64 or 256 (conv1 + bn1 + ReLU). */
 int mono_conv1x1_head_f32(const float *x, const float *w, const float *b_out, float *y, long long M, int K, int N, void *stream);
 

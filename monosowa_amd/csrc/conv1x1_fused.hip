@@ -79,6 +79,60 @@ __global__ __launch_bounds__(kC1Threads) void conv1x1_tail_kernel(const float *_
   }
 }
 
+// The tail of the FIRST frozen bottleneck of a stage, whose identity is a 1 x 1 downsample convolution of the block's input:
+//     Y[m, n] = relu( sum_k relu(X[m, k] + b_in[k]) W[k, n]  +  sum_k X0[m, k] Wd[k, n]  +  b_out[n] ),      K = K0 = 64, N = 256
+// -- the downsample product joins the accumulator instead of being written (503 MB at [16, 96, 320]) by a convolution of its own and read
+// back as the identity.  Both weight matrices sit in LDS (128 KB: one 16-wave workgroup per CU).
+constexpr int kC1Threads2 = 1024;
+__global__ __launch_bounds__(kC1Threads2) void conv1x1_tail_ds_kernel(const float *__restrict__ x, const float *__restrict__ b_in,
+                                                                      const float *__restrict__ w, const float *__restrict__ x0,
+                                                                      const float *__restrict__ wd, const float *__restrict__ b_out,
+                                                                      float *__restrict__ y, long long M) {
+  __shared__ float Ws[2 * kC1K * kC1N];                  // W[k][n], then Wd[k][n]
+  __shared__ float Bi[kC1K], Bo[kC1N];
+  for (int i = threadIdx.x; i < kC1K * kC1N / 4; i += kC1Threads2) {
+    reinterpret_cast<float4 *>(Ws)[i] = reinterpret_cast<const float4 *>(w)[i];
+    reinterpret_cast<float4 *>(Ws + kC1K * kC1N)[i] = reinterpret_cast<const float4 *>(wd)[i];
+  }
+  if (threadIdx.x < kC1K) Bi[threadIdx.x] = b_in[threadIdx.x];
+  if (threadIdx.x < kC1N) Bo[threadIdx.x] = b_out[threadIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m_l = lane & 31, kh = lane >> 5;
+  const long long n_strips = (M + 31) / 32, strip_stride = (long long)gridDim.x * (kC1Threads2 / 64);
+  for (long long strip = (long long)blockIdx.x * (kC1Threads2 / 64) + wave; strip < n_strips; strip += strip_stride) {
+    const long long m = strip * 32 + m_l;
+    const bool live = m < M;
+    const long long mc = live ? m : M - 1;
+    float xr[32], x0r[32];
+    const float *xp = x + mc * kC1K + 32 * kh, *x0p = x0 + mc * kC1K + 32 * kh;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 v = *reinterpret_cast<const float4 *>(xp + 4 * i), b = *reinterpret_cast<const float4 *>(&Bi[32 * kh + 4 * i]);
+      const float4 u = *reinterpret_cast<const float4 *>(x0p + 4 * i);
+      xr[4 * i] = fmaxf(v.x + b.x, 0.f); xr[4 * i + 1] = fmaxf(v.y + b.y, 0.f);
+      xr[4 * i + 2] = fmaxf(v.z + b.z, 0.f); xr[4 * i + 3] = fmaxf(v.w + b.w, 0.f);
+      x0r[4 * i] = u.x; x0r[4 * i + 1] = u.y; x0r[4 * i + 2] = u.z; x0r[4 * i + 3] = u.w;
+    }
+    float *yp = y + mc * kC1N + 4 * kh;
+#pragma unroll 1
+    for (int nb = 0; nb < kC1N / 32; ++nb) {
+      c1_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float *wp = &Ws[(32 * kh) * kC1N + nb * 32 + m_l], *wdp = wp + kC1K * kC1N;
+#pragma unroll
+      for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[s * kC1N], xr[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wdp[s * kC1N], x0r[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bo = *reinterpret_cast<const float4 *>(&Bo[nb * 32 + 8 * g + 4 * kh]);
+        const float4 o = make_float4(fmaxf(acc[4 * g] + bo.x, 0.f), fmaxf(acc[4 * g + 1] + bo.y, 0.f),
+                                     fmaxf(acc[4 * g + 2] + bo.z, 0.f), fmaxf(acc[4 * g + 3] + bo.w, 0.f));
+        if (live) *reinterpret_cast<float4 *>(yp + nb * 32 + 8 * g) = o;
+      }
+    }
+  }
+}
+
 // The head of a FROZEN bottleneck: H[m, n] = relu( sum_k X[m, k] W[k, n] + b[n] ),  K = 256 (64 for the first block), N = 64 --
 // conv1 + bn1 + ReLU in one pass over the block's input (the library's 1 x 1 convolution plus a bias + ReLU pass over its output
 // before).  Same mapping as the tail kernel, with the contraction in chunks of 64 (a lane holds 32 inputs of its pixel at a time:

@@ -531,6 +531,19 @@ int mono_conv1x1_tail_f32(const float *x, const float *b_in, const float *w, con
   return (int)hipGetLastError();
 }
 
+// Y[M, 256] = relu(relu(X[M, 64] + b_in) W[64, 256] + X0[M, 64] Wd[64, 256] + b_out): the tail of a stage's FIRST frozen bottleneck, the
+// 1 x 1 downsample convolution of the block's input x0 (stride 1) evaluated into the same accumulator (conv1x1_fused.hip).
+int mono_conv1x1_tail_ds_f32(const float *x, const float *b_in, const float *w, const float *x0, const float *wd, const float *b_out,
+                             float *y, long long M, int K, int N, void *stream_) {
+  if (!x || !b_in || !w || !x0 || !wd || !b_out || !y) return -1;
+  if (M <= 0 || K != mono::kC1K || N != mono::kC1N) return -2;
+  if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)x0 & 15) || ((uintptr_t)wd & 15) || ((uintptr_t)y & 15)) return -2;
+  const long long strips = (M + 31) / 32, per_wg = mono::kC1Threads2 / 64;
+  const int grid = (int)std::min<long long>(256, (strips + per_wg - 1) / per_wg);
+  mono::conv1x1_tail_ds_kernel<<<grid, mono::kC1Threads2, 0, (hipStream_t)stream_>>>(x, b_in, w, x0, wd, b_out, y, M);
+  return (int)hipGetLastError();
+}
+
 // H[M, 64] = relu(X[M, K] W[K, 64] + b): the head of a frozen bottleneck in one pass (conv1x1_fused.hip); K = 64 or 256, w is [K][64].
 int mono_conv1x1_head_f32(const float *x, const float *w, const float *b_out, float *y, long long M, int K, int N, void *stream_) {
   if (!x || !w || !b_out || !y) return -1;

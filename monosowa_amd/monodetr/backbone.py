@@ -20,7 +20,7 @@ from torch import nn
 
 from ..pointwise import (affine_relu, affine_relu_supported, bias_act, bias_act_fork, bias_relu_maxpool,
                          bias_relu_maxpool_supported, conv1x1_head, conv1x1_head_supported, conv1x1_tail,
-                         conv1x1_tail_supported)
+                         conv1x1_tail_ds, conv1x1_tail_ds_supported, conv1x1_tail_supported)
 from .misc import NestedTensor
 from .position_encoding import build_position_encoding
 
@@ -145,6 +145,7 @@ def conv_bn(x, conv, bn, residual=None, relu=True):
 
 
 FOLD_DOWNSAMPLE_SHIFT = os.environ.get("MONOSOWA_FOLD_DS_SHIFT", "1") != "0"   # A/B switch (tools)
+FUSED_FROZEN_DS = os.environ.get("MONOSOWA_FUSED_FROZEN_DS", "1") != "0"       # A/B switch (tools)
 FUSED_FROZEN_TAIL = os.environ.get("MONOSOWA_FUSED_FROZEN_TAIL", "1") != "0"   # A/B switch (tools)
 FUSED_STEM = os.environ.get("MONOSOWA_FUSED_STEM", "1") != "0"      # A/B switch (tools): 0 = in-place bias + ReLU pass, then F.max_pool2d
 
@@ -235,6 +236,15 @@ class Bottleneck(nn.Module):
         w_kn = cached[1]
         conv2 = self.conv2
         raw2 = F.conv2d(h1, folded_weight(conv2, bn2, scale2), None, conv2.stride, conv2.padding, conv2.dilation, conv2.groups)
+        if ds is not None and FUSED_FROZEN_DS and ds[0].kernel_size == (1, 1) and ds[0].stride == (1, 1) and ds[0].weight.shape[:2] == (256, 64):
+            # the stage's first block: the downsample product of the block's input joins conv3's accumulator (no identity tensor)
+            wd = folded_weight(ds[0], ds[1], ds[1].scale_shift()[0])
+            cached_d = self.__dict__.get("_tail_wd")
+            if cached_d is None or cached_d[0] is not wd:
+                with torch.no_grad():
+                    cached_d = self.__dict__["_tail_wd"] = (wd, wd.reshape(256, 64).t().contiguous())
+            if conv1x1_tail_ds_supported(raw2, w_kn, xb, cached_d[1]):
+                return (conv1x1_tail_ds(raw2, shift2, w_kn, xb, cached_d[1], _summed_shift(bn3, ds[1])),) * n_out
         if ds is None:
             identity, b_out = xb, shift3
         else:

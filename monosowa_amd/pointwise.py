@@ -9,7 +9,7 @@ import torch
 from ._lib import raw_stream, on_device
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
-SYMBOLS = ("mono_bias_act_f32", "mono_bias_relu_maxpool_nhwc_f32", "mono_conv1x1_tail_f32", "mono_conv1x1_head_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
+SYMBOLS = ("mono_bias_act_f32", "mono_bias_relu_maxpool_nhwc_f32", "mono_conv1x1_tail_f32", "mono_conv1x1_tail_ds_f32", "mono_conv1x1_head_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
            "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32", "mono_relu_dropout_bwd_colsum_f32", "mono_sum_slices_f32", "mono_colsum_any_blocks", "mono_colsum_any_f32", "mono_relu_grad_mask3_f32", "mono_lsap_match_flat_f32")
@@ -32,6 +32,8 @@ def load():
         lib.mono_conv1x1_tail_f32.argtypes = [P, P, P, P, P, P, LL, I, I, P]
         lib.mono_conv1x1_head_f32.restype = I
         lib.mono_conv1x1_head_f32.argtypes = [P, P, P, P, LL, I, I, P]
+        lib.mono_conv1x1_tail_ds_f32.restype = I
+        lib.mono_conv1x1_tail_ds_f32.argtypes = [P, P, P, P, P, P, P, LL, I, I, P]
         lib.mono_relu_grad_f32.restype = I
         lib.mono_relu_grad_f32.argtypes = [P, P, P, LL, P]
         lib.mono_bias_relu_mask_f32.restype = I
@@ -285,6 +287,24 @@ def conv1x1_tail(x, b_in, w_kn, b_out, residual):
                                             out.data_ptr(), M, 64, 256, raw_stream())
     if code:
         raise RuntimeError("mono_conv1x1_tail_f32 failed with code %d" % code)
+    return out
+
+
+def conv1x1_tail_ds_supported(x, w_kn, x0, wd_kn):
+    ok_w = lambda w: tuple(w.shape) == (64, 256) and w.is_contiguous() and w.data_ptr() % 16 == 0 and not (torch.is_grad_enabled() and w.requires_grad)
+    return _nhwc_ok(x) and _nhwc_ok(x0) and x.size(1) == 64 and x0.shape == x.shape and ok_w(w_kn) and ok_w(wd_kn) \
+        and not (torch.is_grad_enabled() and (x.requires_grad or x0.requires_grad))
+
+
+def conv1x1_tail_ds(x, b_in, w_kn, x0, wd_kn, b_out):
+    """``relu(conv1x1(relu(x + b_in), w) + conv1x1(x0, wd) + b_out)`` in one pass; weights as [in, out]."""
+    N, _, H, W = x.shape
+    out = torch.empty((N, 256, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with on_device(x.device):
+        code = load().mono_conv1x1_tail_ds_f32(x.data_ptr(), b_in.data_ptr(), w_kn.data_ptr(), x0.data_ptr(), wd_kn.data_ptr(), b_out.data_ptr(),
+                                               out.data_ptr(), N * H * W, 64, 256, raw_stream())
+    if code:
+        raise RuntimeError("mono_conv1x1_tail_ds_f32 failed with code %d" % code)
     return out
 
 

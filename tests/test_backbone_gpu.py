@@ -179,3 +179,23 @@ def test_frozen_bottleneck_head_equals_conv_bias_relu(K, N, H, W):
     want = torch.relu(F.conv2d(x.double(), w.double()) + b.double().view(1, -1, 1, 1))
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert (got.double() - want).abs().max() <= 1e-5 * want.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W", [(2, 96, 320), (1, 5, 7), (3, 1, 1)])
+def test_frozen_first_bottleneck_tail_with_downsample_equals_the_passes(N, H, W):
+    """mono_conv1x1_tail_ds_f32: conv3 of relu(x + b) and the downsample convolution of the block's input in one accumulator,
+    shift + ReLU -- against float64."""
+    from monosowa_amd import pointwise as PW
+    torch.manual_seed(N * 77 + H + W)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    x, x0 = cl(torch.randn(N, 64, H, W, device="cuda")), cl(torch.randn(N, 64, H, W, device="cuda"))
+    w, wd = torch.randn(256, 64, 1, 1, device="cuda") / 8, torch.randn(256, 64, 1, 1, device="cuda") / 8
+    b_in, b_out = torch.randn(64, device="cuda"), torch.randn(256, device="cuda")
+    w_kn, wd_kn = w.view(256, 64).t().contiguous(), wd.view(256, 64).t().contiguous()
+    assert PW.conv1x1_tail_ds_supported(x, w_kn, x0, wd_kn)
+    got = PW.conv1x1_tail_ds(x, b_in, w_kn, x0, wd_kn, b_out)
+    h = torch.relu(x.double() + b_in.double().view(1, -1, 1, 1))
+    want = torch.relu(F.conv2d(h, w.double()) + F.conv2d(x0.double(), wd.double()) + b_out.double().view(1, -1, 1, 1))
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert (got.double() - want).abs().max() <= 1e-5 * want.abs().max()
