@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_BYTES_PER_S = 8.0e12      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MATRIX_PEAK_FLOPS = 157.3e12   # MI355X_MICROARCH.md: FP32 vector / matrix peak (v_mfma_f32_32x32x2_f32: the exact-f32 path the step computes in)
 
 
 def log(msg):
@@ -71,6 +72,8 @@ def parse():
                     help="WxH of the RAW camera images (config 4, 'reference-resampled' variant: 1408x376): the resident batch holds them "
                          "at that size and every step first resamples them to --resolution on the device, which is what the reference's "
                          "loader does on the host for every image (kitti_dataset.py:37,202-206); the model then runs at --resolution")
+    ap.add_argument("--no-step-roofline", action="store_true", help="skip the FLOP-counting extra step (roofline.step)")
+    ap.add_argument("--no-offsets-probe", action="store_true", help="skip the trained-offsets MSDA probe (roofline.trained_offsets)")
     ap.add_argument("--no-miopen-db", action="store_true",
                     help="ignore the shipped MIOpen find results (monosowa_amd/miopen_db) and use MIOpen's heuristics")
     return ap.parse_args()
@@ -290,6 +293,72 @@ def cpu_baseline(args):
         return out
     finally:
         F.MSDeformAttnFunction = saved
+
+
+def count_dense_flops(step, batch):
+    """Dense FLOPs of ONE step, counted where they are issued (not from a formula of the model): every aten mm / addmm / bmm /
+    convolution / convolution_backward the step dispatches -- forward and the backward parts that exist (no gradient below layer2:
+    convolution_backward is counted with the output mask it is called with) -- plus what this repo's own dense kernels report
+    (monosowa_amd/flops.py: HIP attention forward / backward, the frozen bottlenecks' fused 1 x 1 convolutions).  MSDA's bilinear
+    gather / scatter is not a dense contraction and is not in this number (it has its own HBM roofline above).  One extra,
+    untimed step."""
+    import torch
+    from torch.utils.flop_counter import FlopCounterMode
+    from monosowa_amd import flops as own
+    own.start()
+    try:
+        with FlopCounterMode(display=False) as fc:
+            step(batch)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        lib = {str(getattr(k, "__name__", k)).replace("aten.", ""): int(v) for k, v in fc.get_flop_counts().get("Global", {}).items()}
+    finally:
+        mine = own.stop()
+    return lib, mine
+
+
+def step_roofline(step, batch, ms_per_step):
+    """``roofline.step``: the step's dense FLOPs / its time / the f32 matrix peak (north_star: throughput "as fraction of the HBM/MFMA
+    roofline"; the MSDA object above is the HBM side)."""
+    try:
+        lib, mine = count_dense_flops(step, batch)
+    except Exception as e:                                 # the headline must not depend on a counting mode
+        return {"bound": "mfma", "error": "%s: %s" % (type(e).__name__, e)}
+    total = sum(lib.values()) + sum(mine.values())
+    ach = total / (ms_per_step * 1e-3)
+    return {"bound": "mfma", "dense_flops_per_step": total, "library_ops": lib, "own_kernels": mine,
+            "achieved": ach / 1e12, "peak": F32_MATRIX_PEAK_FLOPS / 1e12, "unit": "TFLOP/s", "frac": ach / F32_MATRIX_PEAK_FLOPS,
+            "what": "aten mm/addmm/bmm/convolution(+backward) counted by torch.utils.flop_counter over one extra step, plus the HIP "
+                    "attention and fused 1x1-convolution kernels' own counts; / ms_per_step / 157.3 TFLOP/s (f32 matrix peak)"}
+
+
+def trained_offsets_probe(batch_size, resolution, device, spec="normal:2", iters=20):
+    """``roofline.trained_offsets``: the encoder-shape operator pair on sampling offsets that LEFT the module's initial pattern --
+    N(0, 2 px) of isotropic drift at every level, the 'normal:2' row of tools/msda_fused_bench.py --sweep
+    (profiles/r0*_msda_offset_sweep.json) -- because the bench's own model is a few optimizer steps old and its offsets still sit
+    on that pattern: the line's headline kernel time is the best case.  Same entry points, same batch size, HIP-event timed."""
+    import torch
+    tools = os.path.join(ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import msda_fused_bench as FB
+    from monosowa_amd import MultiScaleDeformableAttention as MSDA
+    FB.set_resolution("%dx%d" % resolution)
+    value, shapes, lsi, proj, ref, go = FB.make(batch_size, "enc", spec, device)
+    B, S, M, D = value.shape
+    _, loc, attw = MSDA.ms_deform_attn_fused_forward_merged_save(value, shapes, lsi, proj, ref)
+    t_f = FB.timeit(lambda: MSDA.ms_deform_attn_fused_forward_merged_save(value, shapes, lsi, proj, ref), 5, iters)
+    t_b = FB.timeit(lambda: MSDA.ms_deform_attn_fused_backward_merged_saved(value, shapes, lsi, loc, attw, ref, go), 5, iters)
+    dims = (B, S, M, D, 4, S, 4)
+    out = {"offsets": spec + " (N(0, sigma px) isotropic drift around the query's own pixel, every level)",
+           "msda_bwd_ms": t_b, "msda_fwd_ms": t_f,
+           "bwd_frac": msda_alg_bytes("bwd", dims) / (t_b * 1e-3) / HBM_PEAK_BYTES_PER_S,
+           "fwd_frac": msda_alg_bytes("fwd", dims) / (t_f * 1e-3) / HBM_PEAK_BYTES_PER_S,
+           "what": "tools/msda_fused_bench.py's operator pair at B = %d, S = Lq = %d, %d launches each, back to back (micro-benchmark, not in the step)"
+                   % (B, S, iters)}
+    del value, proj, ref, go, loc, attw
+    torch.cuda.empty_cache()
+    return out
 
 
 class _StdoutGuard:
@@ -522,6 +591,13 @@ def main():
     global_batch = args.batch * world * accum
     value = global_batch * args.steps / elapsed
 
+    # ---- roofline.step: the step's dense FLOPs counted over ONE extra (untimed) step; every rank runs it (a step is a set of collectives)
+    step_roof = None
+    if train and not args.no_step_roofline and accum == 1:
+        step_roof = step_roofline(step, batch, elapsed / args.steps * 1e3)
+        log("roofline.step: %s" % (("%.1f TFLOP/step, %.1f %% of the f32 matrix peak" % (step_roof["dense_flops_per_step"] / 1e12, 100 * step_roof["frac"]))
+                                   if "frac" in step_roof else step_roof.get("error")))
+
     # ---- DataLoader-fed leg ("separately, with a synthetic DataLoader"): the same K train steps, every batch
     # coming out of build_dataloader(SyntheticKITTI) -- worker processes, collate, pinned host buffers, non-blocking H2D copies --
     # the way the reference loop is fed (lib/helpers/dataloader_helper.py:21-34: 4 workers; trainer_helper.py:121-127: per-key
@@ -598,6 +674,13 @@ def main():
                                            "achieved": tot_bytes / (tot_ms * 1e-3) / 1e9,
                                            "frac": tot_bytes / (tot_ms * 1e-3) / HBM_PEAK_BYTES_PER_S, "target_frac": 0.60},
                     "all_msda_kernels": kernels}
+        if step_roof is not None:
+            roofline["step"] = step_roof
+        if train and world == 1 and not args.no_offsets_probe and k["Lq"] == dims_S(timer):
+            try:
+                roofline["trained_offsets"] = trained_offsets_probe(args.batch, (W, H), device)
+            except Exception as e:
+                roofline["trained_offsets"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     net_ = model.module if hasattr(model, "module") else model
     eval_queries_cfg = int(getattr(net_, "num_queries", 50))

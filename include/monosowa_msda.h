@@ -81,7 +81,11 @@ int msda_options_stamp(void);
 
 /* Diagnostics for tests: reads AND resets a device-side event counter of the current device (synchronises the device).
  * "scatter_overflow_rounds": extra bucket rounds of the self-attention backward's cell scatter (a cell received more points
- * from one batch of candidates than its bucket holds).  Returns 0, MSDA_E_UNSUPPORTED for an unknown name, or a hipError_t. */
+ * from one batch of candidates than its bucket holds).
+ * "scan_candidates", "scan_delivering", "scan_point_tests", "scan_delivered", "scan_points_skipped": the cell scatter's scan census --
+ * (query, level, tile) candidates looked at / with a point in the tile, sampling points whose tap was evaluated / that landed in a
+ * cell of the tile, points skipped by the per-point reach test; counted only by measurement builds of the library
+ * (-DMSDA_ROWS_COUNT=1), 0 otherwise.  Returns 0, MSDA_E_UNSUPPORTED for an unknown name, or a hipError_t. */
 int msda_debug_counter(const char *name, unsigned long long *out);
 
 /* Bytes of device scratch the backward needs for this geometry (0 if none); the caller allocates

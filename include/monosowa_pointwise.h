@@ -18,7 +18,10 @@ int mono_bias_act_f32(float *y, const float *bias, const float *residual, long l
 int mono_bias_relu_maxpool_nhwc_f32(const float *y, const float *bias, float *out, int N, int H, int W, int C, void *stream);
 /* The tail of a FROZEN bottleneck (torchvision Bottleneck behind reference backbone.py:72-74, 83) in one pass:
  * y[M, 256] = relu(relu(x[M, 64] + b_in) w[64, 256] + b_out + res[M, 256]) -- x the 3 x 3 convolution's raw output, w conv3's weight
- * as [K][N] with bn3's scale folded in, rows = channels-last pixels.  K must be 64, N 256.  Forward only; y may alias res. */
+ * as [K][N] with bn3's scale folded in, rows = channels-last pixels.  K must be 64, N 256.  Forward only.  y must NOT alias res, x or
+ * x0 (the kernels read res one channel block ahead of the y stores through __restrict__ pointers): an aliased call returns -2.
+ * gfx950 only: the three conv1x1 kernels keep their weight matrices in more than 64 KB of static LDS (65 KB tail / head, 129 KB tail_ds;
+ * CDNA4 has 160 KB per CU) -- the library is built for --offload-arch=gfx950 and nothing else. */
 int mono_conv1x1_tail_f32(const float *x, const float *b_in, const float *w, const float *b_out, const float *res, float *y,
                           long long M, int K, int N, void *stream);
 /* The tail of a stage's FIRST frozen bottleneck: as mono_conv1x1_tail_f32 with the identity = the stride-1 1 x 1 downsample convolution of

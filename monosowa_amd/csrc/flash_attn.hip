@@ -173,12 +173,17 @@ __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void fwd_kernel(const Args a) 
     for (int v = 1; v < 16; ++v) mx = fmaxf(mx, fmaxf(s0[v], s1[v]));
     mx = fmaxf(mx, xhalf(mx));
     const float m_new = fmaxf(m, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    // MASK: while every key seen so far is padded the running maximum is -inf, and (-inf) - (-inf) would turn alpha and every
+    // probability into NaN for the rest of the row (a leading tile of padded keys in front of valid ones: torch gives finite
+    // output).  Subtracting 0 instead leaves alpha = 0 on an empty accumulator and p = exp2(-inf) = 0; a row whose keys are ALL
+    // padded still ends with lsum = 0 and comes out as NaN, like torch's softmax.
+    const float m_sub = (MASK && m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m - m_sub);
     float rs = 0.f;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
-      s0[v] = __builtin_amdgcn_exp2f(s0[v] - m_new);
-      s1[v] = __builtin_amdgcn_exp2f(s1[v] - m_new);
+      s0[v] = __builtin_amdgcn_exp2f(s0[v] - m_sub);
+      s1[v] = __builtin_amdgcn_exp2f(s1[v] - m_sub);
       rs += s0[v] + s1[v];
     }
     lsum = lsum * alpha + rs;

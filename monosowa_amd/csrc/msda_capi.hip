@@ -658,10 +658,21 @@ int msda_options_stamp(void) {
 
 int msda_debug_counter(const char *name, unsigned long long *out) {
   if (!name || !out) return MSDA_E_NULLPTR;
-  if (std::string(name) != "scatter_overflow_rounds") return MSDA_E_UNSUPPORTED;
+  const std::string n(name);
+  static const char *const scan_names[5] = {"scan_candidates", "scan_delivering", "scan_point_tests", "scan_delivered", "scan_points_skipped"};
+  int scan = -1;
+  for (int i = 0; i < 5; ++i)
+    if (n == scan_names[i]) scan = i;
+  if (n != "scatter_overflow_rounds" && scan < 0) return MSDA_E_UNSUPPORTED;
   const unsigned long long zero = 0;
   // (blocking copies on the null stream: every launch issued before this call has finished when the value is read)
   hipError_t e = hipDeviceSynchronize();
+  if (scan >= 0) {
+    // the cell scatter's scan census: counted by measurement builds only (-DMSDA_ROWS_COUNT=1, msda_scatter_rows.hip); 0 otherwise
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(msda::g_rows_scan), sizeof(zero), scan * sizeof(zero));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(msda::g_rows_scan), &zero, sizeof(zero), scan * sizeof(zero));
+    return (int)e;
+  }
   if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(msda::g_rows_overflow_rounds), sizeof(zero));
   if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(msda::g_rows_overflow_rounds), &zero, sizeof(zero));
   return (int)e;

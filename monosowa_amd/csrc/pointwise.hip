@@ -525,6 +525,7 @@ int mono_conv1x1_tail_f32(const float *x, const float *b_in, const float *w, con
   if (!x || !b_in || !w || !b_out || !res || !y) return -1;
   if (M <= 0 || K != mono::kC1K || N != mono::kC1N) return -2;
   if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)res & 15) || ((uintptr_t)y & 15)) return -2;
+  if ((const float *)y == res || (const float *)y == x) return -2;      // __restrict__ operands; res is read a channel block ahead of the y stores
   const long long strips = (M + 31) / 32, per_wg = mono::kC1Threads / 64;
   const int grid = (int)std::min<long long>(512, (strips + per_wg - 1) / per_wg);
   mono::conv1x1_tail_kernel<<<grid, mono::kC1Threads, 0, (hipStream_t)stream_>>>(x, b_in, w, b_out, res, y, M);
@@ -538,6 +539,7 @@ int mono_conv1x1_tail_ds_f32(const float *x, const float *b_in, const float *w, 
   if (!x || !b_in || !w || !x0 || !wd || !b_out || !y) return -1;
   if (M <= 0 || K != mono::kC1K || N != mono::kC1N) return -2;
   if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)x0 & 15) || ((uintptr_t)wd & 15) || ((uintptr_t)y & 15)) return -2;
+  if ((const float *)y == x || (const float *)y == x0) return -2;
   const long long strips = (M + 31) / 32, per_wg = mono::kC1Threads2 / 64;
   const int grid = (int)std::min<long long>(256, (strips + per_wg - 1) / per_wg);
   mono::conv1x1_tail_ds_kernel<<<grid, mono::kC1Threads2, 0, (hipStream_t)stream_>>>(x, b_in, w, x0, wd, b_out, y, M);

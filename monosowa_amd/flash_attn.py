@@ -6,6 +6,7 @@ import os
 
 import torch
 
+from . import flops
 from ._lib import raw_stream, on_device
 from .token_linear import linear as fast_linear
 
@@ -74,10 +75,12 @@ def _mask_ptr(mask, B, Lk):
     """key padding mask -> pointer of a contiguous [B, Lk] byte tensor (0 for None); non-zero / True = padded key"""
     if mask is None:
         return 0, None
-    if mask.dtype != torch.uint8:
-        mask = mask.to(torch.uint8) if mask.dtype != torch.bool else mask.view(torch.uint8)
+    if mask.dtype not in (torch.bool, torch.uint8) or tuple(mask.shape) != (B, Lk) or not mask.is_cuda:
+        raise RuntimeError("flash_attn: key_padding_mask must be a [B, Lk] bool / uint8 tensor on the GPU (True = padding); "
+                           "additive float masks take the nn.MultiheadAttention path (mha_supported)")
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
     mask = mask.contiguous()
-    assert tuple(mask.shape) == (B, Lk) and mask.is_cuda, "key_padding_mask must be a [B, Lk] tensor on the GPU"
     return mask.data_ptr(), mask
 
 
@@ -95,6 +98,7 @@ def forward(q, k, v, scale, p, seed, key_padding_mask=None, keep_bits=None):
     o = torch.empty((B, H, Lq, 32), dtype=torch.float32, device=q.device)
     lse = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
     mp, keep = _mask_ptr(key_padding_mask, B, k.size(2))
+    flops.attention_forward(B, H, Lq, k.size(2))
     with on_device(q.device):
         code = load().mono_attn_forward_keep_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, keep_bits.data_ptr() if keep_bits is not None else 0,
                                                  o.data_ptr(), lse.data_ptr(), B, H, Lq, k.size(2), 32, _strides(q), _strides(k), _strides(v),
@@ -127,6 +131,7 @@ def backward(q, k, v, o, lse, dout, scale, p, seed, key_padding_mask=None, keep_
     delta = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
     assert dout.stride() == o.stride()
     mp, keep = _mask_ptr(key_padding_mask, B, Lk)
+    flops.attention_backward(B, H, Lq, Lk)
     with on_device(q.device):
         code = load().mono_attn_backward_keep_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, keep_bits.data_ptr() if keep_bits is not None else 0,
                                                   o.data_ptr(), lse.data_ptr(), dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
@@ -147,6 +152,7 @@ class _Attention(torch.autograd.Function):
         lse = torch.empty((B * H, Lq), dtype=torch.float32, device=q.device)
         mp, mask = _mask_ptr(mask, B, k.size(2))
         bits = keep_bits_like(q, k, p) if SAVE_KEEP_BITS else None      # 1 bit per score, kept until the backward
+        flops.attention_forward(B, H, Lq, k.size(2))
         with on_device(q.device):
             code = load().mono_attn_forward_keep_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, bits.data_ptr() if bits is not None else 0,
                                                      o.data_ptr(), lse.data_ptr(), B, H, Lq, k.size(2), 32, _strides(q), _strides(k),
@@ -223,7 +229,16 @@ def mha_forward(mha, query, key, value, key_padding_mask=None):
     return fast_linear(o.permute(2, 0, 1, 3).reshape(Lq, B, E), mha.out_proj.weight, mha.out_proj.bias)
 
 
-def mha_supported(mha, query, key, value):
+def mask_supported(mask, B, Lk, device):
+    """What the kernels read as a key padding mask: a [B, Lk] bool / uint8 tensor on the queries' device (non-zero = padding).
+    nn.MultiheadAttention also takes an ADDITIVE float mask (0 / -inf): that one, a mask of another shape or on another device
+    stays with the module path instead of being misread as bytes."""
+    return mask is None or (torch.is_tensor(mask) and mask.dtype in (torch.bool, torch.uint8) and tuple(mask.shape) == (B, Lk)
+                            and mask.device == device)
+
+
+def mha_supported(mha, query, key, value, key_padding_mask=None):
     return (query.is_cuda and query.dtype == torch.float32 and mha.embed_dim == mha.num_heads * 32 and not mha.batch_first
             and mha._qkv_same_embed_dim and mha.in_proj_bias is not None and mha.bias_k is None and not mha.add_zero_attn
-            and query.dim() == 3 and key.shape == value.shape and query.size(1) * mha.num_heads <= 65535)
+            and query.dim() == 3 and key.shape == value.shape and query.size(1) * mha.num_heads <= 65535
+            and mask_supported(key_padding_mask, query.size(1), key.size(0), query.device))

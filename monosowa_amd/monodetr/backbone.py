@@ -87,7 +87,9 @@ def folded_weight(conv, bn, scale):
     w = conv.weight
     if (w.requires_grad and torch.is_grad_enabled()) or _PARAM_EPOCH is None:
         return w * scale.view(-1, 1, 1, 1)
-    key = (w.data_ptr(), w._version, scale.data_ptr(), scale._version, _PARAM_EPOCH[0])
+    # (a FROZEN weight is in no optimizer's parameter groups -- the raw-pointer AdamW never touches it -- so its folded product
+    # outlives optimizer steps: with the epoch in its key the frozen stem / layer1 were re-folded and re-transposed every train step)
+    key = (w.data_ptr(), w._version, scale.data_ptr(), scale._version, _PARAM_EPOCH[0] if w.requires_grad else -1)
     cached = conv.__dict__.get("_folded")
     if cached is None or cached[0] != key:
         with torch.no_grad():
@@ -107,6 +109,55 @@ def _summed_shift(bn, other):
     return cached[1]
 
 
+# Trainable 1 x 1 convolutions (stride 1: conv1 / conv3 of every bottleneck of layer2-4) as plain GEMMs on the channels-last pixel matrix
+# [N H W, C] -- forward X W^T, input gradient dY W, weight gradient dY^T X through the split-K path of token_linear (K = N H W = 122,880 at
+# layer2) -- instead of MIOpen's implicit-GEMM solvers, whose split-K variants ("gkgs") come with a zero-fill launch in front of their
+# atomics.  A/B switch (tools/ab_step.py monosowa_amd.monodetr.backbone.CONV1X1_GEMM 0 1); bit 1: forward + input gradient, bit 2: weight gradient.
+CONV1X1_GEMM = int(os.environ.get("MONOSOWA_CONV1X1_GEMM", "0"))
+
+
+class _Conv1x1Gemm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, mode):
+        N, C, H, W = x.shape
+        ctx.save_for_backward(x, w)
+        ctx.mode = mode
+        if mode & 1:
+            y2 = torch.mm(x.permute(0, 2, 3, 1).reshape(-1, C), w.reshape(w.shape[0], C).t())
+            return y2.view(N, H, W, w.shape[0]).permute(0, 3, 1, 2)
+        return F.conv2d(x, w)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from ..token_linear import weight_grad
+        x, w = ctx.saved_tensors
+        N, C, H, W = x.shape
+        K = w.shape[0]
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gy2 = gy.permute(0, 2, 3, 1).reshape(-1, K)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            if ctx.mode & 1:
+                gx = torch.mm(gy2, w.reshape(K, C)).view(N, H, W, C).permute(0, 3, 1, 2)
+            else:
+                gx = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1, (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            if ctx.mode & 2:
+                gw = weight_grad(gy2, x.permute(0, 2, 3, 1).reshape(-1, C)).view(K, C, 1, 1).contiguous(memory_format=torch.channels_last)
+            else:
+                gw = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+        return gx, gw, None
+
+
+def conv2d(x, w, conv):
+    """``F.conv2d(x, w)`` with the module's geometry; a trainable stride-1 1 x 1 convolution on a channels-last GPU tensor may take
+    the GEMM path (CONV1X1_GEMM)."""
+    if CONV1X1_GEMM and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and x.is_cuda and x.dim() == 4 \
+            and torch.is_grad_enabled() and w.requires_grad and x.is_contiguous(memory_format=torch.channels_last) and x.dtype == torch.float32:
+        return _Conv1x1Gemm.apply(x, w, CONV1X1_GEMM)
+    return F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
 def conv_bn_fork(x, conv, bn, residual, n_out=2, residual_bn=None):
     """``conv_bn(x, conv, bn, residual)`` returned as a pair for its two consumers (next block's first convolution and
     identity branch): their gradients are added inside the fused ReLU backward (``pointwise.bias_act_fork``).
@@ -116,7 +167,7 @@ def conv_bn_fork(x, conv, bn, residual, n_out=2, residual_bn=None):
         scale, shift = bn.scale_shift()
         if residual_bn is not None:
             shift = _summed_shift(bn, residual_bn)
-        y = F.conv2d(x, folded_weight(conv, bn, scale), None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        y = conv2d(x, folded_weight(conv, bn, scale), conv)
         return bias_act_fork(y, shift, residual, n_out)
     assert residual_bn is None
     out = conv_bn(x, conv, bn, residual)
@@ -132,11 +183,11 @@ def conv_bn(x, conv, bn, residual=None, relu=True):
         if AFFINE_IN_KERNEL and relu and residual is None and conv.weight.requires_grad and torch.is_grad_enabled() and x.is_cuda:
             # trainable convolution without residual: raw weights, the BN affine map runs inside the ReLU kernels
             # (forward y*scale+shift, backward grad*mask*scale) -- no weight multiply per step, none in the backward
-            y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            y = conv2d(x, conv.weight, conv)
             if affine_relu_supported(y, scale):
                 return affine_relu(y, scale, shift)
             return torch.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
-        y = F.conv2d(x, folded_weight(conv, bn, scale), None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        y = conv2d(x, folded_weight(conv, bn, scale), conv)
         return bias_act(y, shift, residual, relu)
     y = bn(conv(x))
     if residual is not None:

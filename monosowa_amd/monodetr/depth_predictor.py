@@ -32,7 +32,7 @@ class DepthEncoderLayer(nn.Module):
 
     def forward(self, src, src_key_padding_mask, pos):
         qk = src if pos is None else src + pos
-        if mha_supported(self.self_attn, qk, qk, src):
+        if mha_supported(self.self_attn, qk, qk, src, src_key_padding_mask):
             attn = mha_forward(self.self_attn, qk, qk, src, key_padding_mask=src_key_padding_mask)          # HIP fp32 attention core
         else:
             attn = self.self_attn(qk, qk, value=src, key_padding_mask=src_key_padding_mask, need_weights=False)[0]

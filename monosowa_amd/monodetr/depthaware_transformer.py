@@ -293,7 +293,7 @@ class DepthAwareDecoderLayer(nn.Module):
                 src_padding_mask, depth_pos_embed, mask_depth, value=None):
         # depth cross attention over the stride-16 depth-aware tokens
         tq = tgt.transpose(0, 1)
-        if mha_supported(self.cross_attn_depth, tq, depth_pos_embed, depth_pos_embed):
+        if mha_supported(self.cross_attn_depth, tq, depth_pos_embed, depth_pos_embed, mask_depth):
             # (the key padding mask of the depth tokens, depthaware_transformer.py:456-459, goes into the HIP kernels)
             tgt2 = mha_forward(self.cross_attn_depth, tq, depth_pos_embed, depth_pos_embed, key_padding_mask=mask_depth).transpose(0, 1)
         else:

@@ -186,7 +186,7 @@ class HungarianMatcher(nn.Module):
             self._status.zero_()
             if word & 1:
                 raise ValueError("cost matrix is infeasible")
-            # bit 2: a problem exceeded the device solver's tables and got placeholder identity pairs instead of an assignment
+            # bit 1 (value 2): a problem exceeded the device solver's tables and got placeholder identity pairs instead of an assignment
             raise ValueError("assignment problem exceeds the device solver's capacity (identity pairs were emitted)")
 
     @torch.no_grad()

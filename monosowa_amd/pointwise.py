@@ -6,6 +6,7 @@ import os
 import numpy as np
 import torch
 
+from . import flops
 from ._lib import raw_stream, on_device
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
@@ -282,6 +283,7 @@ def conv1x1_tail(x, b_in, w_kn, b_out, residual):
     """``relu(conv1x1(relu(x + b_in), w) + b_out + residual)`` in one pass; w_kn = the convolution's weight as [in, out]."""
     out = torch.empty_like(residual)
     M = x.numel() // 64
+    flops.conv1x1(M, 64, 256)
     with on_device(x.device):
         code = load().mono_conv1x1_tail_f32(x.data_ptr(), b_in.data_ptr(), w_kn.data_ptr(), b_out.data_ptr(), residual.data_ptr(),
                                             out.data_ptr(), M, 64, 256, raw_stream())
@@ -300,6 +302,7 @@ def conv1x1_tail_ds(x, b_in, w_kn, x0, wd_kn, b_out):
     """``relu(conv1x1(relu(x + b_in), w) + conv1x1(x0, wd) + b_out)`` in one pass; weights as [in, out]."""
     N, _, H, W = x.shape
     out = torch.empty((N, 256, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    flops.conv1x1(N * H * W, 128, 256)
     with on_device(x.device):
         code = load().mono_conv1x1_tail_ds_f32(x.data_ptr(), b_in.data_ptr(), w_kn.data_ptr(), x0.data_ptr(), wd_kn.data_ptr(), b_out.data_ptr(),
                                                out.data_ptr(), N * H * W, 64, 256, raw_stream())
@@ -317,6 +320,7 @@ def conv1x1_head(x, w_kn, b_out):
     """``relu(conv1x1(x, w) + b_out)`` in one pass (64 output channels); w_kn = the convolution's weight as [in, out]."""
     N, K, H, W = x.shape
     out = torch.empty((N, 64, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    flops.conv1x1(N * H * W, K, 64)
     with on_device(x.device):
         code = load().mono_conv1x1_head_f32(x.data_ptr(), w_kn.data_ptr(), b_out.data_ptr(), out.data_ptr(), N * H * W, K, 64, raw_stream())
     if code:

@@ -98,6 +98,15 @@ def test_attention_library_exports_declared_symbols():
         flash_attn.attention(q, q, q)
     mha = torch.nn.MultiheadAttention(64, 2)
     assert not flash_attn.mha_supported(mha, torch.randn(5, 1, 64), torch.randn(5, 1, 64), torch.randn(5, 1, 64))
+    # key padding masks the kernels read: [B, Lk] bool / uint8 on the queries' device; an additive float mask (0 / -inf), another
+    # shape or another device keeps the module path
+    dev = torch.device("cpu")
+    assert flash_attn.mask_supported(None, 2, 7, dev)
+    assert flash_attn.mask_supported(torch.zeros(2, 7, dtype=torch.bool), 2, 7, dev)
+    assert flash_attn.mask_supported(torch.zeros(2, 7, dtype=torch.uint8), 2, 7, dev)
+    assert not flash_attn.mask_supported(torch.zeros(2, 7), 2, 7, dev)
+    assert not flash_attn.mask_supported(torch.zeros(7, 2, dtype=torch.bool), 2, 7, dev)
+    assert not flash_attn.mask_supported(torch.zeros(2, 7, dtype=torch.bool, device="meta"), 2, 7, dev)
 
 
 def test_kitti_library_exports_declared_symbols():

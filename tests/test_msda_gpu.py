@@ -1115,6 +1115,36 @@ def test_masked_attention_core_matches_fp64_and_zeroes_the_padded_keys_gradients
     assert (k.grad[dead] == 0).all() and (v.grad[dead] == 0).all()
 
 
+def test_masked_attention_with_whole_key_tiles_padded_in_front_of_valid_keys_matches_fp64():
+    """A 64-key tile whose keys are ALL padded in FRONT of valid keys (and one in the middle): the running maximum is still -inf when
+    that tile is seen, and (-inf) - (-inf) must not poison the row (torch gives finite output).  Forward and backward
+    against an fp64 masked softmax; the model's own right / bottom padding never produces this, general key_padding_mask callers can."""
+    from monosowa_amd import flash_attn as FA
+    torch.manual_seed(9)
+    B, H, Lq, Lk = 3, 8, 150, 300
+    q, k, v = (torch.randn(B, H, L, 32, device="cuda", requires_grad=True) for L in (Lq, Lk, Lk))
+    mask = torch.zeros(B, Lk, dtype=torch.bool, device="cuda")
+    mask[0, :64] = True                       # the leading tile
+    mask[1, :130] = True                      # two leading tiles and a bit
+    mask[1, 192:256] = True                   # and a whole tile in the middle
+    mask[2, 64:128] = True                    # a middle tile only
+    go = torch.randn(B, H, Lq, 32, device="cuda")
+    out = FA.attention(q, k, v, key_padding_mask=mask)
+    out.backward(go)
+    assert torch.isfinite(out).all()
+    qd, kd, vd = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    s = (qd @ kd.transpose(-1, -2)) / 32 ** 0.5
+    ref = torch.softmax(s.masked_fill(mask[:, None, None, :], float("-inf")), -1) @ vd
+    ref.backward(go.double())
+    assert (out.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    for name, a, b in (("dq", q.grad, qd.grad), ("dk", k.grad, kd.grad), ("dv", v.grad, vd.grad)):
+        assert torch.isfinite(a).all(), name
+        assert (a.double() - b).abs().max() <= 1e-5 * b.abs().max(), name
+    # with dropout the same rows stay finite (the keep-bit and the re-hashing backward)
+    o2 = FA.attention(q.detach(), k.detach(), v.detach(), dropout_p=0.1, seed=5, key_padding_mask=mask)
+    assert torch.isfinite(o2).all()
+
+
 def test_masked_attention_with_every_key_of_one_image_padded_is_nan_there_like_torch_and_exact_elsewhere():
     """A batch element whose keys are ALL padded has no softmax (torch: NaN rows, F.multi_head_attention_forward's masked_fill(-inf) ->
     softmax); the kernels say the same instead of inventing a value, and the other batch elements do not notice."""
