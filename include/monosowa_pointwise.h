@@ -54,6 +54,9 @@ int mono_affine_relu_grad_f32(const float *grad, const unsigned char *mask, cons
 /* grad_in = (grad_a + grad_b) * (y > 0): ReLU backward of a tensor with two consumers (ResNet block output -> next
  * convolution and identity branch, backbone.py:64-82 of the reference's torchvision ResNet) in one pass. */
 int mono_relu_grad2_f32(const float *grad_a, const float *grad_b, const float *y, float *grad_in, long long n, void *stream);
+/* the same for three consumers: grad_in[i] = y[i] > 0 ? (grad_a[i] + grad_b[i]) + grad_c[i] : 0 */
+int mono_relu_grad3_f32(const float *grad_a, const float *grad_b, const float *grad_c, const float *y, float *grad_in, long long n,
+                        void *stream);
 
 /* y = LayerNorm_256(x + dropout_p(z)) over rows of C = 256 channels (reference: the post-norm residual blocks of
  * depthaware_transformer.py:339-354,500-515).  The keep mask is a hash of (seed, element index): the backward

@@ -16,12 +16,13 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 ARCH = "gfx950"
 
-# library name -> translation unit; every file under csrc/ and include/ is part of every library's source hash
+# library name -> (translation unit, extra link flags); every file under csrc/ and include/ is part of every library's source hash
 LIBS = {
     "libmonosowa_msda.so": ("msda_capi.hip", []),
     "libmonosowa_pointwise.so": ("pointwise.hip", []),
     "libmonosowa_attn.so": ("flash_attn.hip", []),
     "libmonosowa_kitti.so": ("rotate_iou.hip", []),
+    "libmonosowa_gemm.so": ("gemm_lt.cpp", ["-lhipblaslt"]),      # host code only: the hipBLASLt shim (include/monosowa_gemm.h)
 }
 
 FLAGS = ["-O3", "--offload-arch=" + ARCH, "-munsafe-fp-atomics", "-fPIC", "-shared", "-std=c++17",
@@ -93,9 +94,9 @@ def build_all(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     built = build_host_libs(force, verbose)
     want = source_hash(["hipcc"] + FLAGS)
-    for name, (tu, _deps) in LIBS.items():
+    for name, (tu, link) in LIBS.items():
         out = os.path.join(LIBDIR, name)
-        _build_one(out, [hipcc()] + FLAGS + ["-o", out, os.path.join(CSRC, tu)], want, force, verbose)
+        _build_one(out, [hipcc()] + FLAGS + ["-o", out, os.path.join(CSRC, tu)] + link, want, force, verbose)
         built.append(out)
     _stamp_commit()
     return built

@@ -88,11 +88,16 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __bu
 // depth_predictor/transformer.py:57-60: key_padding_mask -> -inf before the softmax, torch.nn.functional.multi_head_attention_forward).
 // The tile's keys carry an additive bias in LDS, 0 or -inf (also for the keys past Lk of a ragged last tile): one ds_read_b128 per
 // four scores.  A query whose keys are ALL masked comes out as NaN, as it does from torch's softmax.
+// Waves per SIMD by instance: the training instance of the shipped pipeline (dropout + keep bits, no padding) and the inference
+// instances fit the 128 VGPRs of 4 waves; dropout together with the pad-bit test or with nothing to amortise the hash against does not
+// (4 - 6 registers spilled inside the tile loop), so those are compiled for 3 waves (170 VGPRs): no instance spills.
+template <bool DROP, bool MASK, bool BITS>
+constexpr int fwd_waves() { return (DROP && (MASK || !BITS)) ? 3 : ATTN_FWD_WAVES; }
 template <bool DROP, bool MASK = false, bool BITS = false>       // BITS (with DROP): also store the keep bits (Args::keep)
-__global__ __launch_bounds__(256, ATTN_FWD_WAVES) void fwd_kernel(const Args a) {
+__global__ __launch_bounds__(256, (fwd_waves<DROP, MASK, BITS>())) void fwd_kernel(const Args a) {
   __shared__ float Ks[2][kTileK * kKStride];
   __shared__ float Vs[2][kTileK * kVStride];
-  __shared__ float Bs[2][MASK ? kTileK : 4];
+  __shared__ unsigned long long Ms[2];                 // MASK: bit k = key k of the tile takes no part (padded, or past Lk)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
   const int q = blockIdx.x * kBlockQ + wave * 32 + r;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void fwd_kernel(const Args a) 
   const float *kb = a.k + b * a.sk.b + hd * a.sk.h, *vb = a.v + b * a.sv.b + hd * a.sv.h;
   const int n_tiles = (a.Lk + kTileK - 1) / kTileK;
   float4 kr[2], vr[2];
-  float br = 0.f;
+  unsigned long long pad_next = 0;                      // MASK: the tile being loaded, as wave 0 sees it (a wave-uniform value: SGPRs)
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -117,9 +122,9 @@ __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void fwd_kernel(const Args a) 
       kr[j] = ok ? ld4(kb + (long long)key * a.sk.t + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       vr[j] = ok ? ld4(vb + (long long)key * a.sv.t + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (MASK && threadIdx.x < kTileK) {
-      const int key = kt * kTileK + threadIdx.x;
-      br = (key < a.Lk && a.kmask[(long long)b * a.Lk + key] == 0) ? 0.f : -INFINITY;
+    if (MASK && wave == 0) {
+      const int key = kt * kTileK + lane;
+      pad_next = __ballot(!(key < a.Lk && a.kmask[(long long)b * a.Lk + key] == 0));
     }
   };
   auto store_tile = [&](int buf) {
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void fwd_kernel(const Args a) 
       *reinterpret_cast<float4 *>(&Ks[buf][row * kKStride + c]) = kr[j];
       *reinterpret_cast<float4 *>(&Vs[buf][row * kVStride + c]) = vr[j];
     }
-    if (MASK && threadIdx.x < kTileK) Bs[buf][threadIdx.x] = br;
+    if (MASK && threadIdx.x == 0) Ms[buf] = pad_next;
   };
   load_tile(0);
   store_tile(0);
@@ -154,11 +159,17 @@ __global__ __launch_bounds__(256, ATTN_FWD_WAVES) void fwd_kernel(const Args a) 
     }
     const int key0 = kt * kTileK + 4 * h;                // + 8 (v >> 2) + (v & 3) (+ 32 for s1)
     if (MASK) {
+      // The tile's 64 pad bits come through the scalar path: one uniform LDS read, two readfirstlanes, and per score a bit test of a
+      // lane word -- 2 VGPRs.  (Round 4 kept a float bias per key in LDS and added it with eight ds_read_b128 per tile: at the 128-VGPR
+      // cap of 4 waves per SIMD the masked instances spilled 8 - 13 registers.)
+      const unsigned long long tm = Ms[buf];
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)tm), hi = __builtin_amdgcn_readfirstlane((unsigned)(tm >> 32));
+      const unsigned w0 = lo >> (4 * h), w1 = hi >> (4 * h);       // this lane's keys: bit 8 (v >> 2) + (v & 3)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 b0 = ld4(&Bs[buf][4 * h + 8 * g]), b1 = ld4(&Bs[buf][32 + 4 * h + 8 * g]);
-        s0[4 * g] += b0.x; s0[4 * g + 1] += b0.y; s0[4 * g + 2] += b0.z; s0[4 * g + 3] += b0.w;
-        s1[4 * g] += b1.x; s1[4 * g + 1] += b1.y; s1[4 * g + 2] += b1.z; s1[4 * g + 3] += b1.w;
+      for (int v = 0; v < 16; ++v) {
+        const int bit = 8 * (v >> 2) + (v & 3);
+        if ((w0 >> bit) & 1u) s0[v] = -INFINITY;
+        if ((w1 >> bit) & 1u) s1[v] = -INFINITY;
       }
     } else if (kt == n_tiles - 1 && (a.Lk & (kTileK - 1))) {
 #pragma unroll
@@ -392,6 +403,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dkdv_kernel(const Arg
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.H, hd = bh % a.H;
   const int key = blockIdx.x * kBlockQ + wave * 32 + r;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);          // the wave's number as a scalar (for the epilogue)
   const int kc_ = min(key, a.Lk - 1);
   const float *kp = a.k + b * a.sk.b + hd * a.sk.h + (long long)kc_ * a.sk.t + 16 * h;
   const float *vp = a.v + b * a.sv.b + hd * a.sv.h + (long long)kc_ * a.sv.t + 16 * h;
@@ -530,9 +542,13 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dkdv_kernel(const Arg
     if (qt + 1 < n_tiles) store_tile(buf ^ 1);
     __syncthreads();
   }
-  if (key < a.Lk) {
-    float *dkp = a.dk + b * a.sdk.b + hd * a.sdk.h + (long long)key * a.sdk.t + 4 * h;
-    float *dvp = a.dv + b * a.sdv.b + hd * a.sdv.h + (long long)key * a.sdv.t + 4 * h;
+  // (the lane's key and half re-derived from the lane counter and a scalar wave number: kept in a VGPR across the tile loop, `key`
+  // was the one register the 170-VGPR build spilled)
+  const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int key_e = (int)blockIdx.x * kBlockQ + wave_s * 32 + (lane_e & 31), h_e = lane_e >> 5;
+  if (key_e < a.Lk) {
+    float *dkp = a.dk + b * a.sdk.b + hd * a.sdk.h + (long long)key_e * a.sdk.t + 4 * h_e;
+    float *dvp = a.dv + b * a.sdv.b + hd * a.sdv.h + (long long)key_e * a.sdv.t + 4 * h_e;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       *reinterpret_cast<float4 *>(dkp + 8 * g) = make_float4(dk[4 * g] * a.scale, dk[4 * g + 1] * a.scale, dk[4 * g + 2] * a.scale, dk[4 * g + 3] * a.scale);

@@ -159,7 +159,10 @@ bool window_tiling(const int64_t *shapes_host, const int64_t *lsi_host, int halo
   if (it == cache.end()) {
     msda::WinGeom g{};
     // the backward keeps a block of grad_out rows per wave behind the windows
-    const bool ok = msda::choose_window_tiling(shapes_host, lsi_host, halo, bwd ? msda::kWinMaxRowsBwd : msda::kWinMaxRows, g);
+    int fy = 0, fx = 0;
+    if (const char *e = std::getenv("MSDA_WIN_TILES")) std::sscanf(e, "%dx%d", &fy, &fx);      // measurement runs: "NYxNX"
+    const bool ok = msda::choose_window_tiling(shapes_host, lsi_host, halo, bwd ? msda::kWinMaxRowsBwd : msda::kWinMaxRows, g, fy, fx,
+                                               bwd ? 18000.0 : 400.0);
     it = cache.emplace(key, std::make_pair(ok, g)).first;
   }
   out = it->second.second;

@@ -256,15 +256,9 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
         l4 = make_float4(add_rn(in.rf.x, div_rc(l4.x, ref_scale.x, ref_rc.x)), add_rn(in.rf.y, div_rc(l4.y, ref_scale.y, ref_rc.y)),
                          add_rn(in.rf.x, div_rc(l4.z, ref_scale.x, ref_rc.x)), add_rn(in.rf.y, div_rc(l4.w, ref_scale.y, ref_rc.y)));
     }
-    // backward with the row-tile scatter: the points it covers (everything else is "far": atomics below) -- with the directional plan the
-    // bounds of each of this lane's two POINTS (msda_plan.h: near_p; the scatter applies the same test)
-    DirBounds near_b[2];
-    near_b[0].ylo = near_b[0].xlo = (short)-far_reach; near_b[0].yhi = near_b[0].xhi = (short)far_reach;
-    near_b[1] = near_b[0];
-    if (BWD && plans) {
-      near_b[0] = MSDA_POINT_BOUNDS ? plans[it.m].near_p[l_mine][2 * (sub & 1)] : plans[it.m].near[l_mine];
-      near_b[1] = MSDA_POINT_BOUNDS ? plans[it.m].near_p[l_mine][2 * (sub & 1) + 1] : near_b[0];
-    }
+    DirBounds near_b;        // backward with the row-tile scatter: the points it covers (everything else is "far": atomics below)
+    near_b.ylo = near_b.xlo = (short)-far_reach; near_b.yhi = near_b.xhi = (short)far_reach;
+    if (BWD && plans) near_b = plans[it.m].near[l_mine];
     unsigned far_bits = 0;   // this lane's two points: bits 2 (sub & 1), 2 (sub & 1) + 1 of the unit's byte
     if (BWD && far_mask && live)
       far_bits = (unsigned)far_mask[((long long)(it.b * M + it.m) * 4 + l_mine) * S + q_u] >> (2 * (sub & 1));
@@ -310,7 +304,7 @@ __global__ __launch_bounds__(BWD ? kWinThreadsBwd : kWinThreads, BWD ? (kWinThre
       }
       if (BWD && far_mask) {
         if (live && tp.valid && (far_bits >> k2 & 1)) far_points |= 1 << k2;
-      } else if (BWD && far_reach >= 0 && live && tp.valid && !inside_bounds(tp.h_low - in.cf_y, tp.w_low - in.cf_x, near_b[k2]))
+      } else if (BWD && far_reach >= 0 && live && tp.valid && !inside_bounds(tp.h_low - in.cf_y, tp.w_low - in.cf_x, near_b))
         far_points |= 1 << k2;
       // Bank parity: a ds_read_b128 is served in groups of 16 lanes over 16 sixteen-byte bank slots; a 128-byte row covers the
       // 8 slots of its parity, and in every group exactly two lanes share a slot position (rot ^ s) -- lanes 16 apart.  The

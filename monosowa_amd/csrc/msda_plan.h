@@ -31,12 +31,6 @@ constexpr float kPlanSigmas = MSDA_PLAN_SIGMAS;
 constexpr int kPlanClip = 64;            // |d| is clipped here before it enters the statistics
 constexpr int kPlanSamples = 256;        // sampled queries per batch element (of Lq): >= 16 k points per (head, level) at B = 16
 
-// Round 5 experiment, measurement builds only (-DMSDA_POINT_BOUNDS=1; default off: DESIGN 4.0b): statistics, near-bounds and the
-// scatter's reach test per (head, level, POINT) instead of per (head, level).  The scan then delivers 89 % of the points it
-// evaluates (64 % before) -- and the backward is 2 % SLOWER: the scan's loads and taps are not what the scatter waits for.
-#ifndef MSDA_POINT_BOUNDS
-#define MSDA_POINT_BOUNDS 0
-#endif
 struct DirBounds { short ylo, yhi, xlo, xhi; };      // inclusive bounds of d
 #if defined(__HIPCC__)
 __device__ __forceinline__ bool inside_bounds(int dy, int dx, const DirBounds b) {
@@ -64,21 +58,15 @@ struct RowItem {
   int c_begin, c_end;                      // this chunk's candidates within the tile's scan list
   int cand_off;                            // the tile's scan list: table[head * cand_total + cand_off ...)
   int pad1;
-  DirBounds near;                          // the head's near-bounds at this level (the union of the four points' bounds)
-  DirBounds near_p[4];                     // ... and per sampling POINT of the level: near <=> inside the point's own bounds
+  DirBounds near;                          // the head's near-bounds at this level
+  int pad2[2];
 };
 constexpr int kPlanMaxItems = 768;         // per head; a pyramid with more items keeps the isotropic host plan
 
 // Everything the kernels read for one head.
 struct HeadPlan {
   DirBounds win[kWinLevels];               // the measured bounds (mean +- kPlanSigmas sigma, within 16 pixels of the mean): diagnostics
-  DirBounds near[kWinLevels];              // scatter scan bounds (clamped to the host's reach): the union of near_p over the level's points
-  // Per (level, POINT): the module initialises point p of head m at (p + 1) pixels along the head's direction
-  // (ms_deform_attn.py:106-114) and training moves that cluster rather than smearing it -- measured in the train step bench.py
-  // times (tools/debug/offset_stats.py): sigma 0.02 - 0.09 px per point against 1.1 px over a level's four points -- so a
-  // point's own bounds are 1 - 2 pixels wide where the level's are 5.  near <=> the footprint's top-left pixel lies inside the
-  // POINT's bounds (scatter and gather kernels apply the same test); the scan region of a tile stays the union.
-  DirBounds near_p[kWinLevels][4];
+  DirBounds near[kWinLevels];              // scatter bounds (clamped to the host's reach): near <=> inside
   // row-tile scatter
   int n_chunks[4], order[4], first_item[5];
   int n_items;

@@ -161,7 +161,6 @@ __global__ __launch_bounds__(256) void dir_plan_kernel(const DirStats *__restric
   // (round 3 also fitted per-head LDS windows here -- 80 shrink-and-refit trips -- which no kernel read: directional windows on the
   // round-3 tiling measured the same time as isotropic ones; removed together with the HeadPlan fields that held them)
   if (tid < 4) { hp.win[tid] = s_win[tid]; hp.near[tid] = s_near[tid]; }
-  if (tid < 16) hp.near_p[tid >> 2][tid & 3] = s_near[tid >> 2];      // (this path keeps one set of bounds per level: pooled statistics)
   if (!g.want_rows) return;
 
   // ---- C. row-tile scatter: per (level, axis tile) the runs of query pixels whose points can reach it ---------------------------
@@ -236,7 +235,6 @@ __global__ __launch_bounds__(256) void dir_plan_kernel(const DirStats *__restric
     d.c_end = (int)((long long)n_cand * (chunk + 1) / nc);
     d.cand_off = rp.cand_base[l] + tile * rp.cand_stride[l];
     d.near = s_near[l];
-    for (int k = 0; k < 4; ++k) d.near_p[k] = s_near[l];
     hp.items[it] = d;
   }
 }
@@ -274,48 +272,17 @@ __device__ __forceinline__ int small_div(int x, int d) {
   return q;
 }
 
-// Position of item j of level l (n[l] items, in row-major tile order: top of the image first) in the launch's item order when the four
-// levels' lists are MERGED by image position instead of run one level after the other: key(l, j) = (2 j + 1) / (2 n[l]) - lead(l), items in
-// ascending key (ties: the coarser level first).  Closed form, integers only: every workgroup of a head derives the same order by itself.
-// Why: all four levels' tiles over one band of the image scan the SAME queries (their grad_out rows, locations, weights); run level by
-// level, a (batch, head) plane's inputs pass through the XCD's 4 MB L2 four times -- 1.3 MB of rows per plane at 1280 x 384, 6.5 MB at
-// 1920 x 1280 (profiles/msda_traffic.json: 1.86x / 3.15x the algorithmic bytes).  The coarse levels' items are the long ones (up to 14
-// batches against 1 - 2): they LEAD their band by kLead items' worth of key, which also keeps them off the launch's tail.
-#ifndef MSDA_PLAN_MERGED_ORDER
-#define MSDA_PLAN_MERGED_ORDER 1
-#endif
-__device__ __forceinline__ int merged_rank(const int l, const int j, const int *n) {
-  // key(l, j) < key(l2, j2)  <=>  (2 j + 1 - 2 lead_l) n2 < (2 j2 + 1 - 2 lead_l2) n   with lead_l = l kLead (in items of its own level)
-  constexpr int kLead = 2;
-  const long long a = 2 * j + 1 - 2 * l * kLead, nl = n[l];
-  int rank = 0;
-#pragma unroll
-  for (int l2 = 0; l2 < 4; ++l2) {
-    const long long n2 = n[l2];
-    if (n2 == 0) continue;
-    if (l2 == l) { rank += j; continue; }
-    // items j2 of level l2 in front of (l, j):  (2 j2 + 1 - 2 l2 kLead) nl < a n2   (<= when l2 is the coarser level)
-    // <=>  2 j2 nl < a n2 - (1 - 2 l2 kLead) nl  =: c      j2 < c / (2 nl)  (or <=)
-    const long long c = a * n2 - (1 - 2 * l2 * kLead) * nl, d = 2 * nl;
-    long long cnt;
-    if (l2 > l) cnt = (c >= 0 ? c / d : -((-c + d - 1) / d)) + 1;                  // floor(c / d) + 1
-    else cnt = c > 0 ? (c + d - 1) / d : -((-c) / d);                              // ceil(c / d)
-    rank += (int)max(0LL, min(cnt, n2));
-  }
-  return rank;
-}
-
 template <int MODE>
 __global__ __launch_bounds__(256) void plan_fused_kernel(const float *__restrict__ loc, const float *__restrict__ ref, const PlanGeom g,
                                                          const RowPlan rp, int B, int loc_rs, int n_tiles, HeadPlan *__restrict__ plans,
                                                          RowCandidate *__restrict__ table) {
   const int m = blockIdx.x / n_tiles, tile_g = blockIdx.x - m * n_tiles, tid = threadIdx.x;
-  __shared__ int sh[16][10];                     // per (level, point): n, up_y, dn_y, up_x, dn_x, sum_y, sum_x, sq_y, sq_x, -
-  __shared__ DirBounds s_near[4], s_win[4], s_near_p[4][4], s_win_p[4][4];
+  __shared__ int sh[4][10];                      // n, up_y, dn_y, up_x, dn_x, sum_y, sum_x, sq_y, sq_x, -
+  __shared__ DirBounds s_near[4], s_win[4];
   __shared__ RowAxis s_rax[kRowMaxAxisTiles];
-  __shared__ int s_cand_max[4], s_nchunks[4], s_order[4], s_first[5], s_nitems[4];
+  __shared__ int s_cand_max[4], s_nchunks[4], s_order[4], s_first[5];
   HeadPlan &hp = plans[m];
-  if (tid < 160) (&sh[0][0])[tid] = 0;
+  if (tid < 40) (&sh[0][0])[tid] = 0;
   if (tid < 4) s_cand_max[tid] = 0;
   __syncthreads();
 
@@ -349,51 +316,45 @@ __global__ __launch_bounds__(256) void plan_fused_kernel(const float *__restrict
       const float4 a = ld4(lp), c = ld4(lp + 4);
       xy[0] = a.x; xy[1] = a.y; xy[2] = a.z; xy[3] = a.w; xy[4] = c.x; xy[5] = c.y; xy[6] = c.z; xy[7] = c.w;
     }
+    int n = 0, up_y = 0, dn_y = 0, up_x = 0, dn_x = 0, sy = 0, sx = 0, qy = 0, qx = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       // (only the footprint's top-left pixel is needed: the scaling, the cuh:274 test and the floors of make_tap)
       const float h_im = scale_loc(xy[2 * k + 1], H), w_im = scale_loc(xy[2 * k], W);
       if (!((h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W))) continue;
       const int dy = max(-kPlanClip, min(kPlanClip, (int)floorf(h_im) - cy)), dx = max(-kPlanClip, min(kPlanClip, (int)floorf(w_im) - cx));
-      int *rec = sh[l * 4 + (MSDA_POINT_BOUNDS ? k : 0)];      // MSDA_POINT_BOUNDS: statistics per (level, POINT), else pooled over the level's four
-      atomicAdd(&rec[0], 1);
-      atomicMax(&rec[1], dy + kPlanClip); atomicMax(&rec[2], kPlanClip - dy); atomicMax(&rec[3], dx + kPlanClip); atomicMax(&rec[4], kPlanClip - dx);
-      atomicAdd(&rec[5], dy); atomicAdd(&rec[6], dx); atomicAdd(&rec[7], dy * dy); atomicAdd(&rec[8], dx * dx);      // <= 16 k x 64^2: fits 32 bits
+      ++n;
+      up_y = max(up_y, dy + kPlanClip); dn_y = max(dn_y, kPlanClip - dy);
+      up_x = max(up_x, dx + kPlanClip); dn_x = max(dn_x, kPlanClip - dx);
+      sy += dy; sx += dx; qy += dy * dy; qx += dx * dx;
+    }
+    if (n) {
+      int *rec = sh[l];
+      atomicAdd(&rec[0], n);
+      atomicMax(&rec[1], up_y); atomicMax(&rec[2], dn_y); atomicMax(&rec[3], up_x); atomicMax(&rec[4], dn_x);
+      atomicAdd(&rec[5], sy); atomicAdd(&rec[6], sx); atomicAdd(&rec[7], qy); atomicAdd(&rec[8], qx);      // <= 16 k x 64^2: fits 32 bits
     }
   }
   __syncthreads();
-  if (tid < 16) {                                // per (level, point): [min, max] of the sample, cut at mean +- kPlanSigmas sigma
-    const int *rec = sh[MSDA_POINT_BOUNDS ? tid : (tid & ~3)];
-    const int n = rec[0];
+  if (tid < 4) {                                 // bounds: [min, max] of the sample, cut at mean +- kPlanSigmas sigma (dir_plan_kernel, A)
+    const int l = tid;
+    const int n = sh[l][0];
     DirBounds b;
     if (n == 0) {
       b.ylo = b.xlo = (short)-g.default_halo;
       b.yhi = b.xhi = (short)(g.default_halo - 1);
     } else {
-      const float my = (float)rec[5] / (float)n, mx = (float)rec[6] / (float)n;
-      const float vy = fmaxf((float)(unsigned)rec[7] / (float)n - my * my, 0.f), vx = fmaxf((float)(unsigned)rec[8] / (float)n - mx * mx, 0.f);
+      const float my = (float)sh[l][5] / (float)n, mx = (float)sh[l][6] / (float)n;
+      const float vy = fmaxf((float)(unsigned)sh[l][7] / (float)n - my * my, 0.f), vx = fmaxf((float)(unsigned)sh[l][8] / (float)n - mx * mx, 0.f);
       const float dy = kPlanSigmas * sqrtf(vy) + 0.5f, dx = kPlanSigmas * sqrtf(vx) + 0.5f;
-      b.ylo = (short)max(kPlanClip - rec[2], (int)floorf(my - dy)); b.yhi = (short)min(rec[1] - kPlanClip, (int)ceilf(my + dy));
-      b.xlo = (short)max(kPlanClip - rec[4], (int)floorf(mx - dx)); b.xhi = (short)min(rec[3] - kPlanClip, (int)ceilf(mx + dx));
+      b.ylo = (short)max(kPlanClip - sh[l][2], (int)floorf(my - dy)); b.yhi = (short)min(sh[l][1] - kPlanClip, (int)ceilf(my + dy));
+      b.xlo = (short)max(kPlanClip - sh[l][4], (int)floorf(mx - dx)); b.xhi = (short)min(sh[l][3] - kPlanClip, (int)ceilf(mx + dx));
     }
+    s_win[l] = b;
     DirBounds nb;                                // scatter: the candidate tables hold |d| <= reach (both ends clamped into that range)
     const int R = g.reach;
     nb.ylo = (short)min(max((int)b.ylo, -R), R); nb.yhi = (short)max(min((int)b.yhi, R), -R);
     nb.xlo = (short)min(max((int)b.xlo, -R), R); nb.xhi = (short)max(min((int)b.xhi, R), -R);
-    s_near_p[tid >> 2][tid & 3] = nb;
-    s_win_p[tid >> 2][tid & 3] = b;
-  }
-  __syncthreads();
-  if (tid < 4) {                                 // per level: the union over its points
-    const int l = tid;
-    DirBounds b, nb;
-    b.ylo = b.xlo = nb.ylo = nb.xlo = (short)32767; b.yhi = b.xhi = nb.yhi = nb.xhi = (short)-32768;
-    for (int k = 0; k < 4; ++k) {
-      const DirBounds np_ = s_near_p[l][k], wp = s_win_p[l][k];
-      b.ylo = min(b.ylo, wp.ylo); b.yhi = max(b.yhi, wp.yhi); b.xlo = min(b.xlo, wp.xlo); b.xhi = max(b.xhi, wp.xhi);
-      nb.ylo = min(nb.ylo, np_.ylo); nb.yhi = max(nb.yhi, np_.yhi); nb.xlo = min(nb.xlo, np_.xlo); nb.xhi = max(nb.xhi, np_.xhi);
-    }
-    s_win[l] = b;
     s_near[l] = nb;
   }
   __syncthreads();
@@ -443,12 +404,8 @@ __global__ __launch_bounds__(256) void plan_fused_kernel(const float *__restrict
       const int l = s_order[i];
       s_first[i + 1] = s_first[i] + rp.n_ty[l] * rp.n_tx[l] * s_nchunks[l];
     }
-    for (int l = 0; l < 4; ++l) s_nitems[l] = rp.n_ty[l] * rp.n_tx[l] * s_nchunks[l];
     if (tile_g == 0) {
-      for (int l = 0; l < 4; ++l) {
-        hp.n_chunks[l] = s_nchunks[l]; hp.order[l] = s_order[l]; hp.win[l] = s_win[l]; hp.near[l] = s_near[l];
-        for (int k = 0; k < 4; ++k) hp.near_p[l][k] = s_near_p[l][k];
-      }
+      for (int l = 0; l < 4; ++l) { hp.n_chunks[l] = s_nchunks[l]; hp.order[l] = s_order[l]; hp.win[l] = s_win[l]; hp.near[l] = s_near[l]; }
       for (int i = 0; i < 5; ++i) hp.first_item[i] = s_first[i];
       hp.n_items = s_first[4];
     }
@@ -467,7 +424,7 @@ __global__ __launch_bounds__(256) void plan_fused_kernel(const float *__restrict
   int oi = 0;
   while (oi < 3 && s_order[oi] != l) ++oi;
   if (tid < nc) {
-    const int it = MSDA_PLAN_MERGED_ORDER ? merged_rank(l, t * nc + tid, s_nitems) : s_first[oi] + t * nc + tid;
+    const int it = s_first[oi] + t * nc + tid;
     if (it < kPlanMaxItems) {
       RowItem d{};
       d.level = (short)l; d.chunk = (short)tid; d.n_chunks = (short)nc;
@@ -476,7 +433,6 @@ __global__ __launch_bounds__(256) void plan_fused_kernel(const float *__restrict
       d.c_end = (int)((long long)n_cand * (tid + 1) / nc);
       d.cand_off = rp.cand_base[l] + t * rp.cand_stride[l];
       d.near = s_near[l];
-      for (int k = 0; k < 4; ++k) d.near_p[k] = s_near_p[l][k];
       hp.items[it] = d;
     }
   }

@@ -51,7 +51,8 @@ __device__ unsigned long long g_rows_overflow_rounds;
 #define MSDA_ROWS_COUNT 0        // measurement builds only: scan census (msda_debug_counter("scan_*")) -- what the scan looked at and what it delivered
 #endif
 // [0] candidates scanned (query, level, tile), [1] candidates with a point in the tile, [2] point tests (taps evaluated),
-// [3] points delivered to a cell of the tile, [4] points skipped by the per-point reach test before their loads
+// [3] points delivered to a cell of the tile, [4] points skipped before their loads (the round-5 per-point reach test:
+// tools/debug/experiments/r05_point_bounds_merged_order.patch; 0 in this tree)
 __device__ unsigned long long g_rows_scan[5];
 
 // Workgroup barrier for LDS hand-offs that leaves global loads in flight: __syncthreads() carries a workgroup-scope fence
@@ -124,8 +125,7 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
   const HeadPlan *hp = plans ? plans + m : nullptr;
   int l, n_chunks, y0, th, x0, tw, c_begin, c_end;
   const RowCandidate *cands;
-  DirBounds nb;              // near <=> the footprint's top-left pixel lies inside these bounds around the query's centre floor:
-                             // THIS THREAD's point's own bounds with the directional plan (msda_plan.h: near_p), else the level's
+  DirBounds nb;              // near <=> the footprint's top-left pixel lies inside these bounds around the query's centre floor
   bool by_list = false;
   const unsigned *list = nullptr;
   if (lists) {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
     y0 = d.y0; th = d.th; x0 = d.x0; tw = d.tw;
     c_begin = d.c_begin; c_end = d.c_end;
     cands = table + (long long)m * p.cand_total + d.cand_off;
-    nb = MSDA_POINT_BOUNDS ? hp->items[it].near_p[threadIdx.x & 3] : d.near;
+    nb = d.near;
   } else {
     int oi = 0;
     while (oi < 3 && it >= p.first_item[oi + 1]) ++oi;
@@ -217,21 +217,12 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
     }
     return c;
   };
-  // Can this thread's point of candidate c land in the tile's cells [y0 - 1, y0 + th) x [x0 - 1, x0 + tw) at all?  Its footprint's
-  // top-left pixel is c's centre floor + d with d inside the point's bounds, or the point is far (not this kernel's).  The scan list
-  // holds the union over the level's four points: a candidate at its edge serves one or two of them -- the others skip their loads.
-  const int ry_lo = y0 - 1 - nb.yhi, ry_hi = y0 + th - 1 - nb.ylo, rx_lo = x0 - 1 - nb.xhi, rx_hi = x0 + tw - 1 - nb.xlo;
-  auto reaches = [&](const RowCandidate c) {
-    if (!MSDA_POINT_BOUNDS) return true;       // per-level bounds: the scan list holds exactly the candidates within reach
-    return by_list || ((int)c.cy >= ry_lo && (int)c.cy <= ry_hi && (int)c.cx >= rx_lo && (int)c.cx <= rx_hi);
-  };
 #if MSDA_ROWS_COUNT
   unsigned n_scan[5] = {0, 0, 0, 0, 0};
 #endif
   auto fetch = [&](const RowCandidate c) {
     Points in{};
-    // (FUSED: the candidate's four threads share their loads -- each holds four of the pair's 16 logits for the quad's softmax)
-    if (c.token >= 0 && (FUSED || reaches(c))) {
+    if (c.token >= 0) {
       const long long q_lin = (long long)b * S + c.token;                          // Lq == S
       const long long pl = (((long long)(b * M + m) * 4 + l) * S + c.token) * 4 + pt;          // level-major point index
       in.xy = LEVEL_MAJOR ? *reinterpret_cast<const float2 *>(loc + pl * 2)
@@ -267,8 +258,6 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
 #pragma unroll
     for (int u = 0; u < kRowSub; ++u) {
       g0[u] = g1[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      // (requested for every live candidate, also one none of whose points can reach: the request has to be out before the taps
-      // say whether it is needed -- DESIGN 4.0a: behind its own condition the load's latency is exposed)
       if (cur[u].token >= 0 && !(MSDA_ROWS_SKIP & 16)) {
         const float *gp = grad_out + (((long long)b * S + cur[u].token) * M + m) * 32 + pt * 8;
         g0[u] = ld4(gp);
@@ -294,11 +283,9 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
         ly = loc_from_offset<4>(in[u].rs.ry, ly, in[u].rs.sy, ref_dim);
       }
       cells[u] = 0;
+      if (cur[u].token >= 0 && (!(MSDA_ROWS_SKIP & 32) || lx == 123.456f)) {
 #if MSDA_ROWS_COUNT
-      if (cur[u].token >= 0) { n_scan[0] += pt == 0; n_scan[4] += !reaches(cur[u]); }
-#endif
-      if (cur[u].token >= 0 && reaches(cur[u]) && (!(MSDA_ROWS_SKIP & 32) || lx == 123.456f)) {
-#if MSDA_ROWS_COUNT
+        n_scan[0] += pt == 0;
         ++n_scan[2];
 #endif
         const Tap<float> tp = make_tap<float>(lx, ly, H, W);

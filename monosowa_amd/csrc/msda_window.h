@@ -118,7 +118,16 @@ inline void fill_query_table(const WinTable &t, WinQuery *out) {
 // Host: choose the tiling.  Cost model (LDS cycles per tile, measured orders of magnitude): ~5 per staged row (L2 -> LDS),
 // ~80 per (query, head) pair slot of a pass (16 points x 4 row reads + records), so halo rows are cheap next to idle pair
 // slots.  Returns false when no tiling fits (tiny or huge levels): the caller keeps the plain gather kernels.
-inline bool choose_window_tiling(const int64_t *shapes_host, const int64_t *lsi_host, int halo, int max_rows, WinGeom &best) {
+// tile_cost: the fixed part of a tile in the same units (a full pass of 128 pair slots = 10,240).  400 for the forward.  The BACKWARD
+// gather pays much more per tile than its row loops -- a block of grad_out rows per wave, the softmax / offset backward epilogue, two
+// more barriers -- and where the LDS budget forbids 256-query tiles it is faster on FEWER, partly filled two-pass tiles than on
+// one-pass tiles: measured at 1920 x 1280 (config 5, B = 4; interior tiles carry the halo on all four sides: 1,304 rows for 256
+// queries against a budget of 1,181) 10 x 30 tiles of <= 170 queries 1.510 ms per backward, 20 x 20 tiles of 128 queries (this
+// model's choice with 400) 1.645 ms; the forward prefers the latter (0.436 against 0.485 ms).  18,000 reproduces both choices and
+// leaves 1280 x 384 / 1408 x 376 (2 x 20 / 2 x 22 full tiles, the minimum count) as they are.
+inline bool choose_window_tiling(const int64_t *shapes_host, const int64_t *lsi_host, int halo, int max_rows, WinGeom &best,
+                                 int force_ty = 0, int force_tx = 0, double tile_cost = 400.0) {
+  // force_ty x force_tx (> 0, measurement runs: MSDA_WIN_TILES): only that tiling is considered (still checked against the budgets)
   WinGeom g;
   for (int l = 0; l < kWinLevels; ++l) {
     g.H[l] = (int)shapes_host[2 * l];
@@ -130,12 +139,14 @@ inline bool choose_window_tiling(const int64_t *shapes_host, const int64_t *lsi_
   double best_cost = -1;
   AxisSpec ys[kWinMaxAxisTiles][kWinLevels], xs[kWinMaxAxisTiles][kWinLevels];
   for (int n_ty = 1; n_ty <= g.H[0] && n_ty < kWinMaxAxisTiles; ++n_ty) {
+    if (force_ty > 0 && n_ty != force_ty) continue;
     const int th = (g.H[0] + n_ty - 1) / n_ty;
     if (th > 64) continue;
     if (th < 4 && n_ty > 1) break;
     for (int ty = 0; ty < n_ty; ++ty)
       for (int l = 0; l < kWinLevels; ++l) ys[ty][l] = axis_spec(g.H, n_ty, ty, l, halo);
     for (int n_tx = 1; n_tx <= g.W[0] && n_ty + n_tx <= kWinMaxAxisTiles; ++n_tx) {
+      if (force_tx > 0 && n_tx != force_tx) continue;
       const int tw = (g.W[0] + n_tx - 1) / n_tx;
       if (tw > 64) continue;
       if (tw < 4 && n_tx > 1) break;
@@ -152,7 +163,7 @@ inline bool choose_window_tiling(const int64_t *shapes_host, const int64_t *lsi_
           }
           if (rows > max_rows || queries > kWinPairsPerPass * kWinMaxPasses) { ok = false; break; }
           const int passes = (queries + kWinPairsPerPass - 1) / kWinPairsPerPass;
-          cost += 5.0 * rows + 80.0 * passes * kWinPairsPerPass + 400.0;      // + fixed per-tile overhead (barriers)
+          cost += 5.0 * rows + 80.0 * passes * kWinPairsPerPass + tile_cost;      // + fixed per-tile overhead
         }
       if (ok && (best_cost < 0 || cost < best_cost)) { best_cost = cost; best = g; best.n_ty = n_ty; best.n_tx = n_tx; }
     }

@@ -169,6 +169,19 @@ __global__ __launch_bounds__(256) void relu_grad2_kernel(const float *__restrict
   }
 }
 
+// three consumers (the last block of a stage feeds the next stage, its identity branch and an input projection): their gradients meet
+// here, masked by the sign of the block's OUTPUT (the epilogue-GEMM bottleneck path keeps no byte mask)
+__global__ __launch_bounds__(256) void relu_grad3_kernel(const float *__restrict__ ga, const float *__restrict__ gb, const float *__restrict__ gc,
+                                                         const float *__restrict__ y, float *__restrict__ grad_in, long long n_vec) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    const float4 a = reinterpret_cast<const float4 *>(ga)[i], b = reinterpret_cast<const float4 *>(gb)[i], c = reinterpret_cast<const float4 *>(gc)[i];
+    const float4 v = reinterpret_cast<const float4 *>(y)[i];
+    reinterpret_cast<float4 *>(grad_in)[i] = make_float4(v.x > 0.f ? (a.x + b.x) + c.x : 0.f, v.y > 0.f ? (a.y + b.y) + c.y : 0.f,
+                                                         v.z > 0.f ? (a.z + b.z) + c.z : 0.f, v.w > 0.f ? (a.w + b.w) + c.w : 0.f);
+  }
+}
+
 // ---- LayerNorm(x + dropout(z)) over rows of 256 channels: one wave per row, float4 per lane -----------------
 // (reference: `src = self.norm1(src + self.dropout1(src2))`, depthaware_transformer.py:339-354,500-515).
 // The keep mask is a counter-based hash of (seed, element index), recomputed in the backward: no mask tensor.
@@ -611,6 +624,16 @@ int mono_relu_grad2_f32(const float *grad_a, const float *grad_b, const float *y
   if (!grad_a || !grad_b || !y || !grad_in) return -1;
   if (n <= 0 || (n & 3) || ((uintptr_t)grad_a & 15) || ((uintptr_t)grad_b & 15) || ((uintptr_t)y & 15) || ((uintptr_t)grad_in & 15)) return -2;
   mono::relu_grad2_kernel<<<mono::grid_for_vec(n / 4), 256, 0, (hipStream_t)stream_>>>(grad_a, grad_b, y, grad_in, n / 4);
+  return (int)hipGetLastError();
+}
+
+int mono_relu_grad3_f32(const float *grad_a, const float *grad_b, const float *grad_c, const float *y, float *grad_in, long long n,
+                        void *stream_) {
+  if (!grad_a || !grad_b || !grad_c || !y || !grad_in) return -1;
+  if (n <= 0 || (n & 3) || ((uintptr_t)grad_a & 15) || ((uintptr_t)grad_b & 15) || ((uintptr_t)grad_c & 15) || ((uintptr_t)y & 15) ||
+      ((uintptr_t)grad_in & 15))
+    return -2;
+  mono::relu_grad3_kernel<<<mono::grid_for_vec(n / 4), 256, 0, (hipStream_t)stream_>>>(grad_a, grad_b, grad_c, y, grad_in, n / 4);
   return (int)hipGetLastError();
 }
 

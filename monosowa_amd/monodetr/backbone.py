@@ -109,53 +109,67 @@ def _summed_shift(bn, other):
     return cached[1]
 
 
-# Trainable 1 x 1 convolutions (stride 1: conv1 / conv3 of every bottleneck of layer2-4) as plain GEMMs on the channels-last pixel matrix
-# [N H W, C] -- forward X W^T, input gradient dY W, weight gradient dY^T X through the split-K path of token_linear (K = N H W = 122,880 at
-# layer2) -- instead of MIOpen's implicit-GEMM solvers, whose split-K variants ("gkgs") come with a zero-fill launch in front of their
-# atomics.  A/B switch (tools/ab_step.py monosowa_amd.monodetr.backbone.CONV1X1_GEMM 0 1); bit 1: forward + input gradient, bit 2: weight gradient.
-CONV1X1_GEMM = int(os.environ.get("MONOSOWA_CONV1X1_GEMM", "0"))
+# Trainable 1 x 1 convolutions (stride 1: conv1 / conv3 of every bottleneck of layer2-4) with the frozen norm's scale and shift, the
+# identity and the ReLU inside the GEMM's EPILOGUE (monosowa_amd/gemm_lt.py: hipBLASLt through the C-ABI shim, include/monosowa_gemm.h):
+#     y[N H W, out] = relu(scale * (x[N H W, in] w^T) + identity + shift)            one launch over the channels-last pixel matrix
+# instead of MIOpen's convolution followed by a pass over its output (bias_relu_mask / affine_relu_mask: 1.4 ms per step at B = 16).
+# The backward reads the ReLU mask from y itself (relu_grad / relu_grad2 kernels), forms dX = (g * scale) w by a library GEMM and
+# leaves the weight gradient with MIOpen's solver (round 5 A/B: a split-K GEMM for it was 3.4 ms per step SLOWER).
+# Bits (A/B: tools/ab_step.py monosowa_amd.monodetr.backbone.CONV1X1_EPILOGUE 0 3): 1 forward through the epilogue GEMM, 2 input
+# gradient through the library GEMM (else MIOpen's backward-data solver).
+CONV1X1_EPILOGUE = int(os.environ.get("MONOSOWA_CONV1X1_EPILOGUE", "3"))
 
 
-class _Conv1x1Gemm(torch.autograd.Function):
+def _pixels(t):
+    """[N, C, H, W] channels-last -> its [N H W, C] row-major matrix (a view)."""
+    return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+
+
+class _Conv1x1BnAct(torch.autograd.Function):
+    """relu(scale * conv1x1(x, w) + shift (+ residual)), returned n_out times (one tensor object per consumer, as bias_act_fork)."""
+
     @staticmethod
-    def forward(ctx, x, w, mode):
-        N, C, H, W = x.shape
-        ctx.save_for_backward(x, w)
-        ctx.mode = mode
-        if mode & 1:
-            y2 = torch.mm(x.permute(0, 2, 3, 1).reshape(-1, C), w.reshape(w.shape[0], C).t())
-            return y2.view(N, H, W, w.shape[0]).permute(0, 3, 1, 2)
-        return F.conv2d(x, w)
-
-    @staticmethod
-    def backward(ctx, gy):
-        from ..token_linear import weight_grad
-        x, w = ctx.saved_tensors
+    def forward(ctx, x, w, scale, shift, residual, n_out):
+        from .. import gemm_lt
         N, C, H, W = x.shape
         K = w.shape[0]
-        gy = gy.contiguous(memory_format=torch.channels_last)
-        gy2 = gy.permute(0, 2, 3, 1).reshape(-1, K)
+        y = torch.empty((N, K, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        gemm_lt.gemm_nt(_pixels(x), w.reshape(K, C), scale, shift, None if residual is None else _pixels(residual), True, out=_pixels(y))
+        ctx.save_for_backward(x, w, scale, y)
+        ctx.has_res = residual is not None
+        return (y,) + tuple(y.detach() for _ in range(n_out - 1))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from .. import gemm_lt
+        from ..pointwise import relu_grad_from_output
+        x, w, scale, y = ctx.saved_tensors
+        N, C, H, W = x.shape
+        K = w.shape[0]
+        g = relu_grad_from_output([t for t in grads if t is not None], y)          # (sum of the consumers' gradients) * (y > 0), one pass
         gx = gw = None
+        w2 = w.reshape(K, C)
         if ctx.needs_input_grad[0]:
-            if ctx.mode & 1:
-                gx = torch.mm(gy2, w.reshape(K, C)).view(N, H, W, C).permute(0, 3, 1, 2)
+            ws = w2 * scale.view(-1, 1)                                             # [out, in]: the scale rides on the (small) weight
+            if CONV1X1_EPILOGUE & 2:
+                gx = torch.empty_like(x)
+                gemm_lt.gemm_nn(_pixels(g), ws, out=_pixels(gx))
             else:
-                gx = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1, (True, False, False))[0]
+                gx = torch.ops.aten.convolution_backward(g, x, ws.view(K, C, 1, 1), None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
+                                                         (True, False, False))[0]
         if ctx.needs_input_grad[1]:
-            if ctx.mode & 2:
-                gw = weight_grad(gy2, x.permute(0, 2, 3, 1).reshape(-1, C)).view(K, C, 1, 1).contiguous(memory_format=torch.channels_last)
-            else:
-                gw = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1, (False, True, False))[1]
-        return gx, gw, None
+            gw = torch.ops.aten.convolution_backward(g, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+            gw = gw * scale.view(-1, 1, 1, 1)
+        return gx, gw, None, None, (g if ctx.has_res else None), None
 
 
-def conv2d(x, w, conv):
-    """``F.conv2d(x, w)`` with the module's geometry; a trainable stride-1 1 x 1 convolution on a channels-last GPU tensor may take
-    the GEMM path (CONV1X1_GEMM)."""
-    if CONV1X1_GEMM and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and x.is_cuda and x.dim() == 4 \
-            and torch.is_grad_enabled() and w.requires_grad and x.is_contiguous(memory_format=torch.channels_last) and x.dtype == torch.float32:
-        return _Conv1x1Gemm.apply(x, w, CONV1X1_GEMM)
-    return F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+def conv1x1_epilogue_applies(x, conv, residual=None):
+    from .. import gemm_lt
+    return bool(CONV1X1_EPILOGUE & 1) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and conv.padding == (0, 0) \
+        and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and torch.is_grad_enabled() and conv.weight.requires_grad \
+        and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 4 == 0 and conv.weight.shape[0] % 4 == 0 \
+        and (residual is None or (residual.shape[1] == conv.weight.shape[0] and residual.is_contiguous(memory_format=torch.channels_last)
+                                  and residual.dtype == torch.float32))
 
 
 def conv_bn_fork(x, conv, bn, residual, n_out=2, residual_bn=None):
@@ -167,7 +181,9 @@ def conv_bn_fork(x, conv, bn, residual, n_out=2, residual_bn=None):
         scale, shift = bn.scale_shift()
         if residual_bn is not None:
             shift = _summed_shift(bn, residual_bn)
-        y = conv2d(x, folded_weight(conv, bn, scale), conv)
+        if conv1x1_epilogue_applies(x, conv, residual):
+            return _Conv1x1BnAct.apply(x, conv.weight, scale, shift, residual, n_out)
+        y = F.conv2d(x, folded_weight(conv, bn, scale), None, conv.stride, conv.padding, conv.dilation, conv.groups)
         return bias_act_fork(y, shift, residual, n_out)
     assert residual_bn is None
     out = conv_bn(x, conv, bn, residual)
@@ -180,14 +196,16 @@ def conv_bn(x, conv, bn, residual=None, relu=True):
     an add pass and a ReLU pass)."""
     if isinstance(bn, FrozenBatchNorm2d):
         scale, shift = bn.scale_shift()
+        if relu and residual is None and conv1x1_epilogue_applies(x, conv):
+            return _Conv1x1BnAct.apply(x, conv.weight, scale, shift, None, 1)[0]
         if AFFINE_IN_KERNEL and relu and residual is None and conv.weight.requires_grad and torch.is_grad_enabled() and x.is_cuda:
             # trainable convolution without residual: raw weights, the BN affine map runs inside the ReLU kernels
             # (forward y*scale+shift, backward grad*mask*scale) -- no weight multiply per step, none in the backward
-            y = conv2d(x, conv.weight, conv)
+            y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
             if affine_relu_supported(y, scale):
                 return affine_relu(y, scale, shift)
             return torch.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
-        y = conv2d(x, folded_weight(conv, bn, scale), conv)
+        y = F.conv2d(x, folded_weight(conv, bn, scale), None, conv.stride, conv.padding, conv.dilation, conv.groups)
         return bias_act(y, shift, residual, relu)
     y = bn(conv(x))
     if residual is not None:

@@ -10,7 +10,7 @@ from . import flops
 from ._lib import raw_stream, on_device
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmonosowa_pointwise.so")
-SYMBOLS = ("mono_bias_act_f32", "mono_bias_relu_maxpool_nhwc_f32", "mono_conv1x1_tail_f32", "mono_conv1x1_tail_ds_f32", "mono_conv1x1_head_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
+SYMBOLS = ("mono_bias_act_f32", "mono_bias_relu_maxpool_nhwc_f32", "mono_conv1x1_tail_f32", "mono_conv1x1_tail_ds_f32", "mono_conv1x1_head_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_relu_grad3_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
            "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32", "mono_relu_dropout_bwd_colsum_f32", "mono_sum_slices_f32", "mono_colsum_any_blocks", "mono_colsum_any_f32", "mono_relu_grad_mask3_f32", "mono_lsap_match_flat_f32")
@@ -47,6 +47,8 @@ def load():
         lib.mono_affine_relu_grad_f32.argtypes = [P, P, P, P, LL, I, P]
         lib.mono_relu_grad2_f32.restype = I
         lib.mono_relu_grad2_f32.argtypes = [P, P, P, P, LL, P]
+        lib.mono_relu_grad3_f32.restype = I
+        lib.mono_relu_grad3_f32.argtypes = [P, P, P, P, P, LL, P]
         U, F = ctypes.c_ulonglong, ctypes.c_float
         lib.mono_dropout_add_layernorm_fwd_f32.restype = I
         lib.mono_dropout_add_layernorm_fwd_f32.argtypes = [P] * 8 + [LL, I, F, U, F, P]
@@ -253,6 +255,26 @@ class _BiasActFork(torch.autograd.Function):
         if code:
             raise RuntimeError("mono_relu_grad(2)_f32 failed with code %d" % code)
         return g, (g.sum((0, 2, 3)) if ctx.bias_grad else None), g, None
+
+
+def relu_grad_from_output(grads, y):
+    """``(sum of grads) * (y > 0)`` for the 1 - 3 gradients a ReLU output's consumers returned, in ONE pass that reads the mask off
+    the output itself (channels-last float32; the epilogue-GEMM bottleneck paths of backbone.py keep no byte mask)."""
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    given = [cl(t) for t in grads]
+    g = torch.empty(y.shape, dtype=torch.float32, device=y.device, memory_format=torch.channels_last)
+    n = g.numel()
+    lib = load()
+    with on_device(y.device):
+        if len(given) == 3:
+            code = lib.mono_relu_grad3_f32(given[0].data_ptr(), given[1].data_ptr(), given[2].data_ptr(), y.data_ptr(), g.data_ptr(), n, raw_stream())
+        elif len(given) == 2:
+            code = lib.mono_relu_grad2_f32(given[0].data_ptr(), given[1].data_ptr(), y.data_ptr(), g.data_ptr(), n, raw_stream())
+        else:
+            code = lib.mono_relu_grad_f32(given[0].data_ptr(), y.data_ptr(), g.data_ptr(), n, raw_stream())
+    if code:
+        raise RuntimeError("mono_relu_grad(2)_f32 failed with code %d" % code)
+    return g
 
 
 def bias_relu_maxpool_supported(y, bias):

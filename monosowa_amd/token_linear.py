@@ -33,6 +33,11 @@ def weight_grad(g2, x2):
     return g2.t() @ x2
 
 
+# (Round 5, measured and NOT used: hipBLASLt's bias-gradient epilogue -- dW = dY^T X with db = the column sums of dY from the same launch,
+# gemm_lt.gemm_tn_bgrad through the C-ABI shim -- is correct (tests/test_gemm_lt_gpu.py) and slow: ~1 ms per call at [8800, 256] x
+# [8800, 256], +45 ms per train step when every token linear below MIN_TOKENS rows used it, tools/ab_step.py.  The column-sum kernels stay.)
+
+
 class _TokenLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):

@@ -199,3 +199,55 @@ def test_frozen_first_bottleneck_tail_with_downsample_equals_the_passes(N, H, W)
     want = torch.relu(F.conv2d(h, w.double()) + F.conv2d(x0.double(), wd.double()) + b_out.double().view(1, -1, 1, 1))
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert (got.double() - want).abs().max() <= 1e-5 * want.abs().max()
+
+
+@pytest.mark.parametrize("downsample", [False, True], ids=["identity", "downsample"])
+def test_trainable_bottleneck_through_epilogue_gemms_equals_float64(downsample, monkeypatch):
+    """A TRAINABLE bottleneck (layer2-4 of the reference's backbone.py:72-74 freeze rule) with its two 1 x 1 convolutions run as
+    library GEMMs whose epilogue applies the frozen norm's scale + shift, the identity and the ReLU (backbone.CONV1X1_EPILOGUE = 3:
+    forward and input gradient): output and every gradient (input pair, three weights) against a float64 evaluation with F.conv2d,
+    the affine map and F.relu; ragged pixel count, frozen-BN buffers away from the identity."""
+    from monosowa_amd.monodetr import backbone as BB
+    torch.manual_seed(13)
+    inplanes, planes, stride = (256, 128, 2) if downsample else (512, 128, 1)
+    ds = None
+    if downsample:
+        ds = torch.nn.Sequential(torch.nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), BB.FrozenBatchNorm2d(planes * 4))
+    blk = BB.Bottleneck(inplanes, planes, stride, ds).cuda()
+    gen = torch.Generator().manual_seed(3)
+    for n, b in blk.named_buffers():
+        b.copy_((torch.rand(b.shape, generator=gen) * 1.5 + 0.5) if ("var" in n or n.endswith("weight")) else torch.randn(b.shape, generator=gen) * 0.2)
+    blk = blk.to(memory_format=torch.channels_last)
+    x = torch.randn(3, inplanes, 13, 22, device="cuda").contiguous(memory_format=torch.channels_last)
+
+    def run(flag):
+        monkeypatch.setattr(BB, "CONV1X1_EPILOGUE", flag)
+        blk.zero_grad(set_to_none=True)
+        xa = x.clone().requires_grad_(True)
+        ya, yb = blk(xa)                                  # the pair a block hands to its two consumers
+        torch.manual_seed(1)
+        g1, g2 = torch.randn(ya.shape, device="cuda"), torch.randn(ya.shape, device="cuda")
+        torch.autograd.backward([ya, yb], [g1, g2])
+        return [ya.detach(), xa.grad] + [p.grad for p in blk.parameters()], (g1 + g2)
+
+    got, gsum = run(3)
+    old, _ = run(0)
+    # float64 reference
+    sd = {k: v.detach().double().cpu() for k, v in blk.state_dict().items()}
+    xd = x.double().cpu().requires_grad_(True)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.endswith("weight") and "conv" in k or k == "downsample.0.weight"}
+
+    def bn(y, p):
+        scale = sd[p + ".weight"] / torch.sqrt(sd[p + ".running_var"] + 1e-5)
+        return y * scale.view(1, -1, 1, 1) + (sd[p + ".bias"] - sd[p + ".running_mean"] * scale).view(1, -1, 1, 1)
+    o = F.relu(bn(F.conv2d(xd, params["conv1.weight"]), "bn1"))
+    o = F.relu(bn(F.conv2d(o, params["conv2.weight"], None, stride, 1), "bn2"))
+    o = bn(F.conv2d(o, params["conv3.weight"]), "bn3")
+    idt = bn(F.conv2d(xd, params["downsample.0.weight"], None, stride), "downsample.1") if downsample else xd
+    yd = F.relu(o + idt)
+    yd.backward(gsum.double().cpu())
+    names = [n for n, _ in blk.named_parameters()]
+    want = [yd.detach(), xd.grad] + [params[n].grad for n in names]
+    for name, a, b, c in zip(["out", "grad_x"] + names, got, want, old):
+        assert _rel(a, b) <= 2e-5, (name, _rel(a, b))
+        assert _rel(c, b) <= 2e-5, ("module path " + name, _rel(c, b))

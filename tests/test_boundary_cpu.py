@@ -109,6 +109,20 @@ def test_attention_library_exports_declared_symbols():
     assert not flash_attn.mask_supported(torch.zeros(2, 7, dtype=torch.bool, device="meta"), 2, 7, dev)
 
 
+def test_gemm_library_exports_declared_symbols():
+    from monosowa_amd import gemm_lt
+    text = open(os.path.join(ROOT, "include", "monosowa_gemm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(mono_[a-z0-9_]+)\s*\(", text)))
+    assert names == sorted(gemm_lt.SYMBOLS)
+    lib = ctypes.CDLL(gemm_lt._PATH)
+    for n in names:
+        assert hasattr(lib, n)
+    # argument checks come before any device work
+    assert gemm_lt.load().mono_gemm_nn_f32(None, 0, None, 0, None, 0, 1, 1, 1, None) == -1
+    assert not gemm_lt.supported(torch.randn(4, 4))
+
+
 def test_kitti_library_exports_declared_symbols():
     from monosowa_amd import kitti_eval
     text = open(os.path.join(ROOT, "include", "monosowa_kitti.h")).read()

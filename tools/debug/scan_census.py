@@ -38,10 +38,13 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--micro", default=None)
     ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--resolution", default=None, help="--micro only: WxH (config 5: 1920x1280 with --batch 4)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     if a.micro:
         import msda_fused_bench as FB
+        if a.resolution:
+            FB.set_resolution(a.resolution)
         for spec in a.micro.split(","):
             value, shapes, lsi, proj, ref, go = FB.make(a.batch, "enc", spec, dev)
             _, loc, attw = MSDA.ms_deform_attn_fused_forward_merged_save(value, shapes, lsi, proj, ref)

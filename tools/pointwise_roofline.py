@@ -44,9 +44,19 @@ print("# mono:: kernels inside the train step (bench.py, B = 16): bytes per laun
 print("# average duration from the kernel trace of the same runs; profiled runs clock ~3 % lower than unprofiled ones.")
 print("%-58s %9s %9s %10s %10s %8s %7s" % ("kernel", "launches", "avg us", "fetch MB", "write MB", "GB/s", "of 8TB/s"))
 tot_t = 0.0
-for total, k, n, avg, fetch, write in rows[:15]:
+for total, k, n, avg, fetch, write in rows[:24]:
     gbps = (fetch + write) / avg / 1e9
     print("%-58s %9d %9.1f %10.2f %10.2f %8.0f %6.1f%%" % (k, n, avg * 1e6, fetch / 1e6, write / 1e6, gbps, 100 * (fetch + write) / avg / PEAK))
     tot_t += total
-print("# the 15 kernels above: %.2f ms of kernel time over the profiled steps; all mono:: kernels: %.2f ms over %d launches"
+# the hand-written DENSE kernels among them (frozen layer1, conv1x1_fused.hip): also against the f32 matrix peak.  Pixel counts of the
+# default bench workload (B = 16, 1280 x 384: layer1 at 96 x 320)
+M_PIX = 16 * 96 * 320
+DENSE = {"conv1x1_head_kernel<256>": 2.0 * M_PIX * 256 * 64, "conv1x1_head_kernel<64>": 2.0 * M_PIX * 64 * 64,
+         "conv1x1_tail_kernel": 2.0 * M_PIX * 64 * 256, "conv1x1_tail_ds_kernel": 2.0 * M_PIX * 128 * 256}
+print("# dense kernels of this library: FLOP per launch (default bench shape) / average duration / 157.3 TFLOP/s (f32 matrix peak)")
+for total, k, n, avg, fetch, write in rows:
+    if k in DENSE:
+        print("%-58s %9d %9.1f us %8.1f GFLOP %7.1f TFLOP/s %6.1f%% of the f32 matrix peak; %5.1f%% of 8 TB/s"
+              % (k, n, avg * 1e6, DENSE[k] / 1e9, DENSE[k] / avg / 1e12, 100 * DENSE[k] / avg / 157.3e12, 100 * (fetch + write) / avg / PEAK))
+print("# the 24 kernels above: %.2f ms of kernel time over the profiled steps; all mono:: kernels: %.2f ms over %d launches"
       % (tot_t * 1e3, sum(r[0] for r in rows) * 1e3, sum(r[2] for r in rows)))

@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   echo "pass $C" >> "$OUT/progress.log"
-  timeout -k 5 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --preheat-seconds 0 --no-cpu-baseline --no-inference-leg --no-dataloader-leg > "$OUT/bench_$C.json" 2> "$OUT/bench_$C.err"
+  timeout -k 5 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --preheat-seconds 0 --no-cpu-baseline --no-inference-leg --no-dataloader-leg --no-step-roofline --no-offsets-probe > "$OUT/bench_$C.json" 2> "$OUT/bench_$C.err"
 done
 python3 "$ROOT/tools/pointwise_roofline.py" "$OUT" > "$OUT/pointwise_roofline.txt"
 cat "$OUT/pointwise_roofline.txt"
