@@ -201,8 +201,8 @@ def test_frozen_first_bottleneck_tail_with_downsample_equals_the_passes(N, H, W)
     assert (got.double() - want).abs().max() <= 1e-5 * want.abs().max()
 
 
-@pytest.mark.parametrize("downsample", [False, True], ids=["identity", "downsample"])
-def test_trainable_bottleneck_through_epilogue_gemms_equals_float64(downsample, monkeypatch):
+@pytest.mark.parametrize("downsample,n_out", [(False, 2), (True, 2), (False, 3)], ids=["identity", "downsample", "three-consumers"])
+def test_trainable_bottleneck_through_epilogue_gemms_equals_float64(downsample, n_out, monkeypatch):
     """A TRAINABLE bottleneck (layer2-4 of the reference's backbone.py:72-74 freeze rule) with its two 1 x 1 convolutions run as
     library GEMMs whose epilogue applies the frozen norm's scale + shift, the identity and the ReLU (backbone.CONV1X1_EPILOGUE = 3:
     forward and input gradient): output and every gradient (input pair, three weights) against a float64 evaluation with F.conv2d,
@@ -218,17 +218,19 @@ def test_trainable_bottleneck_through_epilogue_gemms_equals_float64(downsample, 
     for n, b in blk.named_buffers():
         b.copy_((torch.rand(b.shape, generator=gen) * 1.5 + 0.5) if ("var" in n or n.endswith("weight")) else torch.randn(b.shape, generator=gen) * 0.2)
     blk = blk.to(memory_format=torch.channels_last)
+    blk.n_out = n_out                                    # 3: the last block of a stage (next stage, its identity branch, an input projection)
     x = torch.randn(3, inplanes, 13, 22, device="cuda").contiguous(memory_format=torch.channels_last)
 
     def run(flag):
         monkeypatch.setattr(BB, "CONV1X1_EPILOGUE", flag)
         blk.zero_grad(set_to_none=True)
         xa = x.clone().requires_grad_(True)
-        ya, yb = blk(xa)                                  # the pair a block hands to its two consumers
+        ys = blk(xa)                                      # one tensor object per consumer
+        assert len(ys) == n_out
         torch.manual_seed(1)
-        g1, g2 = torch.randn(ya.shape, device="cuda"), torch.randn(ya.shape, device="cuda")
-        torch.autograd.backward([ya, yb], [g1, g2])
-        return [ya.detach(), xa.grad] + [p.grad for p in blk.parameters()], (g1 + g2)
+        gs = [torch.randn(ys[0].shape, device="cuda") for _ in ys]
+        torch.autograd.backward(list(ys), gs)
+        return [ys[0].detach(), xa.grad] + [p.grad for p in blk.parameters()], sum(gs)
 
     got, gsum = run(3)
     old, _ = run(0)

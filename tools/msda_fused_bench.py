@@ -48,12 +48,15 @@ def make(B, kind, offsets, dev, seed=0):
     if offsets.startswith("normal:"):
         # isotropic learned drift of sigma pixels (of each sampled level) around the query's own pixel
         off = float(offsets.split(":")[1]) * torch.randn(B, Lq, M, L, P, 2, device=dev, generator=g)
-    elif offsets == "init":
+    elif offsets == "init" or offsets.startswith("init:"):
+        # init:<sigma px> -- the drift around the pattern; 0.05 is what the train step bench.py times shows after its warm-up
+        # (tools/debug/offset_stats.py: 0.02 - 0.09 px per (head, level, point)), the default 0.3 a few hundred steps later
+        drift = float(offsets.split(":")[1]) if ":" in offsets else 0.3
         th = torch.arange(M, dtype=torch.float32, device=dev) * (2.0 * math.pi / M)
         d = torch.stack([th.cos(), th.sin()], -1)
         d = d / d.abs().max(-1, keepdim=True)[0]
         off = d[None, None, :, None, None, :] * torch.arange(1, P + 1, device=dev)[None, None, None, None, :, None]
-        off = off + 0.3 * torch.randn(B, Lq, M, L, P, 2, device=dev, generator=g)
+        off = off + drift * torch.randn(B, Lq, M, L, P, 2, device=dev, generator=g)
     else:
         off = torch.rand(B, Lq, M, L, P, 2, device=dev, generator=g) * 8 - 4
     logits = torch.randn(B, Lq, M, L * P, device=dev, generator=g)
