@@ -18,3 +18,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/c5_$C" -- python3 "$ROOT/tools/msda_fused_bench.py" --iters 3 --warmup 1 --kinds enc --resolution 1920x1280 --batch 4 > "$OUT/c5_$C.log" 2>&1
 done
 python3 "$ROOT/tools/pmc_summarize.py" "$OUT"
+# the raw counter tables are tens of MB each (gpurun copies at most 64 MiB back): keep the summary, the logs and the JSON
+for d in "$OUT"/calib_* "$OUT"/msda_* "$OUT"/c4_* "$OUT"/c5_*; do [ -d "$d" ] && rm -rf "$d"; done

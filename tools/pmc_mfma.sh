@@ -28,3 +28,4 @@ for g, u, cnt, k in sorted(rows, reverse=True)[:14]:
 w = sum(r[0] * r[1] for r in rows) / tot
 print("time-weighted MfmaUtil over these kernels: %.1f%%" % (100 * w))
 PY
+rm -rf "$OUT/run"
