@@ -28,7 +28,7 @@ struct DeviceState {
 
 std::mutex g_mutex;
 std::map<int, DeviceState> g_devices;
-int g_autotune = 8;
+int g_autotune = 32;
 
 // (kind, m, n, k, lda, ldb, ldc, ldd, flags) in the library's column-major terms
 typedef std::tuple<int, int, int, int, long long, long long, long long, long long, int> Key;

@@ -31,7 +31,7 @@ def load():
         lib.mono_gemm_set_autotune.restype = I
         lib.mono_gemm_set_autotune.argtypes = [I]
         lib.mono_gemm_cache_size.restype = I
-        n = os.environ.get("MONOSOWA_GEMM_AUTOTUNE")              # candidates timed per problem key (default 8; 1: the library's first choice)
+        n = os.environ.get("MONOSOWA_GEMM_AUTOTUNE")              # candidates timed per problem key (default 32; 1: the library's first choice)
         if n is not None:
             lib.mono_gemm_set_autotune(int(n))
         _lib = lib
