@@ -30,12 +30,19 @@ def weight_grad(g2, x2):
     if s:
         parts = torch.bmm(g2.view(s, -1, g2.shape[1]).transpose(1, 2), x2.view(s, -1, x2.shape[1]))
         return sum_slices(parts) if USE_SUM_SLICES else parts.sum(0)
-    return g2.t() @ x2
+    return small_weight_grad(g2, x2)
 
 
 # (Round 5, measured and NOT used: hipBLASLt's bias-gradient epilogue -- dW = dY^T X with db = the column sums of dY from the same launch,
 # gemm_lt.gemm_tn_bgrad through the C-ABI shim -- is correct (tests/test_gemm_lt_gpu.py) and slow: ~1 ms per call at [8800, 256] x
 # [8800, 256], +45 ms per train step when every token linear below MIN_TOKENS rows used it, tools/ab_step.py.  The column-sum kernels stay.)
+
+
+def small_weight_grad(g2, x2):
+    """dW = dY^T X below the sliced path (the decoder's 8,800 rows, the depth tokens' 30,720): torch.mm with the shipped TunableOp
+    choices.  (Round 5 A/B: the same product through the GEMM shim -- hipBLASLt's 32 best heuristic candidates timed per shape, split-K
+    ones included -- is 0.83 ms per step SLOWER; the tuned choices already are what the library has.)"""
+    return torch.mm(g2.t(), x2)
 
 
 class _TokenLinear(torch.autograd.Function):
@@ -58,7 +65,10 @@ class _TokenLinear(torch.autograd.Function):
         gw = None
         if need_w:
             x2 = x.reshape(-1, x.shape[-1])
-            gw = weight_grad(g2, x2) if x2.shape[0] >= MIN_TOKENS else torch.mm(g2.t(), x2)
+            if x2.shape[0] >= MIN_TOKENS:
+                gw = weight_grad(g2, x2)
+            else:
+                gw = small_weight_grad(g2, x2)
         gb = colsum(g2) if (ctx.has_bias and need_b) else None
         return gx, gw, gb
 
