@@ -31,6 +31,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
                                 // top instead of right in front of the MFMA that consumes them.  Measured round 4: 2.12 vs 2.09 ms on the
                                 // 1920 x 1920 backward -- the LDS round trips are not what the MFMA pipe waits for
 #endif
+#ifndef ATTN_OPDEPTH
+#define ATTN_OPDEPTH 0          // measurement builds: software-pipelining depth of the second-stage MFMAs' LDS operands (0: as the compiler places them)
+#endif
+#ifndef ATTN_OPDEPTH_KV
+#define ATTN_OPDEPTH_KV 0       // the same for bwd_dkdv's two operand streams (no scheduling directives there: with them the 170-register build spilled)
+#endif
+#ifndef ATTN_PRIO
+#define ATTN_PRIO 0             // measurement builds only: 1 = waves inside an MFMA cluster issue ahead of waves in their vector sections
+                                // (s_setprio 2 around the clusters), 2 = the inverse (vector sections first)
+#endif
+#define ATTN_PRIO_MFMA()  do { if (ATTN_PRIO == 1) __builtin_amdgcn_s_setprio(2); else if (ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(0); } while (0)
+#define ATTN_PRIO_VALU()  do { if (ATTN_PRIO == 1) __builtin_amdgcn_s_setprio(0); else if (ATTN_PRIO == 2) __builtin_amdgcn_s_setprio(2); } while (0)
 #ifndef ATTN_SKIP
 #define ATTN_SKIP 0             // measurement builds only (bits, backward kernels): 1 no exp2 of the recomputed scores, 2 no dropout hash,
                                 // 4 no second-stage MFMAs (dQ / dK, dV), 8 no recomputation MFMAs (S, dP), 16 no LDS reads of the A operands,
@@ -149,6 +161,7 @@ __global__ __launch_bounds__(256, (fwd_waves<DROP, MASK, BITS>())) void fwd_kern
     // S^T = K Q^T for the two 32-key halves of the tile
     f32x16 s0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s1 = s0;
     const float *k0 = &Ks[buf][r * kKStride + 16 * h], *k1 = k0 + 32 * kKStride;
+    ATTN_PRIO_MFMA();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float4 a0 = ld4(k0 + 4 * i), a1 = ld4(k1 + 4 * i);
@@ -157,6 +170,7 @@ __global__ __launch_bounds__(256, (fwd_waves<DROP, MASK, BITS>())) void fwd_kern
       s0 = mfma(a0.z, qreg[4 * i + 2], s0); s1 = mfma(a1.z, qreg[4 * i + 2], s1);
       s0 = mfma(a0.w, qreg[4 * i + 3], s0); s1 = mfma(a1.w, qreg[4 * i + 3], s1);
     }
+    ATTN_PRIO_VALU();
     const int key0 = kt * kTileK + 4 * h;                // + 8 (v >> 2) + (v & 3) (+ 32 for s1)
     if (MASK) {
       // The tile's 64 pad bits come through the scalar path: one uniform LDS read, two readfirstlanes, and per score a bit test of a
@@ -222,6 +236,7 @@ __global__ __launch_bounds__(256, (fwd_waves<DROP, MASK, BITS>())) void fwd_kern
       if (BITS) a.keep[keep_index(a, bh, blockIdx.x, kt, threadIdx.x)] = word;
     }
     // O^T += V^T P^T
+    ATTN_PRIO_MFMA();
     const float *v0 = &Vs[buf][(4 * h) * kVStride + r], *v1 = v0 + 32 * kVStride;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -233,6 +248,7 @@ __global__ __launch_bounds__(256, (fwd_waves<DROP, MASK, BITS>())) void fwd_kern
       const int row = 8 * (t >> 2) + (t & 3);
       o = mfma(v1[row * kVStride], s1[t], o);
     }
+    ATTN_PRIO_VALU();
     if (kt + 1 < n_tiles) store_tile(buf ^ 1);
     __syncthreads();
   }
@@ -320,6 +336,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dq_kernel(const Args 
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       f32x16 s = zero, dp = zero;
+      ATTN_PRIO_MFMA();
       const float *k0 = &Ks[buf][(half * 32 + r) * kKStride + 16 * h], *v0 = &Vs[buf][(half * 32 + r) * kKStride + 16 * h];
       const float *kc = &Ks[buf][(half * 32 + 4 * h) * kKStride + r];          // dQ^T += K^T dS^T : A = K[key(t, h)][d = r]
 #if ATTN_PREFETCH
@@ -345,6 +362,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dq_kernel(const Args 
         s = mfma(ka.z, qreg[4 * i + 2], s); dp = mfma(va.z, doreg[4 * i + 2], dp);
         s = mfma(ka.w, qreg[4 * i + 3], s); dp = mfma(va.w, doreg[4 * i + 3], dp);
       }
+      ATTN_PRIO_VALU();
       const int key0 = kt * kTileK + half * 32 + 4 * h;
       if (MASK) {
 #pragma unroll
@@ -370,6 +388,25 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dq_kernel(const Args 
         }
         s[v] = p * (dpe - delta);                                                          // dS^T
       }
+      ATTN_PRIO_MFMA();
+#if ATTN_OPDEPTH > 0 && !ATTN_PREFETCH
+      // the A operands of the second-stage MFMAs ATTN_OPDEPTH steps ahead of their use (an LDS round trip is longer than the one
+      // MFMA + ~14 vector instructions the compiler leaves between a read and its MFMA)
+      float kop[ATTN_OPDEPTH];
+#pragma unroll
+      for (int j = 0; j < ATTN_OPDEPTH; ++j) kop[j] = kc[(8 * (j >> 2) + (j & 3)) * kKStride];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float aop = kop[t % ATTN_OPDEPTH];
+        if (t + ATTN_OPDEPTH < 16) {
+          const int u = t + ATTN_OPDEPTH;
+          kop[t % ATTN_OPDEPTH] = kc[(8 * (u >> 2) + (u & 3)) * kKStride];
+        }
+        dq = mfma(aop, s[t], dq);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // this MFMA ...
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // ... then the read for step t + depth, not later
+      }
+#else
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         if (ATTN_SKIP & 4) { dq[t] += s[t]; continue; }
@@ -379,6 +416,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dq_kernel(const Args 
         dq = mfma((ATTN_SKIP & 16) ? qreg[t] : kc[(8 * (t >> 2) + (t & 3)) * kKStride], s[t], dq);
 #endif
       }
+#endif
     }
     if (kt + 1 < n_tiles) store_tile(buf ^ 1);
     __syncthreads();
@@ -471,6 +509,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dkdv_kernel(const Arg
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       f32x16 s = zero, dp = zero;
+      ATTN_PRIO_MFMA();
       const float *q0 = &Qs[buf][(half * 32 + r) * kKStride + 16 * h], *d0 = &Ds[buf][(half * 32 + r) * kKStride + 16 * h];
       const float *dc = &Ds[buf][(half * 32 + 4 * h) * kKStride + r], *qc = &Qs[buf][(half * 32 + 4 * h) * kKStride + r];
 #if ATTN_PREFETCH
@@ -499,6 +538,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dkdv_kernel(const Arg
         s = mfma(qa.z, kreg[4 * i + 2], s); dp = mfma(da.z, vreg[4 * i + 2], dp);
         s = mfma(qa.w, kreg[4 * i + 3], s); dp = mfma(da.w, vreg[4 * i + 3], dp);
       }
+      ATTN_PRIO_VALU();
       const int q0i = qt * kTileK + half * 32 + 4 * h;       // query of register v: q0i + 8 (v >> 2) + (v & 3)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -526,6 +566,26 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dkdv_kernel(const Arg
           s[v] = p * (dpe - es[j]);                            // dS       (operand of dK)
         }
       }
+      ATTN_PRIO_MFMA();
+#if ATTN_OPDEPTH_KV > 0 && !ATTN_PREFETCH
+      float dop[ATTN_OPDEPTH_KV], qop[ATTN_OPDEPTH_KV];      // (as in bwd_dq: the two A operands of step t + depth requested at step t)
+#pragma unroll
+      for (int j = 0; j < ATTN_OPDEPTH_KV; ++j) {
+        dop[j] = dc[(8 * (j >> 2) + (j & 3)) * kKStride];
+        qop[j] = qc[(8 * (j >> 2) + (j & 3)) * kKStride];
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float da_ = dop[t % ATTN_OPDEPTH_KV], qa_ = qop[t % ATTN_OPDEPTH_KV];
+        if (t + ATTN_OPDEPTH_KV < 16) {
+          const int u = t + ATTN_OPDEPTH_KV, rowu = (8 * (u >> 2) + (u & 3)) * kKStride;
+          dop[t % ATTN_OPDEPTH_KV] = dc[rowu];
+          qop[t % ATTN_OPDEPTH_KV] = qc[rowu];
+        }
+        dv = mfma(da_, dp[t], dv);
+        dk = mfma(qa_, s[t], dk);
+      }
+#else
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         if (ATTN_SKIP & 4) { dv[t] += dp[t]; dk[t] += s[t]; continue; }
@@ -538,6 +598,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dkdv_kernel(const Arg
         dk = mfma((ATTN_SKIP & 16) ? kreg[t] : qc[row], s[t], dk);
 #endif
       }
+#endif
     }
     if (qt + 1 < n_tiles) store_tile(buf ^ 1);
     __syncthreads();

@@ -47,6 +47,9 @@ typedef float rows_v2f __attribute__((ext_vector_type(2)));      // packed pair:
 // that rare path only, by one thread per workgroup and round.  Tests read it to prove that they reached the path.
 __device__ unsigned long long g_rows_overflow_rounds;
 
+#ifndef MSDA_ROWS_PRIO
+#define MSDA_ROWS_PRIO 0         // measurement builds only: wave priority by phase (1: scan above walk, 2: walk above scan)
+#endif
 #ifndef MSDA_ROWS_COUNT
 #define MSDA_ROWS_COUNT 0        // measurement builds only: scan census (msda_debug_counter("scan_*")) -- what the scan looked at and what it delivered
 #endif
@@ -253,6 +256,11 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
 
   for (int k = 0; k < n_batches; ++k) {
     ROWS_STAMP(0);
+#if MSDA_ROWS_PRIO == 1
+    __builtin_amdgcn_s_setprio(2);           // measurement builds: the load-issuing part of a batch ahead of the other workgroup's walk
+#elif MSDA_ROWS_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
     // ---- 0. the batch's grad_out rows: this thread's 32 bytes of its candidates' rows ---------------------------------------
     float4 g0[kRowSub], g1[kRowSub];
 #pragma unroll
@@ -325,6 +333,11 @@ __global__ __launch_bounds__(kRowThreads, MSDA_ROW_WAVES) void scatter_rows_kern
       c_next[u] = candidate(cand_index(k + 2, u));
     }
     ROWS_STAMP(1);
+#if MSDA_ROWS_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#elif MSDA_ROWS_PRIO == 2
+    __builtin_amdgcn_s_setprio(2);           // (the inverse: appends + walk first)
+#endif
     // ---- 2./3. buckets and cell sums; a cell whose bucket overflows (many points on one pixel) takes more rounds -----------
     bool again;
     do {
