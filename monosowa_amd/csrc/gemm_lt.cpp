@@ -42,9 +42,12 @@ int device_state(DeviceState &out) {
   if (it == g_devices.end()) {
     DeviceState s;
     hipblasStatus_t st = hipblasLtCreate(&s.handle);
-    if (st != HIPBLAS_STATUS_SUCCESS) return (int)st;
+    if (st != HIPBLAS_STATUS_SUCCESS) return (int)st == 0 ? 1 : (int)st;
     e = hipMalloc(&s.workspace, kWorkspaceBytes);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) {                       // nothing half-made stays behind: the next call starts over
+      hipblasLtDestroy(s.handle);
+      return (int)e;
+    }
     it = g_devices.emplace(dev, s).first;
   }
   out = it->second;
@@ -148,8 +151,15 @@ int run(const Problem &p, hipStream_t stream) {
       if (best < 0) { rc = MONO_GEMM_E_NO_ALGO; goto done; }
       it = g_algos.emplace(key, res[best].algo).first;
     }
-    LT_CHECK(hipblasLtMatmul(ds.handle, desc, alpha_ptr, p.a, la, p.b, lb, &p.beta, p.c ? p.c : p.d, lc, p.d, ld, &it->second, ds.workspace,
-                             kWorkspaceBytes, stream));
+    {
+      const hipblasStatus_t st = hipblasLtMatmul(ds.handle, desc, alpha_ptr, p.a, la, p.b, lb, &p.beta, p.c ? p.c : p.d, lc, p.d, ld, &it->second,
+                                                 ds.workspace, kWorkspaceBytes, stream);
+      if (st != HIPBLAS_STATUS_SUCCESS) {
+        g_algos.erase(it);                       // (a kernel that refuses these operands is not kept for the key)
+        rc = (int)st == 0 ? 1 : (int)st;
+        goto done;
+      }
+    }
   }
 done:
   if (pref) hipblasLtMatmulPreferenceDestroy(pref);

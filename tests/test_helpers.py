@@ -490,3 +490,54 @@ def test_dataloader_fed_batches_keep_the_loop_contract():
     assert seen == 2
     both = build_dataloader(cfg, workers=0)
     assert both[1] is not None and len(both[0]) == 3                      # the reference's behaviour: nothing dropped, a test loader
+
+
+def test_dense_flop_bookkeeping_of_the_own_kernels():
+    """monosowa_amd/flops.py: off by default (nothing recorded), counts 2 flop per multiply-add for the hand-written dense kernels when
+    bench.py's roofline.step switches it on; the attention backward counts the recomputed S once."""
+    from monosowa_amd import flops
+    flops.attention_forward(2, 8, 100, 200)            # not counting: no effect, no error
+    assert flops.stop() == {}
+    flops.start()
+    flops.attention_forward(2, 8, 100, 200)
+    flops.attention_backward(2, 8, 100, 200)
+    flops.conv1x1(1000, 64, 256)
+    flops.conv1x1(1000, 64, 256)
+    got = flops.stop()
+    assert got == {"attention_fwd": 2 * 2 * 2 * 8 * 100 * 200 * 32, "attention_bwd": 5 * 2 * 2 * 8 * 100 * 200 * 32,
+                   "conv1x1_fused": 2 * 2 * 1000 * 64 * 256}
+    assert flops.stop() == {}                           # stopped: a second stop has nothing
+
+
+def test_build_source_hash_follows_the_sources(tmp_path, monkeypatch):
+    """monosowa_amd/build.py: a library is rebuilt when the content hash of csrc/ + include/ + flags differs from the one recorded beside
+    it -- the hash must change with a source byte and with a flag, and not with file times."""
+    import os
+    import shutil
+    from monosowa_amd import build
+    root = tmp_path / "pkg"
+    (root / "csrc").mkdir(parents=True)
+    (tmp_path / "include").mkdir()
+    (root / "csrc" / "a.hip").write_text("int a;\n")
+    (tmp_path / "include" / "a.h").write_text("int a();\n")
+    monkeypatch.setattr(build, "HERE", str(root))
+    monkeypatch.setattr(build, "CSRC", str(root / "csrc"))
+    h0 = build.source_hash(["-O3"])
+    os.utime(root / "csrc" / "a.hip", (1, 1))
+    assert build.source_hash(["-O3"]) == h0
+    assert build.source_hash(["-O2"]) != h0
+    (root / "csrc" / "a.hip").write_text("int a ;\n")
+    assert build.source_hash(["-O3"]) != h0
+    (root / "csrc" / "a.hip").write_text("int a;\n")
+    assert build.source_hash(["-O3"]) == h0
+    (tmp_path / "include" / "a.h").write_text("int a(void);\n")
+    assert build.source_hash(["-O3"]) != h0
+    # _build_one: recompiles when the recorded hash differs, says "up to date" when it matches
+    out = str(tmp_path / "lib.so")
+    calls = []
+    monkeypatch.setattr(build.subprocess, "check_call", lambda cmd: (calls.append(cmd), open(out, "w").write("x"))[0])
+    assert build._build_one(out, ["cc"], "h1", False, False) is True
+    assert build._build_one(out, ["cc"], "h1", False, False) is False
+    assert build._build_one(out, ["cc"], "h2", False, False) is True
+    assert build._build_one(out, ["cc"], "h2", True, False) is True
+    assert len(calls) == 3
