@@ -45,6 +45,13 @@ def small_weight_grad(g2, x2):
     return torch.mm(g2.t(), x2)
 
 
+# (Round 5, measured and NOT used: dW and db of a small linear on a SIDE STREAM beside dX -- the three products are independent and each
+# fills a fraction of the chip (138 / 12 / 35 workgroups at 8,800 rows) -- with the side stream waiting for the main one and the main one
+# for the side stream inside the node, so that every returned gradient is complete in stream order: +1.55 ms per step (+2.35 in blocks of
+# four un-synchronised steps), tools/ab_step.py.  Two cross-stream dependencies per node cost more than the overlap returns on this
+# runtime, as round 3 had found for the MSDA plan.)
+
+
 class _TokenLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
