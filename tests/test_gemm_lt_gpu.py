@@ -56,3 +56,28 @@ def test_nn_and_strided_views():
     wt = torch.randn(64, 256, device="cuda")
     b = torch.randn(64, device="cuda")
     assert _rel(gemm_lt.gemm_nt(a, wt, None, b, None, True), (a.double() @ wt.double().t() + b.double()).clamp_min(0)) <= 2e-6
+
+
+def test_kernel_selection_is_cached_per_problem_key_and_can_skip_the_timing():
+    """One selection per (shape, epilogue) key: a repeated call adds nothing to the cache, another epilogue or shape adds one;
+    mono_gemm_set_autotune(1) takes the library's first choice without timing (no host synchronisation) and computes the same product."""
+    from monosowa_amd import gemm_lt
+    lib = gemm_lt.load()
+    torch.manual_seed(2)
+    a, w = torch.randn(640, 96, device="cuda"), torch.randn(48, 96, device="cuda")
+    b = torch.randn(48, device="cuda")
+    n0 = lib.mono_gemm_cache_size()
+    y1 = gemm_lt.gemm_nt(a, w, None, b, None, True)
+    n1 = lib.mono_gemm_cache_size()
+    y2 = gemm_lt.gemm_nt(a, w, None, b, None, True)
+    assert lib.mono_gemm_cache_size() == n1 == n0 + 1 and torch.equal(y1, y2)
+    gemm_lt.gemm_nt(a, w, None, b, None, False)                       # another epilogue: another key
+    assert lib.mono_gemm_cache_size() == n1 + 1
+    prev = lib.mono_gemm_set_autotune(1)
+    try:
+        a2 = torch.randn(704, 96, device="cuda")                       # a new shape, selected without timing
+        y3 = gemm_lt.gemm_nt(a2, w, None, b, None, True)
+        assert lib.mono_gemm_cache_size() == n1 + 2
+        assert _rel(y3, (a2.double() @ w.double().t() + b.double()).clamp_min(0)) <= 2e-6
+    finally:
+        assert lib.mono_gemm_set_autotune(prev) == 1
