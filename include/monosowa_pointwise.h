@@ -97,6 +97,15 @@ int mono_matched_losses_bwd_f32(const float *boxes, const float *depth, const fl
  * (int32 elements per chunk, any size), then wd[n_chunks] (float weight decay). */
 int mono_adamw_step_f32(const void *table, int n_chunks, double beta1, double beta2, double eps, double step_size, void *stream);
 
+/* dW[M, N] = dY[R, M]^T . X[R, N] and (db != NULL) db[M] = the column sums of dY, f32, exact products (v_mfma_f32_32x32x2_f32), summed in a
+ * fixed order (no atomics): the weight and bias gradients of y = x W^T + b over a few thousand tokens -- autograd's AddmmBackward of the
+ * nn.Linear layers of the decoder / depth-token encoder (reference depthaware_transformer.py:339-354,440-515) -- in two launches that
+ * read dY once.  Row-major, leading dimensions ldy / ldx in floats and multiples of 4, every pointer 16-byte aligned.
+ * mono_linear_wgrad_workspace: floats of scratch `ws` for the call; 0 = shape not served (M, N multiples of 64 up to 4096, R >= 64). */
+long long mono_linear_wgrad_workspace(int R, int M, int N);
+int mono_linear_wgrad_f32(const float *dy, long long ldy, const float *x, long long ldx, float *dw, float *db, float *ws, int R, int M,
+                          int N, void *stream);
+
 /* out[c] = sum_r g[r][c] for ANY width C <= 1024 (odd widths too: 81 depth bins); partials: mono_colsum_any_blocks(rows) * C floats. */
 int mono_colsum_any_blocks(long long rows);
 int mono_colsum_any_f32(const float *g, float *out, float *partials, long long rows, int C, void *stream);

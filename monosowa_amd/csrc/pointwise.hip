@@ -11,6 +11,7 @@
 #include "head_tail.hip"
 #include "lsap_device.hip"
 #include "conv1x1_fused.hip"
+#include "small_wgrad.hip"
 #include <stdint.h>
 #include <algorithm>
 
@@ -775,6 +776,28 @@ int mono_colsum_f32(const float *g, float *out, float *partials, long long rows,
   else if (C <= 512) mono::colsum_kernel<2><<<grid, 256, 0, st>>>(g, partials, rows, C, rpb, rows, 0);
   else mono::colsum_kernel<4><<<grid, 256, 0, st>>>(g, partials, rows, C, rpb, rows, 0);
   mono::partial_sum_kernel<<<(C / 4 + 63) / 64, 1024, 0, st>>>(partials, out, grid, C);
+  return (int)hipGetLastError();
+}
+
+// Weight and bias gradient of a linear over R tokens (small_wgrad.hip).  mono_linear_wgrad_workspace: floats of scratch the call needs,
+// 0 when the shape is not served (M, N multiples of 64, 64 <= R < 2^24).
+long long mono_linear_wgrad_workspace(int R, int M, int N) {
+  if (R < 64 || R >= (1 << 24) || M <= 0 || N <= 0 || M % 64 || N % 64 || M > 4096 || N > 4096) return 0;
+  return (long long)mono::linear_wgrad_splits(R, M, N) * ((long long)M * N + M);
+}
+int mono_linear_wgrad_f32(const float *dy, long long ldy, const float *x, long long ldx, float *dw, float *db, float *ws, int R, int M,
+                          int N, void *stream_) {
+  if (!dy || !x || !dw || !ws) return -1;
+  if (!mono_linear_wgrad_workspace(R, M, N) || ldy < M || ldx < N || ldy % 4 || ldx % 4 || ((size_t)dy | (size_t)x | (size_t)dw | (size_t)ws) % 16 ||
+      (db && (size_t)db % 16))
+    return -2;
+  hipStream_t st = (hipStream_t)stream_;
+  const int S = mono::linear_wgrad_splits(R, M, N);
+  const int rows_per_split = ((R + S - 1) / S + 1) / 2 * 2;
+  const int tiles = (M / 64) * (N / 64);
+  mono::linear_wgrad_partial_kernel<<<tiles * S, 256, 0, st>>>(dy, ldy, x, ldx, ws, R, M, N, S, rows_per_split);
+  const long long MN = (long long)M * N;
+  mono::linear_wgrad_reduce_kernel<<<(int)(((MN + M) / 4 + 255) / 256), 256, 0, st>>>(ws, dw, db, MN, M, S);
   return (int)hipGetLastError();
 }
 

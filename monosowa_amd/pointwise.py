@@ -13,7 +13,8 @@ _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmono
 SYMBOLS = ("mono_bias_act_f32", "mono_bias_relu_maxpool_nhwc_f32", "mono_conv1x1_tail_f32", "mono_conv1x1_tail_ds_f32", "mono_conv1x1_head_f32", "mono_relu_grad_f32", "mono_relu_grad2_f32", "mono_relu_grad3_f32", "mono_bias_relu_mask_f32", "mono_relu_grad_mask_f32", "mono_affine_relu_mask_f32", "mono_affine_relu_grad_f32", "mono_dropout_add_layernorm_fwd_f32",
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
-           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32", "mono_relu_dropout_bwd_colsum_f32", "mono_sum_slices_f32", "mono_colsum_any_blocks", "mono_colsum_any_f32", "mono_relu_grad_mask3_f32", "mono_lsap_match_flat_f32")
+           "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32", "mono_relu_dropout_bwd_colsum_f32", "mono_sum_slices_f32", "mono_colsum_any_blocks", "mono_colsum_any_f32", "mono_relu_grad_mask3_f32", "mono_lsap_match_flat_f32",
+           "mono_linear_wgrad_workspace", "mono_linear_wgrad_f32")
 _lib = None
 
 
@@ -86,6 +87,10 @@ def load():
         lib.mono_colsum_strided_f32.argtypes = [P, P, P, I, LL, LL, I, P]
         lib.mono_colsum_f32.restype = I
         lib.mono_colsum_f32.argtypes = [P, P, P, LL, I, P]
+        lib.mono_linear_wgrad_workspace.restype = LL
+        lib.mono_linear_wgrad_workspace.argtypes = [I, I, I]
+        lib.mono_linear_wgrad_f32.restype = I
+        lib.mono_linear_wgrad_f32.argtypes = [P, LL, P, LL, P, P, P, I, I, I, P]
         lib.mono_ddn_loss_blocks.restype = I
         lib.mono_ddn_loss_blocks.argtypes = [I, I, I]
         lib.mono_ddn_loss_fwd_f32.restype = I
@@ -601,6 +606,34 @@ def sum_slices(t):
 
 
 COLSUM_MAX_C = 512     # wider matrices: the PyTorch reduction is as fast
+
+
+def linear_wgrad_applies(g2, x2):
+    """True when ``linear_wgrad`` serves the pair: f32 GPU matrices with unit column stride, out / in features multiples of 64."""
+    return g2.is_cuda and g2.dtype == torch.float32 and x2.dtype == torch.float32 and g2.dim() == 2 and x2.dim() == 2 \
+        and g2.shape[0] == x2.shape[0] and g2.stride(1) == 1 and x2.stride(1) == 1 and g2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0 \
+        and g2.stride(0) >= g2.shape[1] and x2.stride(0) >= x2.shape[1] and g2.stride(0) % 4 == 0 and x2.stride(0) % 4 == 0 \
+        and load().mono_linear_wgrad_workspace(g2.shape[0], g2.shape[1], x2.shape[1]) > 0
+
+
+def linear_wgrad(g2, x2, with_bias=True):
+    """(g2^T @ x2, g2.sum(0) or None) for [rows, out] / [rows, in] matrices by `mono_linear_wgrad_f32` (csrc/small_wgrad.hip): the weight and
+    bias gradients of a linear over a few thousand tokens, two launches, dY read once.  Raises when the shape is not served."""
+    R, M = g2.shape
+    N = x2.shape[1]
+    lib = load()
+    n_ws = lib.mono_linear_wgrad_workspace(R, M, N)
+    if not n_ws or not linear_wgrad_applies(g2, x2):
+        raise ValueError("linear_wgrad: unsupported operands %s %s" % (tuple(g2.shape), tuple(x2.shape)))
+    ws = torch.empty(n_ws, dtype=torch.float32, device=g2.device)
+    out = torch.empty(M * N + M, dtype=torch.float32, device=g2.device)
+    p = out.data_ptr()
+    with on_device(g2.device):
+        code = lib.mono_linear_wgrad_f32(g2.data_ptr(), g2.stride(0), x2.data_ptr(), x2.stride(0), p, p + 4 * M * N if with_bias else None,
+                                         ws.data_ptr(), R, M, N, raw_stream())
+    if code:
+        raise RuntimeError("mono_linear_wgrad_f32 failed with code %d" % code)
+    return out[:M * N].view(M, N), (out[M * N:] if with_bias else None)
 
 
 def colsum(g2):

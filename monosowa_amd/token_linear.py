@@ -10,10 +10,11 @@ Same math as ``F.linear`` (fp32 summation order differs in the weight gradient: 
 import torch
 import torch.nn.functional as F
 
-from .pointwise import colsum, sum_slices
+from .pointwise import colsum, sum_slices, linear_wgrad, linear_wgrad_applies
 
 USE_SUM_SLICES = True     # the slices of a split-K weight gradient added by one coalesced pass (pointwise.sum_slices)
 MIN_TOKENS = 32768      # split-K weight gradient from here on
+SMALL_WGRAD_KERNEL = int(__import__('os').environ.get('MONOSOWA_SMALL_WGRAD', '1'))   # dW + db below MIN_TOKENS by csrc/small_wgrad.hip
 MIN_ROWS = int(__import__('os').environ.get('MONOSOWA_TL_MIN_ROWS', '32768'))   # our backward from here on
 
 
@@ -70,13 +71,17 @@ class _TokenLinear(torch.autograd.Function):
             g2 = g2.contiguous()
         gx = torch.mm(g2, weight).view(x.shape) if need_x else None
         gw = None
+        need_b = ctx.has_bias and need_b
         if need_w:
             x2 = x.reshape(-1, x.shape[-1])
             if x2.shape[0] >= MIN_TOKENS:
                 gw = weight_grad(g2, x2)
+            elif SMALL_WGRAD_KERNEL and x2.shape[0] >= 64 and g2.shape[1] % 64 == 0 and x2.shape[1] % 64 == 0 and linear_wgrad_applies(g2, x2):
+                gw, gb = linear_wgrad(g2, x2, need_b)             # one pass over dY for both gradients
+                return gx, gw, gb
             else:
                 gw = small_weight_grad(g2, x2)
-        gb = colsum(g2) if (ctx.has_bias and need_b) else None
+        gb = colsum(g2) if need_b else None
         return gx, gw, gb
 
 
