@@ -793,7 +793,8 @@ int mono_linear_wgrad_f32(const float *dy, long long ldy, const float *x, long l
     return -2;
   hipStream_t st = (hipStream_t)stream_;
   const int S = mono::linear_wgrad_splits(R, M, N);
-  const int rows_per_split = ((R + S - 1) / S + 1) / 2 * 2;
+  // whole stages per split (only the matrix's last rows leave a tail: a tail is a chain of exposed memory latencies)
+  const int rows_per_split = ((R + S - 1) / S + mono::kWgStageRows - 1) / mono::kWgStageRows * mono::kWgStageRows;
   const int tiles = (M / 64) * (N / 64);
   mono::linear_wgrad_partial_kernel<<<tiles * S, 256, 0, st>>>(dy, ldy, x, ldx, ws, R, M, N, S, rows_per_split);
   const long long MN = (long long)M * N;

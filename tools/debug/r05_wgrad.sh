@@ -4,8 +4,4 @@ OUT=${1:-gpurun_out/r05_wgrad}
 mkdir -p $OUT
 python -m pytest tests/test_linear_wgrad_gpu.py -m gpu -x -q > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log
 python tools/debug/wgrad_time.py > $OUT/time_default.log 2>&1; cat $OUT/time_default.log
-for v in p8_w512 p16_w512 p8_w1024 p16_w1024 p4_w1024 p16_w256; do
-  echo "== $v" | tee -a $OUT/time_variants.log
-  MONOSOWA_POINTWISE_LIB=tools/debug/variants/pw_$v.so python tools/debug/wgrad_time.py 8800 256 256 2>&1 | tee -a $OUT/time_variants.log
-done
 python tools/ab_step.py monosowa_amd.token_linear.SMALL_WGRAD_KERNEL 0 1 --steps 80 > $OUT/ab.log 2>&1; tail -8 $OUT/ab.log

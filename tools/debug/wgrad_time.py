@@ -25,6 +25,8 @@ def main():
         shapes = [tuple(int(v) for v in sys.argv[1:4])]
     for R, M, N in shapes:
         gy = torch.randn(R, M, device="cuda"); x = torch.randn(R, N, device="cuda")
+        if os.environ.get("WGRAD_ZEROS"):                    # all-zero operands: what the data costs the matrix pipe (power management)
+            gy.zero_(); x.zero_()
         w = torch.randn(M, M, device="cuda")
         ours = timed(lambda: linear_wgrad(gy, x))
         lib = timed(lambda: (torch.mm(gy.t(), x), colsum(gy)))
