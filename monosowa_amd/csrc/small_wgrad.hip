@@ -15,6 +15,9 @@
 //        bias gradient costs one v_add per MFMA and no second pass.  Splits are the FAST index of the grid and a multiple of 8: a split's
 //        rows are read by one XCD only (blockIdx % 8), each L2 sees R / 8 rows of both matrices; every split is a whole number of stages.
 //   linear_wgrad_reduce_kernel    sums the S partial [M N + M] images in split order -- no atomics, the result is deterministic.
+//        (Folded into the first launch -- every workgroup releases its image with an agent-scope fence and counts itself in, the last one
+//        of a tile adds the tile's images -- the pair took 50.6 us instead of 21.8 and the step +1.9 ms: the fence is an L2 write-back
+//        per wave.  Bit-identical, measured, removed.)
 //
 // Measured, [8800, 256] x [8800, 256] stand-alone (tools/debug/r05_wgrad_prof.sh, in-kernel s_memtime stamps since removed, tools/ubench/mfma_f32_chain.hip): 17.3 us +
 // 4.4 us for the reduction, against the library's 18.6 (25.7 inside the step) + 7.5 + 5.1 for the column sums.  The matrix pipe's floor is

@@ -608,29 +608,41 @@ def sum_slices(t):
 COLSUM_MAX_C = 512     # wider matrices: the PyTorch reduction is as fast
 
 
+_WGRAD_WS = {}          # (rows, out, in) -> floats of workspace (0: shape not served); saves a library call per launch
+
+
+def _wgrad_workspace(R, M, N):
+    n = _WGRAD_WS.get((R, M, N))
+    if n is None:
+        n = _WGRAD_WS[(R, M, N)] = load().mono_linear_wgrad_workspace(R, M, N)
+    return n
+
+
 def linear_wgrad_applies(g2, x2):
-    """True when ``linear_wgrad`` serves the pair: f32 GPU matrices with unit column stride, out / in features multiples of 64."""
-    return g2.is_cuda and g2.dtype == torch.float32 and x2.dtype == torch.float32 and g2.dim() == 2 and x2.dim() == 2 \
-        and g2.shape[0] == x2.shape[0] and g2.stride(1) == 1 and x2.stride(1) == 1 and g2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0 \
-        and g2.stride(0) >= g2.shape[1] and x2.stride(0) >= x2.shape[1] and g2.stride(0) % 4 == 0 and x2.stride(0) % 4 == 0 \
-        and load().mono_linear_wgrad_workspace(g2.shape[0], g2.shape[1], x2.shape[1]) > 0
+    """True when ``linear_wgrad`` serves the pair: f32 GPU matrices with unit column stride, 16-byte aligned rows, out / in features
+    multiples of 64, at least 64 rows."""
+    if not (g2.is_cuda and g2.dtype == torch.float32 and x2.dtype == torch.float32 and g2.dim() == 2 and x2.dim() == 2):
+        return False
+    (R, M), (R2, N) = g2.shape, x2.shape
+    sg, sx = g2.stride(), x2.stride()
+    return R == R2 and sg[1] == 1 and sx[1] == 1 and sg[0] >= M and sx[0] >= N and sg[0] % 4 == 0 and sx[0] % 4 == 0 \
+        and g2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0 and _wgrad_workspace(R, M, N) > 0
 
 
-def linear_wgrad(g2, x2, with_bias=True):
+def linear_wgrad(g2, x2, with_bias=True, checked=False):
     """(g2^T @ x2, g2.sum(0) or None) for [rows, out] / [rows, in] matrices by `mono_linear_wgrad_f32` (csrc/small_wgrad.hip): the weight and
-    bias gradients of a linear over a few thousand tokens, two launches, dY read once.  Raises when the shape is not served."""
+    bias gradients of a linear over a few thousand tokens, two launches, dY read once.  Raises when the shape is not served
+    (``checked``: the caller has asked ``linear_wgrad_applies`` already -- the host side of this call is on the step's critical path)."""
+    if not checked and not linear_wgrad_applies(g2, x2):
+        raise ValueError("linear_wgrad: unsupported operands %s %s" % (tuple(g2.shape), tuple(x2.shape)))
     R, M = g2.shape
     N = x2.shape[1]
-    lib = load()
-    n_ws = lib.mono_linear_wgrad_workspace(R, M, N)
-    if not n_ws or not linear_wgrad_applies(g2, x2):
-        raise ValueError("linear_wgrad: unsupported operands %s %s" % (tuple(g2.shape), tuple(x2.shape)))
-    ws = torch.empty(n_ws, dtype=torch.float32, device=g2.device)
+    ws = torch.empty(_wgrad_workspace(R, M, N), dtype=torch.float32, device=g2.device)
     out = torch.empty(M * N + M, dtype=torch.float32, device=g2.device)
     p = out.data_ptr()
     with on_device(g2.device):
-        code = lib.mono_linear_wgrad_f32(g2.data_ptr(), g2.stride(0), x2.data_ptr(), x2.stride(0), p, p + 4 * M * N if with_bias else None,
-                                         ws.data_ptr(), R, M, N, raw_stream())
+        code = load().mono_linear_wgrad_f32(g2.data_ptr(), g2.stride(0), x2.data_ptr(), x2.stride(0), p, p + 4 * M * N if with_bias else None,
+                                            ws.data_ptr(), R, M, N, raw_stream())
     if code:
         raise RuntimeError("mono_linear_wgrad_f32 failed with code %d" % code)
     return out[:M * N].view(M, N), (out[M * N:] if with_bias else None)

@@ -76,8 +76,8 @@ class _TokenLinear(torch.autograd.Function):
             x2 = x.reshape(-1, x.shape[-1])
             if x2.shape[0] >= MIN_TOKENS:
                 gw = weight_grad(g2, x2)
-            elif SMALL_WGRAD_KERNEL and x2.shape[0] >= 64 and g2.shape[1] % 64 == 0 and x2.shape[1] % 64 == 0 and linear_wgrad_applies(g2, x2):
-                gw, gb = linear_wgrad(g2, x2, need_b)             # one pass over dY for both gradients
+            elif SMALL_WGRAD_KERNEL and linear_wgrad_applies(g2, x2):
+                gw, gb = linear_wgrad(g2, x2, need_b, True)       # one pass over dY for both gradients
                 return gx, gw, gb
             else:
                 gw = small_weight_grad(g2, x2)
