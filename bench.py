@@ -299,7 +299,7 @@ def count_dense_flops(step, batch):
     """Dense FLOPs of ONE step, counted where they are issued (not from a formula of the model): every aten mm / addmm / bmm /
     convolution / convolution_backward the step dispatches -- forward and the backward parts that exist (no gradient below layer2:
     convolution_backward is counted with the output mask it is called with) -- plus what this repo's own dense kernels report
-    (monosowa_amd/flops.py: HIP attention forward / backward, the frozen bottlenecks' fused 1 x 1 convolutions).  MSDA's bilinear
+    (monosowa_amd/flops.py: HIP attention forward / backward, the frozen bottlenecks' fused 1 x 1 convolutions, the small linears' weight gradients).  MSDA's bilinear
     gather / scatter is not a dense contraction and is not in this number (it has its own HBM roofline above).  One extra,
     untimed step."""
     import torch

@@ -38,3 +38,8 @@ def attention_backward(B, H, Lq, Lk, d=32):
 
 def conv1x1(M, K, N):
     add("conv1x1_fused", 2 * M * K * N)
+
+
+def linear_wgrad(R, M, N):
+    """dW[M, N] = dY[R, M]^T X[R, N] by csrc/small_wgrad.hip (the product torch.mm would have reported; the column sums are not counted)"""
+    add("linear_wgrad", 2 * R * M * N)

@@ -637,6 +637,7 @@ def linear_wgrad(g2, x2, with_bias=True, checked=False):
         raise ValueError("linear_wgrad: unsupported operands %s %s" % (tuple(g2.shape), tuple(x2.shape)))
     R, M = g2.shape
     N = x2.shape[1]
+    flops.linear_wgrad(R, M, N)
     ws = torch.empty(_wgrad_workspace(R, M, N), dtype=torch.float32, device=g2.device)
     out = torch.empty(M * N + M, dtype=torch.float32, device=g2.device)
     p = out.data_ptr()

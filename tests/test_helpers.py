@@ -503,9 +503,10 @@ def test_dense_flop_bookkeeping_of_the_own_kernels():
     flops.attention_backward(2, 8, 100, 200)
     flops.conv1x1(1000, 64, 256)
     flops.conv1x1(1000, 64, 256)
+    flops.linear_wgrad(8800, 256, 128)
     got = flops.stop()
     assert got == {"attention_fwd": 2 * 2 * 2 * 8 * 100 * 200 * 32, "attention_bwd": 5 * 2 * 2 * 8 * 100 * 200 * 32,
-                   "conv1x1_fused": 2 * 2 * 1000 * 64 * 256}
+                   "conv1x1_fused": 2 * 2 * 1000 * 64 * 256, "linear_wgrad": 2 * 8800 * 256 * 128}
     assert flops.stop() == {}                           # stopped: a second stop has nothing
 
 

@@ -1,6 +1,6 @@
 """Category summary of a rocprofv3 run of bench.py:
     python tools/summarize_kernel_stats.py <..._kernel_stats.csv> <steps in the run>
-    python tools/summarize_kernel_stats.py <..._kernel_trace.csv> <last K steps to summarise>"""
+    python tools/summarize_kernel_stats.py <..._kernel_trace.csv> <last K steps to summarise> [kernels to list, default 25]"""
 import csv
 import sys
 
@@ -79,7 +79,8 @@ def main():
     for c, (t, n) in sorted(cats.items(), key=lambda kv: -kv[1][0]):
         print("%-26s %7.2f ms/step %5.1f%%  %6.0f launches/step" % (c, t / 1e6 / steps, 100 * t / tot, n / steps))
     print()
-    for r in rows[:25]:
+    top = int(sys.argv[3]) if len(sys.argv) > 3 else 25         # third argument: how many kernels to list
+    for r in rows[:top]:
         print("%5.2f%% %7.2f ms/step %5.0f x %8.1f us  %s" % (float(r["Percentage"]), float(r["TotalDurationNs"]) / 1e6 / steps,
                                                            int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3, r["Name"][:100]))
 
