@@ -14,7 +14,7 @@ SYMBOLS = ("mono_bias_act_f32", "mono_bias_relu_maxpool_nhwc_f32", "mono_conv1x1
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
            "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32", "mono_relu_dropout_bwd_colsum_f32", "mono_sum_slices_f32", "mono_colsum_any_blocks", "mono_colsum_any_f32", "mono_relu_grad_mask3_f32", "mono_lsap_match_flat_f32",
-           "mono_linear_wgrad_workspace", "mono_linear_wgrad_f32")
+           "mono_linear_wgrad_workspace", "mono_linear_wgrad_f32", "mono_colsum_levels_blocks", "mono_colsum_levels_f32")
 _lib = None
 
 
@@ -85,6 +85,10 @@ def load():
         lib.mono_adamw_step_f32.argtypes = [P, I] + [ctypes.c_double] * 4 + [P]
         lib.mono_colsum_strided_f32.restype = I
         lib.mono_colsum_strided_f32.argtypes = [P, P, P, I, LL, LL, I, P]
+        lib.mono_colsum_levels_blocks.restype = I
+        lib.mono_colsum_levels_blocks.argtypes = [I, LL, I, P]
+        lib.mono_colsum_levels_f32.restype = I
+        lib.mono_colsum_levels_f32.argtypes = [P, P, P, I, LL, I, I, P, P]
         lib.mono_colsum_f32.restype = I
         lib.mono_colsum_f32.argtypes = [P, P, P, LL, I, P]
         lib.mono_linear_wgrad_workspace.restype = LL
@@ -545,12 +549,30 @@ def conv_group_norm(x, conv, gn, relu=False):
     return group_norm(conv(x), gn, relu)
 
 
+COLSUM_LEVELS_ONE_LAUNCH = 1     # all levels by one launch pair (mono_colsum_levels_f32); 0: a launch pair per level
+_LEVEL_PLANS = {}                # (B, S, bounds) -> (ctypes int array, partial rows)
+
+
 def colsum_levels(g3, bounds):
-    """Per-level column sums of a [B, S, C] tensor (contiguous, C <= 256): rows [a, b) of every batch for each (a, b)
+    """Per-level column sums of a [B, S, C] tensor (contiguous, C <= 512): rows [a, b) of every batch for each (a, b)
     in ``bounds`` -> [len(bounds), C]."""
     B, S, C = g3.shape
     out = torch.empty((len(bounds), C), dtype=torch.float32, device=g3.device)
     lib = load()
+    if COLSUM_LEVELS_ONE_LAUNCH and len(bounds) <= 8 and C % 4 == 0 and C <= 512:
+        key = (B, S, tuple(tuple(ab) for ab in bounds))
+        plan = _LEVEL_PLANS.get(key)
+        if plan is None:
+            arr = (ctypes.c_int * (2 * len(bounds)))(*[int(v) for ab in bounds for v in ab])
+            plan = _LEVEL_PLANS[key] = (arr, lib.mono_colsum_levels_blocks(B, S, len(bounds), arr))
+        arr, blocks = plan
+        if blocks > 0:
+            partials = torch.empty(blocks * C, dtype=torch.float32, device=g3.device)
+            with on_device(g3.device):
+                code = lib.mono_colsum_levels_f32(g3.data_ptr(), out.data_ptr(), partials.data_ptr(), B, S, C, len(bounds), arr, raw_stream())
+            if code:
+                raise RuntimeError("mono_colsum_levels_f32 failed with code %d" % code)
+            return out
     with on_device(g3.device):
         st = raw_stream()
         for i, (a, b) in enumerate(bounds):

@@ -908,6 +908,31 @@ def test_colsum_matches_torch(rows, C):
     assert (got.double() - ref).abs().max() <= 2e-6 * g.abs().double().sum(0).max()
 
 
+@pytest.mark.parametrize("B,S,C,bounds", [(16, 10200, 384, [(0, 7680), (7680, 9600), (9600, 10080), (10080, 10200)]),
+                                          (4, 777, 256, [(0, 1), (1, 400), (500, 777)]),
+                                          (2, 300, 128, [(0, 300)]),
+                                          (3, 1000, 512, [(10, 20), (0, 1000), (999, 1000), (5, 6), (100, 900), (0, 64), (64, 128), (128, 129)])])
+def test_colsum_levels_one_launch_equals_float64_and_the_per_level_launches(B, S, C, bounds):
+    """pointwise.colsum_levels (mono_colsum_levels_f32: the encoder's per-pyramid-level sums of d proj, depthaware_transformer.py:232-240):
+    one launch pair over all levels against float64, and against the launch-pair-per-level form it replaces (overlapping and
+    gapped ranges included: the ranges are independent)."""
+    from monosowa_amd import pointwise as pw
+    torch.manual_seed(B * S + C)
+    g = torch.randn(B, S, C, device="cuda")
+    ref = torch.stack([g[:, a:b].double().sum((0, 1)) for a, b in bounds])
+    got = pw.colsum_levels(g, bounds)
+    assert got.shape == (len(bounds), C)
+    scale = max(g.abs().double().sum((0, 1)).max().item(), 1.0)
+    assert (got.double() - ref).abs().max() <= 2e-6 * scale
+    try:
+        pw.COLSUM_LEVELS_ONE_LAUNCH = 0
+        per_level = pw.colsum_levels(g, bounds)
+    finally:
+        pw.COLSUM_LEVELS_ONE_LAUNCH = 1
+    assert (per_level.double() - ref).abs().max() <= 2e-6 * scale
+    assert torch.equal(pw.colsum_levels(g, bounds), got)               # fixed summation order
+
+
 def test_sum_slices_and_channel_bias():
     """pointwise.sum_slices (the slices of a split-K weight gradient) and conv_channel_bias (bias-free convolution + bias node
     whose gradient is a row sum of the channels-last gradient, odd channel counts included) against plain PyTorch."""
