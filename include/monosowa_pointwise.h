@@ -33,6 +33,9 @@ int mono_conv1x1_head_f32(const float *x, const float *w, const float *b_out, fl
 
 /* grad_in[i] = y[i] > 0 ? grad_out[i] : 0   (n % 4 == 0; grad_in may alias grad_out). */
 int mono_relu_grad_f32(const float *grad_out, const float *y, float *grad_in, long long n, void *stream);
+/* grad_in = scale[c] * grad_out * (y > 0) on a channels-last tensor of n elements, C channels (C % 4 == 0, n % C == 0): the same with the
+ * frozen norm's scale put on the gradient (trainable 1 x 1 convolution + frozen BN + ReLU without an identity branch, backbone.py:72-115). */
+int mono_relu_grad_scale_f32(const float *grad_out, const float *y, const float *scale, float *grad_in, long long n, int C, void *stream);
 
 /* ReLU with a byte mask: y = relu(y + bias (+ residual)) in place and mask[i] = sign bits of elements 4i..4i+3 (one byte
  * per float4); the backward below reads the mask instead of y (1/16 of the bytes).  grad_b may be NULL. */

@@ -157,6 +157,21 @@ __global__ __launch_bounds__(256) void relu_grad_kernel(const float *__restrict_
   }
 }
 
+// grad_in = scale[channel] * grad_out * (y > 0) on a channels-last tensor (c_vec = C / 4 float4 per pixel): the ReLU backward of a
+// trainable 1 x 1 convolution + frozen norm WITHOUT an identity branch, with the norm's scale already on the gradient -- both of its
+// consumers (dX = g' W, dW = g'^T x) then need no scaled copy of the weight / no rescaling of the weight gradient (2 launches per node)
+__global__ __launch_bounds__(256) void relu_grad_scale_kernel(const float *__restrict__ grad_out, const float *__restrict__ y,
+                                                              const float *__restrict__ scale, float *__restrict__ grad_in, long long n_vec,
+                                                              int c_vec) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    const float4 g = reinterpret_cast<const float4 *>(grad_out)[i], v = reinterpret_cast<const float4 *>(y)[i];
+    const float4 sc = reinterpret_cast<const float4 *>(scale)[i % c_vec];
+    reinterpret_cast<float4 *>(grad_in)[i] = make_float4(v.x > 0.f ? g.x * sc.x : 0.f, v.y > 0.f ? g.y * sc.y : 0.f,
+                                                         v.z > 0.f ? g.z * sc.z : 0.f, v.w > 0.f ? g.w * sc.w : 0.f);
+  }
+}
+
 // grad_in = (grad_a + grad_b) * (y > 0): the two consumers of a block output (next conv and the identity branch) and
 // the ReLU backward in one pass (autograd would run an accumulation add and then the ReLU backward)
 __global__ __launch_bounds__(256) void relu_grad2_kernel(const float *__restrict__ ga, const float *__restrict__ gb,
@@ -720,6 +735,15 @@ int mono_relu_grad_f32(const float *grad_out, const float *y, float *grad_in, lo
   if (!grad_out || !y || !grad_in) return -1;
   if (n <= 0 || (n & 3) || ((uintptr_t)grad_out & 15) || ((uintptr_t)y & 15) || ((uintptr_t)grad_in & 15)) return -2;
   mono::relu_grad_kernel<<<mono::grid_for_vec(n / 4), 256, 0, (hipStream_t)stream_>>>(grad_out, y, grad_in, n / 4);
+  return (int)hipGetLastError();
+}
+
+// grad_in = scale[c] * grad_out * (y > 0), channels-last [.., C] with n elements in all; C % 4 == 0, n % C == 0.
+int mono_relu_grad_scale_f32(const float *grad_out, const float *y, const float *scale, float *grad_in, long long n, int C, void *stream_) {
+  if (!grad_out || !y || !scale || !grad_in) return -1;
+  if (n <= 0 || C <= 0 || (C & 3) || n % C || ((uintptr_t)grad_out & 15) || ((uintptr_t)y & 15) || ((uintptr_t)grad_in & 15) || ((uintptr_t)scale & 15))
+    return -2;
+  mono::relu_grad_scale_kernel<<<mono::grid_for_vec(n / 4), 256, 0, (hipStream_t)stream_>>>(grad_out, y, scale, grad_in, n / 4, C / 4);
   return (int)hipGetLastError();
 }
 

@@ -118,6 +118,7 @@ def _summed_shift(bn, other):
 # Bits (A/B: tools/ab_step.py monosowa_amd.monodetr.backbone.CONV1X1_EPILOGUE 0 3): 1 forward through the epilogue GEMM, 2 input
 # gradient through the library GEMM (else MIOpen's backward-data solver).
 CONV1X1_EPILOGUE = int(os.environ.get("MONOSOWA_CONV1X1_EPILOGUE", "3"))
+CONV1X1_SCALED_GRAD = 1      # nodes without an identity branch: the frozen norm's scale inside the ReLU backward's pass (2 launches fewer)
 
 
 def _pixels(t):
@@ -146,11 +147,15 @@ class _Conv1x1BnAct(torch.autograd.Function):
         x, w, scale, y = ctx.saved_tensors
         N, C, H, W = x.shape
         K = w.shape[0]
-        g = relu_grad_from_output([t for t in grads if t is not None], y)          # (sum of the consumers' gradients) * (y > 0), one pass
+        given = [t for t in grads if t is not None]
+        # Without an identity branch and with one consumer (conv1 of a bottleneck) the norm's scale goes onto the gradient inside the
+        # ReLU backward's pass: dX = g' w and dW = g'^T x need neither a scaled copy of the weight nor a rescaled weight gradient.
+        pre_scaled = bool(CONV1X1_SCALED_GRAD) and not ctx.has_res and len(given) == 1 and scale.data_ptr() % 16 == 0 and scale.is_contiguous()
+        g = relu_grad_from_output(given, y, scale if pre_scaled else None)         # (sum of the consumers' gradients) * (y > 0), one pass
         gx = gw = None
         w2 = w.reshape(K, C)
         if ctx.needs_input_grad[0]:
-            ws = w2 * scale.view(-1, 1)                                             # [out, in]: the scale rides on the (small) weight
+            ws = w2 if pre_scaled else w2 * scale.view(-1, 1)                       # [out, in]: the scale rides on the (small) weight
             if CONV1X1_EPILOGUE & 2:
                 gx = torch.empty_like(x)
                 gemm_lt.gemm_nn(_pixels(g), ws, out=_pixels(gx))
@@ -161,7 +166,8 @@ class _Conv1x1BnAct(torch.autograd.Function):
             # (MIOpen's weight-gradient solver: the library's own split-K TN GEMM for it -- gemm_lt.gemm_tn_bgrad, timed candidates --
             # measured +3.2 ms per step, PyTorch's sliced bmm +3.4 ms: round 5 A/Bs)
             gw = torch.ops.aten.convolution_backward(g, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1, (False, True, False))[1]
-            gw = gw * scale.view(-1, 1, 1, 1)
+            if not pre_scaled:
+                gw = gw * scale.view(-1, 1, 1, 1)
         return gx, gw, None, None, (g if ctx.has_res else None), None
 
 

@@ -14,7 +14,7 @@ SYMBOLS = ("mono_bias_act_f32", "mono_bias_relu_maxpool_nhwc_f32", "mono_conv1x1
            "mono_dropout_add_layernorm_bwd_f32", "mono_groupnorm_nhwc_fwd_f32", "mono_groupnorm_nhwc_bwd_f32", "mono_groupnorm_blocks", "mono_colsum_f32", "mono_colsum_strided_f32", "mono_reduce_blocks", "mono_adamw_step_f32", "mono_relu_dropout_fwd_f32",
            "mono_relu_dropout_bwd_f32", "mono_matched_losses_fwd_f32", "mono_matched_losses_bwd_f32", "mono_ddn_loss_blocks",
            "mono_ddn_loss_fwd_f32", "mono_ddn_loss_bwd_f32", "mono_depth_expect_fwd_f32", "mono_depth_expect_bwd_f32", "mono_focal_fwd_f32", "mono_focal_bwd_f32", "mono_head_tail_fwd_f32", "mono_head_tail_bwd_f32", "mono_match_cost_f32", "mono_refine_reference_f32", "mono_relu_dropout_bwd_colsum_f32", "mono_sum_slices_f32", "mono_colsum_any_blocks", "mono_colsum_any_f32", "mono_relu_grad_mask3_f32", "mono_lsap_match_flat_f32",
-           "mono_linear_wgrad_workspace", "mono_linear_wgrad_f32", "mono_colsum_levels_blocks", "mono_colsum_levels_f32")
+           "mono_linear_wgrad_workspace", "mono_linear_wgrad_f32", "mono_colsum_levels_blocks", "mono_colsum_levels_f32", "mono_relu_grad_scale_f32")
 _lib = None
 
 
@@ -38,6 +38,8 @@ def load():
         lib.mono_conv1x1_tail_ds_f32.argtypes = [P, P, P, P, P, P, P, LL, I, I, P]
         lib.mono_relu_grad_f32.restype = I
         lib.mono_relu_grad_f32.argtypes = [P, P, P, LL, P]
+        lib.mono_relu_grad_scale_f32.restype = I
+        lib.mono_relu_grad_scale_f32.argtypes = [P, P, P, P, LL, I, P]
         lib.mono_bias_relu_mask_f32.restype = I
         lib.mono_bias_relu_mask_f32.argtypes = [P, P, P, P, LL, I, P]
         lib.mono_relu_grad_mask_f32.restype = I
@@ -266,16 +268,21 @@ class _BiasActFork(torch.autograd.Function):
         return g, (g.sum((0, 2, 3)) if ctx.bias_grad else None), g, None
 
 
-def relu_grad_from_output(grads, y):
+def relu_grad_from_output(grads, y, scale=None):
     """``(sum of grads) * (y > 0)`` for the 1 - 3 gradients a ReLU output's consumers returned, in ONE pass that reads the mask off
-    the output itself (channels-last float32; the epilogue-GEMM bottleneck paths of backbone.py keep no byte mask)."""
+    the output itself (channels-last float32; the epilogue-GEMM bottleneck paths of backbone.py keep no byte mask).
+    ``scale`` (one gradient only): a per-channel factor put on the result in the same pass."""
     cl = lambda t: t.contiguous(memory_format=torch.channels_last)
     given = [cl(t) for t in grads]
     g = torch.empty(y.shape, dtype=torch.float32, device=y.device, memory_format=torch.channels_last)
     n = g.numel()
     lib = load()
+    if scale is not None and len(given) != 1:
+        raise ValueError("relu_grad_from_output: a scale goes with exactly one gradient")
     with on_device(y.device):
-        if len(given) == 3:
+        if scale is not None:
+            code = lib.mono_relu_grad_scale_f32(given[0].data_ptr(), y.data_ptr(), scale.data_ptr(), g.data_ptr(), n, y.shape[1], raw_stream())
+        elif len(given) == 3:
             code = lib.mono_relu_grad3_f32(given[0].data_ptr(), given[1].data_ptr(), given[2].data_ptr(), y.data_ptr(), g.data_ptr(), n, raw_stream())
         elif len(given) == 2:
             code = lib.mono_relu_grad2_f32(given[0].data_ptr(), given[1].data_ptr(), y.data_ptr(), g.data_ptr(), n, raw_stream())

@@ -253,3 +253,55 @@ def test_trainable_bottleneck_through_epilogue_gemms_equals_float64(downsample, 
     for name, a, b, c in zip(["out", "grad_x"] + names, got, want, old):
         assert _rel(a, b) <= 2e-5, (name, _rel(a, b))
         assert _rel(c, b) <= 2e-5, ("module path " + name, _rel(c, b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,H,W", [(2, 128, 48, 160), (1, 4, 3, 5), (3, 512, 1, 1)])
+def test_relu_backward_with_the_frozen_norms_scale_in_the_same_pass(N, C, H, W):
+    """pointwise.relu_grad_from_output(scale=...) (mono_relu_grad_scale_f32): scale[c] * g * (y > 0) on channels-last tensors -- the ReLU
+    backward of a trainable 1 x 1 convolution + frozen BN without an identity branch (backbone.py:72-115 -> torchvision Bottleneck
+    conv1 / bn1 / relu), exact against the two-step evaluation; and the flag that switches the node's backward to it changes no result
+    beyond rounding."""
+    from monosowa_amd.pointwise import relu_grad_from_output
+    torch.manual_seed(C)
+    g = torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    y = torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    scale = torch.rand(C, device="cuda") + 0.5
+    got = relu_grad_from_output([g], y, scale)
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, torch.where(y > 0, g * scale.view(1, -1, 1, 1), torch.zeros_like(g)))
+    with pytest.raises(ValueError):
+        relu_grad_from_output([g, g], y, scale)
+
+
+@pytest.mark.gpu
+def test_scaled_gradient_path_of_the_epilogue_convolution_equals_the_unscaled_one():
+    from monosowa_amd.monodetr import backbone as bb
+    from monosowa_amd.monodetr.backbone import FrozenBatchNorm2d
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(256, 64, 1, bias=False).cuda().to(memory_format=torch.channels_last)
+    bn = FrozenBatchNorm2d(64).cuda()
+    bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    x0 = torch.randn(2, 256, 24, 80, device="cuda").contiguous(memory_format=torch.channels_last)
+    go = torch.randn(2, 64, 24, 80, device="cuda").contiguous(memory_format=torch.channels_last)
+    res = {}
+    for flag in (1, 0):
+        bb.CONV1X1_SCALED_GRAD = flag
+        try:
+            x = x0.clone().requires_grad_(True)
+            conv.weight.grad = None
+            y = bb.conv_bn(x, conv, bn, None)
+            y.backward(go)
+            res[flag] = (y.detach().clone(), x.grad.clone(), conv.weight.grad.clone())
+        finally:
+            bb.CONV1X1_SCALED_GRAD = 1
+    for a, b, name in zip(res[1], res[0], ("y", "dx", "dw")):
+        assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1.0), name
+    # and against float64
+    xd = x0.double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    scale, shift = bn.scale_shift()
+    yd = torch.relu(torch.nn.functional.conv2d(xd, wd) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    yd.backward(go.double())
+    assert (res[1][1].double() - xd.grad).abs().max().item() <= 2e-5 * xd.grad.abs().max().item()
+    assert (res[1][2].double() - wd.grad).abs().max().item() <= 2e-5 * wd.grad.abs().max().item()
