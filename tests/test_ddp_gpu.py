@@ -92,7 +92,13 @@ for it in range(2):                            # second iteration: bucket views 
     assert dw <= 1e-6 + max(3 * dw_noise, 2.05 * lr * (it + 1)), (dw, dw_noise, lr)
     n_w = sum(wa[n].numel() for n in ga)
     wdist = lambda x, y: (torch.cat([(x[n] - y[n]).reshape(-1) for n in ga]).norm() / (lr * n_w ** 0.5)).item()
-    assert wdist(wa, wb) <= 1e-3 + 3 * wdist(wa, wc), (wdist(wa, wb), wdist(wa, wc))
+    # (round 5: 0.020 against a twin at 0.0044 failed `<= 1e-3 + 3 twin` once in some ten runs -- 4e-4 of all entries flipped, none missed.
+    # The whole-model distance keeps a floor that a run of flips cannot reach but a missed mid-size tensor does; the per-tensor
+    # comparison below is the sharp check: a tensor that missed its update is ~lr off in EVERY entry while its twin is not.)
+    assert wdist(wa, wb) <= max(1e-3 + 3 * wdist(wa, wc), 0.03), (wdist(wa, wb), wdist(wa, wc))
+    for n in ga:
+        off_b, off_c = (wa[n] - wb[n]).abs().mean().item() / lr, (wa[n] - wc[n]).abs().mean().item() / lr
+        assert off_b <= 0.25 * (it + 1) + 3 * off_c, (n, off_b, off_c)
     # ... and per parameter TENSOR (ADVICE round 4: one tensor that missed its update could hide inside the L2 over all of them): a
     # missed update leaves (nearly) every entry of the tensor ~lr per step away, sign flips of noise-level gradients only a few
     for n in ga:
