@@ -139,10 +139,11 @@ int mono_colsum_strided_f32(const float *g, float *out, float *partials, int bat
 /* Column sums of several row ranges of a contiguous [batch, S, C] tensor in one launch pair: out[l][c] = sum over all batches and rows
  * [bounds[2 l], bounds[2 l + 1]) of g[., ., c], l < n_levels <= 8, C % 4 == 0, C <= 512; `bounds` is a HOST array of 2 n_levels ints.  The
  * sums of the encoder's d(offsets | logits) over each pyramid level: their total is a bias gradient, times W they are d level_embed
- * (depthaware_transformer.py:232-240).  partials: mono_colsum_levels_blocks(...) * C floats of scratch (0: unusable bounds). */
+ * (depthaware_transformer.py:232-240).  with_total != 0: out has n_levels + 1 rows, the last one the sum of all the ranges' sums (added in the
+ * same launch, in workgroup order).  partials: mono_colsum_levels_blocks(...) * C floats of scratch (0: unusable bounds). */
 int mono_colsum_levels_blocks(int batch, long long S, int n_levels, const int *bounds);
 int mono_colsum_levels_f32(const float *g, float *out, float *partials, int batch, long long S, int C, int n_levels, const int *bounds,
-                           void *stream);
+                           int with_total, void *stream);
 
 /* GroupNorm(32 groups, 256 channels) (+ ReLU when relu != 0) on a channels-last tensor x [B, HW, 256]
  * (reference: nn.GroupNorm(32, hidden_dim) in monodetr.py:68-88 input_proj and depth_predictor.py:27-52).

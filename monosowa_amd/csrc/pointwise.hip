@@ -524,14 +524,15 @@ __global__ __launch_bounds__(256) void colsum_levels_kernel(const float *__restr
     }
   }
 }
-// out[l][c] = sum of level l's partial rows (blockIdx.y = level)
+// out[l][c] = sum of level l's partial rows (blockIdx.y = level); blockIdx.y = plan.n (when launched): out[n][c] = the sum over ALL levels
 __global__ __launch_bounds__(1024) void partial_sum_levels_kernel(const float *__restrict__ partials, float *__restrict__ out, const LevelPlan plan, int C) {
   __shared__ float4 red[15][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = blockIdx.x * 64 + lane, l = blockIdx.y;
+  const int k0 = l < plan.n ? plan.blk0[l] : 0, k1 = l < plan.n ? plan.blk0[l + 1] : plan.blk0[plan.n];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < (C >> 2)) {
 #pragma unroll 8
-    for (int k = plan.blk0[l] + wave; k < plan.blk0[l + 1]; k += 16) {
+    for (int k = k0 + wave; k < k1; k += 16) {
       const float4 v = *reinterpret_cast<const float4 *>(partials + (long long)k * C + c * 4);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
@@ -967,7 +968,7 @@ int mono_colsum_levels_blocks(int batch, long long S, int n_levels, const int *b
   return colsum_levels_plan(p, batch, S, n_levels, bounds);
 }
 int mono_colsum_levels_f32(const float *g, float *out, float *partials, int batch, long long S, int C, int n_levels, const int *bounds,
-                           void *stream_) {
+                           int with_total, void *stream_) {
   if (!g || !out || !partials) return -1;
   mono::LevelPlan p;
   const int grid = colsum_levels_plan(p, batch, S, n_levels, bounds);
@@ -975,7 +976,7 @@ int mono_colsum_levels_f32(const float *g, float *out, float *partials, int batc
   hipStream_t st = (hipStream_t)stream_;
   if (C <= 256) mono::colsum_levels_kernel<1><<<grid, 256, 0, st>>>(g, partials, p, batch, S * C, C);
   else mono::colsum_levels_kernel<2><<<grid, 256, 0, st>>>(g, partials, p, batch, S * C, C);
-  mono::partial_sum_levels_kernel<<<dim3((C / 4 + 63) / 64, n_levels), 1024, 0, st>>>(partials, out, p, C);
+  mono::partial_sum_levels_kernel<<<dim3((C / 4 + 63) / 64, n_levels + (with_total ? 1 : 0)), 1024, 0, st>>>(partials, out, p, C);
   return (int)hipGetLastError();
 }
 

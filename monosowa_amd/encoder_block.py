@@ -88,9 +88,9 @@ class _AttnBlock(torch.autograd.Function):
                 gv, gproj = MSDA.ms_deform_attn_fused_backward_merged(v, shapes, lsi, proj, ref, ga.contiguous())
             gp2 = gproj.view(-1, gproj.shape[-1])
             # per-level column sums of d proj serve twice: their total is the bias gradient, times W they are d level_embed
-            level_sums = colsum_levels(gproj, ctx.levels) if ctx.levels is not None else None
+            level_sums, level_total = colsum_levels(gproj, ctx.levels, with_total=True) if ctx.levels is not None else (None, None)
             gw_ol = weight_grad(gp2, q2)
-            gb_ol = level_sums.sum(0) if level_sums is not None else colsum(gp2)
+            gb_ol = level_total if level_sums is not None else colsum(gp2)
             gwo, gwa, gbo, gba = gw_ol[:n_off], gw_ol[n_off:], gb_ol[:n_off], gb_ol[n_off:]
         else:
             gv, goff, glogit = MSDA.ms_deform_attn_fused_backward(v, shapes, lsi, off, logit, ref, ga.contiguous())

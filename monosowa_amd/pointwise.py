@@ -90,7 +90,7 @@ def load():
         lib.mono_colsum_levels_blocks.restype = I
         lib.mono_colsum_levels_blocks.argtypes = [I, LL, I, P]
         lib.mono_colsum_levels_f32.restype = I
-        lib.mono_colsum_levels_f32.argtypes = [P, P, P, I, LL, I, I, P, P]
+        lib.mono_colsum_levels_f32.argtypes = [P, P, P, I, LL, I, I, P, I, P]
         lib.mono_colsum_f32.restype = I
         lib.mono_colsum_f32.argtypes = [P, P, P, LL, I, P]
         lib.mono_linear_wgrad_workspace.restype = LL
@@ -560,26 +560,27 @@ COLSUM_LEVELS_ONE_LAUNCH = 1     # all levels by one launch pair (mono_colsum_le
 _LEVEL_PLANS = {}                # (B, S, bounds) -> (ctypes int array, partial rows)
 
 
-def colsum_levels(g3, bounds):
+def colsum_levels(g3, bounds, with_total=False):
     """Per-level column sums of a [B, S, C] tensor (contiguous, C <= 512): rows [a, b) of every batch for each (a, b)
-    in ``bounds`` -> [len(bounds), C]."""
+    in ``bounds`` -> [len(bounds), C].  ``with_total``: -> (the same, their sum over the levels [C]) -- from the same launch pair."""
     B, S, C = g3.shape
-    out = torch.empty((len(bounds), C), dtype=torch.float32, device=g3.device)
+    L = len(bounds)
+    out = torch.empty((L + (1 if with_total else 0), C), dtype=torch.float32, device=g3.device)
     lib = load()
-    if COLSUM_LEVELS_ONE_LAUNCH and len(bounds) <= 8 and C % 4 == 0 and C <= 512:
+    if COLSUM_LEVELS_ONE_LAUNCH and L <= 8 and C % 4 == 0 and C <= 512:
         key = (B, S, tuple(tuple(ab) for ab in bounds))
         plan = _LEVEL_PLANS.get(key)
         if plan is None:
-            arr = (ctypes.c_int * (2 * len(bounds)))(*[int(v) for ab in bounds for v in ab])
-            plan = _LEVEL_PLANS[key] = (arr, lib.mono_colsum_levels_blocks(B, S, len(bounds), arr))
+            arr = (ctypes.c_int * (2 * L))(*[int(v) for ab in bounds for v in ab])
+            plan = _LEVEL_PLANS[key] = (arr, lib.mono_colsum_levels_blocks(B, S, L, arr))
         arr, blocks = plan
         if blocks > 0:
             partials = torch.empty(blocks * C, dtype=torch.float32, device=g3.device)
             with on_device(g3.device):
-                code = lib.mono_colsum_levels_f32(g3.data_ptr(), out.data_ptr(), partials.data_ptr(), B, S, C, len(bounds), arr, raw_stream())
+                code = lib.mono_colsum_levels_f32(g3.data_ptr(), out.data_ptr(), partials.data_ptr(), B, S, C, L, arr, int(with_total), raw_stream())
             if code:
                 raise RuntimeError("mono_colsum_levels_f32 failed with code %d" % code)
-            return out
+            return (out[:L], out[L]) if with_total else out
     with on_device(g3.device):
         st = raw_stream()
         for i, (a, b) in enumerate(bounds):
@@ -587,6 +588,8 @@ def colsum_levels(g3, bounds):
             code = lib.mono_colsum_strided_f32(g3.data_ptr() + a * C * 4, out[i].data_ptr(), partials.data_ptr(), B, b - a, S * C, C, st)
             if code:
                 raise RuntimeError("mono_colsum_strided_f32 failed with code %d" % code)
+    if with_total:
+        return out[:L], out[:L].sum(0)
     return out
 
 

@@ -931,6 +931,9 @@ def test_colsum_levels_one_launch_equals_float64_and_the_per_level_launches(B, S
         pw.COLSUM_LEVELS_ONE_LAUNCH = 1
     assert (per_level.double() - ref).abs().max() <= 2e-6 * scale
     assert torch.equal(pw.colsum_levels(g, bounds), got)               # fixed summation order
+    lv, total = pw.colsum_levels(g, bounds, with_total=True)           # the sum over the levels' sums from the same launch pair
+    assert torch.equal(lv, got) and total.shape == (C,)
+    assert (total.double() - ref.sum(0)).abs().max() <= 2e-6 * max(ref.abs().sum(0).max().item(), scale)
 
 
 def test_sum_slices_and_channel_bias():
