@@ -158,10 +158,11 @@ int mono_groupnorm_blocks(int B, int HW);
 
 /* gx [B, HW, 256].  part: f64 [B, 256, 2], ZERO on entry; on return part[b][c] = {sum gy'*xhat, sum gy'} so that
  * ggamma[c] = sum_b part[b][c][0], gbeta[c] = sum_b part[b][c][1].  y = forward output (ReLU mask), NULL if relu == 0.
- * With pre_bias != NULL: gbias [256] = gradient of pre_bias, gbias_partials = scratch. */
+ * With pre_bias != NULL: gbias [256] = gradient of pre_bias, gbias_partials = scratch.
+ * ggamma_gbeta (nullable): f32 [2][256] = {ggamma, gbeta}, written by the second kernel (no launch of its own). */
 int mono_groupnorm_nhwc_bwd_f32(const float *gy, const float *x, const float *pre_bias, const float *y,
                                 const float *mean_rstd, const float *gamma, float *gx, double *part, float *gbias,
-                                float *gbias_partials, int B, int HW, int C, int G, int relu, void *stream);
+                                float *gbias_partials, float *ggamma_gbeta, int B, int HW, int C, int G, int relu, void *stream);
 
 /* DDN depth-map loss (depth_predictor/ddn_loss/ddn_loss.py:12-127 + balancer.py + focalloss.py) in one kernel per
  * direction.  logits [B, C = num_bins + 1, H, W] addressed with (batch, channel, pixel) strides in floats (NCHW or

@@ -10,7 +10,7 @@
 //             gn_apply_kernel  -> y = (x - mean) * rstd * gamma + beta (ReLU optional); mean/rstd saved
 //   backward: gn_bwd_stats_kernel -> part[b][c] = {sum gy' * xhat, sum gy'}   (gy' = gy masked by the ReLU)
 //             gn_bwd_apply_kernel -> gx = rstd * (gy' * gamma - (sum_g gy' gamma + xhat * sum_g gy' gamma xhat) / n)
-// ggamma / gbeta are the sums of part over b (done by the caller on the tiny [B, 256, 2] tensor).
+// ggamma / gbeta are the sums of part over b: by one wave of gn_bwd_apply_kernel's first workgroup (ggamma_gbeta [2][256]), or by the caller.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -133,9 +133,22 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restri
                                                            const float *__restrict__ pre_bias, const float *__restrict__ y,
                                                            const float *__restrict__ mean_rstd, const float *__restrict__ gamma,
                                                            const double *__restrict__ part, float *__restrict__ gx,
-                                                           float *__restrict__ gbias_partials, int HW) {
+                                                           float *__restrict__ gbias_partials, int HW,
+                                                           float *__restrict__ ggamma_gbeta) {
   __shared__ float4 red[3][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y, g = lane >> 1;
+  if (ggamma_gbeta && blockIdx.x == 0 && blockIdx.y == 0 && wave == 3) {
+    // ggamma[c] = sum_b part[b][c][0], gbeta[c] = sum_b part[b][c][1]: `part` is complete when this kernel starts; one wave of
+    // one workgroup adds the gridDim.y batches in order (ATen did it in three launches on the tiny tensor: cast, sum, transpose copy)
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int bb = 0; bb < (int)gridDim.y; ++bb) {
+      const double *q = part + ((long long)bb * kGnC + lane * 4) * 2;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += q[k];
+    }
+    reinterpret_cast<float4 *>(ggamma_gbeta)[lane] = make_float4((float)s[0], (float)s[2], (float)s[4], (float)s[6]);
+    reinterpret_cast<float4 *>(ggamma_gbeta + kGnC)[lane] = make_float4((float)s[1], (float)s[3], (float)s[5], (float)s[7]);
+  }
   const float mean = mean_rstd[((long long)b * kGnG + g) * 2], rstd = mean_rstd[((long long)b * kGnG + g) * 2 + 1];
   const float4 ga = reinterpret_cast<const float4 *>(gamma)[lane];
   const double *pp = part + ((long long)b * kGnC + lane * 4) * 2;

@@ -1003,7 +1003,7 @@ int mono_groupnorm_blocks(int B, int HW) { return B * ((HW + mono::kGnPix - 1) /
 // gradient (= sum of gx over batch and pixels), gbias_partials is scratch of mono_groupnorm_blocks(B, HW) * 256 floats.
 int mono_groupnorm_nhwc_bwd_f32(const float *gy, const float *x, const float *pre_bias, const float *y,
                                 const float *mean_rstd, const float *gamma, float *gx, double *part, float *gbias,
-                                float *gbias_partials, int B, int HW, int C, int G, int relu, void *stream_) {
+                                float *gbias_partials, float *ggamma_gbeta, int B, int HW, int C, int G, int relu, void *stream_) {
   if (!gy || !x || !mean_rstd || !gamma || !gx || !part || (relu && !y) || (pre_bias && (!gbias || !gbias_partials))) return -1;
   if (B <= 0 || HW <= 0 || C != mono::kGnC || G != mono::kGnG || B > 65535) return -2;
   hipStream_t st = (hipStream_t)stream_;
@@ -1011,10 +1011,10 @@ int mono_groupnorm_nhwc_bwd_f32(const float *gy, const float *x, const float *pr
   float *gp = pre_bias ? gbias_partials : nullptr;
   if (relu) {
     mono::gn_bwd_stats_kernel<true><<<grid, 256, 0, st>>>(gy, x, pre_bias, y, mean_rstd, part, HW);
-    mono::gn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(gy, x, pre_bias, y, mean_rstd, gamma, part, gx, gp, HW);
+    mono::gn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(gy, x, pre_bias, y, mean_rstd, gamma, part, gx, gp, HW, ggamma_gbeta);
   } else {
     mono::gn_bwd_stats_kernel<false><<<grid, 256, 0, st>>>(gy, x, pre_bias, y, mean_rstd, part, HW);
-    mono::gn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(gy, x, pre_bias, y, mean_rstd, gamma, part, gx, gp, HW);
+    mono::gn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(gy, x, pre_bias, y, mean_rstd, gamma, part, gx, gp, HW, ggamma_gbeta);
   }
   if (pre_bias) mono::partial_sum_kernel<<<1, 1024, 0, st>>>(gbias_partials, gbias, (int)(grid.x * grid.y), mono::kGnC);
   return (int)hipGetLastError();

@@ -62,7 +62,7 @@ def load():
         lib.mono_groupnorm_nhwc_fwd_f32.restype = I
         lib.mono_groupnorm_nhwc_fwd_f32.argtypes = [P] * 7 + [I, I, I, I, F, I, P]
         lib.mono_groupnorm_nhwc_bwd_f32.restype = I
-        lib.mono_groupnorm_nhwc_bwd_f32.argtypes = [P] * 10 + [I, I, I, I, I, P]
+        lib.mono_groupnorm_nhwc_bwd_f32.argtypes = [P] * 11 + [I, I, I, I, I, P]
         lib.mono_groupnorm_blocks.restype = I
         lib.mono_groupnorm_blocks.argtypes = [I, I]
         lib.mono_relu_dropout_fwd_f32.restype = I
@@ -490,12 +490,32 @@ def dropout_add_layernorm(x, z, norm, dropout):
 
 
 # ---------------------------------------------------------------------------------------------------------
+_ZERO_POOL = {}          # device -> [chunk, used]: float64 zeros handed out in slices, never reused (a new chunk when one is used up)
+ZERO_POOL_DOUBLES = 1 << 17   # 1 MiB per chunk: the nine GroupNorms of a train step take 0.65 MB of zeroed accumulators
+
+
+def zeros_f64(n, device):
+    """``n`` float64 zeros on ``device`` (16-byte aligned), cut from a pooled chunk: ONE fill launch per chunk instead of one per
+    accumulator (the GroupNorm kernels add into zeroed f64 statistics: 18 tiny fills per step).  A slice is handed out once; the
+    chunk lives as long as any of its slices."""
+    n_al = (n + 1) & ~1
+    if n_al > ZERO_POOL_DOUBLES // 4:
+        return torch.zeros(n, dtype=torch.float64, device=device)
+    key = (device.type, device.index)
+    slot = _ZERO_POOL.get(key)
+    if slot is None or slot[1] + n_al > ZERO_POOL_DOUBLES:
+        slot = _ZERO_POOL[key] = [torch.zeros(ZERO_POOL_DOUBLES, dtype=torch.float64, device=device), 0]
+    out = slot[0][slot[1]:slot[1] + n]
+    slot[1] += n_al
+    return out
+
+
 class _GroupNormNHWC(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pre_bias, weight, bias, eps, relu):
         B, C, H, W = x.shape
         y = torch.empty_like(x)                                       # keeps the channels_last strides
-        stats = torch.zeros(B, 32, 2, dtype=torch.float64, device=x.device)
+        stats = zeros_f64(B * 32 * 2, x.device)
         mean_rstd = torch.empty(B, 32, 2, dtype=torch.float32, device=x.device)
         with on_device(x.device):
             code = load().mono_groupnorm_nhwc_fwd_f32(x.data_ptr(), pre_bias.data_ptr() if pre_bias is not None else None,
@@ -514,7 +534,8 @@ class _GroupNormNHWC(torch.autograd.Function):
         B, C, H, W = x.shape
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = torch.empty_like(x)
-        part = torch.zeros(B, C, 2, dtype=torch.float64, device=x.device)
+        part = zeros_f64(B * C * 2, x.device)
+        gwb = torch.empty(2, C, dtype=torch.float32, device=x.device)
         lib = load()
         gbias = partials = None
         if pre_bias is not None:
@@ -524,12 +545,11 @@ class _GroupNormNHWC(torch.autograd.Function):
         with on_device(x.device):
             code = lib.mono_groupnorm_nhwc_bwd_f32(gy.data_ptr(), x.data_ptr(), ptr(pre_bias), ptr(y if ctx.relu else None),
                                                    mean_rstd.data_ptr(), weight.data_ptr(), gx.data_ptr(), part.data_ptr(),
-                                                   ptr(gbias), ptr(partials), B, H * W, C, 32, int(ctx.relu),
+                                                   ptr(gbias), ptr(partials), gwb.data_ptr(), B, H * W, C, 32, int(ctx.relu),
                                                    raw_stream())
         if code:
             raise RuntimeError("mono_groupnorm_nhwc_bwd_f32 failed with code %d" % code)
-        gw, gb = part.sum(0, dtype=torch.float32).t().contiguous().unbind(0)      # [2, C]: two contiguous rows (2 launches, not 4)
-        return gx, gbias, gw, gb, None, None
+        return gx, gbias, gwb[0], gwb[1], None, None      # ggamma / gbeta: two contiguous rows written by the backward's second kernel
 
 
 def group_norm(x, gn, relu=False, pre_bias=None):

@@ -542,3 +542,28 @@ def test_build_source_hash_follows_the_sources(tmp_path, monkeypatch):
     assert build._build_one(out, ["cc"], "h2", False, False) is True
     assert build._build_one(out, ["cc"], "h2", True, False) is True
     assert len(calls) == 3
+
+
+def test_pooled_zero_accumulators_are_zero_disjoint_and_aligned(monkeypatch):
+    """pointwise.zeros_f64: the GroupNorm kernels' zeroed float64 accumulators come as slices of one pooled chunk (one fill per chunk,
+    not one per accumulator); a slice is handed out once, a request that would not fit starts a new chunk, a large one bypasses the pool."""
+    import torch
+    from monosowa_amd import pointwise as pw
+    monkeypatch.setattr(pw, "ZERO_POOL_DOUBLES", 64)
+    monkeypatch.setattr(pw, "_ZERO_POOL", {})
+    dev = torch.device("cpu")
+    a = pw.zeros_f64(5, dev); b = pw.zeros_f64(6, dev); c = pw.zeros_f64(16, dev)
+    assert a.dtype == torch.float64 and a.shape == (5,) and b.shape == (6,) and c.shape == (16,)
+    assert a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and c.data_ptr() % 16 == 0
+    assert b.data_ptr() >= a.data_ptr() + 5 * 8 and c.data_ptr() >= b.data_ptr() + 6 * 8          # disjoint, same chunk
+    a += 1.0; b += 2.0
+    assert float(c.abs().sum()) == 0.0 and float(a.sum()) == 5.0 and float(b.sum()) == 12.0
+    chunk0 = pw._ZERO_POOL[("cpu", None)][0]
+    for _ in range(3):
+        d = pw.zeros_f64(16, dev)                                        # 6 + 6 + 16 + 16 + 16 + 16 > 64: a new chunk on the way
+        assert float(d.abs().sum()) == 0.0
+        d += 3.0
+    assert pw._ZERO_POOL[("cpu", None)][0] is not chunk0
+    big = pw.zeros_f64(17, dev)                                          # more than a quarter of a chunk: its own allocation
+    assert big.shape == (17,) and float(big.abs().sum()) == 0.0
+    assert float(a.sum()) == 5.0                                         # earlier slices untouched
