@@ -52,7 +52,10 @@ for total, k, n, avg, fetch, write in rows[:24]:
 # default bench workload (B = 16, 1280 x 384: layer1 at 96 x 320)
 M_PIX = 16 * 96 * 320
 DENSE = {"conv1x1_head_kernel<256>": 2.0 * M_PIX * 256 * 64, "conv1x1_head_kernel<64>": 2.0 * M_PIX * 64 * 64,
-         "conv1x1_tail_kernel": 2.0 * M_PIX * 64 * 256, "conv1x1_tail_ds_kernel": 2.0 * M_PIX * 128 * 256}
+         "conv1x1_tail_kernel": 2.0 * M_PIX * 64 * 256, "conv1x1_tail_ds_kernel": 2.0 * M_PIX * 128 * 256,
+         # the small linears' weight gradients (small_wgrad.hip): 53 launches per step of different shapes (49 x [8800, 256] x [8800, 256],
+         # 4 x [30720, 512 | 256] x [30720, 256 | 512]); the step's total as bench.py's roofline.step counts it / 53
+         "linear_wgrad_partial_kernel": 101953044480.0 / 53}
 print("# dense kernels of this library: FLOP per launch (default bench shape) / average duration / 157.3 TFLOP/s (f32 matrix peak)")
 for total, k, n, avg, fetch, write in rows:
     if k in DENSE:
