@@ -497,9 +497,10 @@ ZERO_POOL_DOUBLES = 1 << 17   # 1 MiB per chunk: the nine GroupNorms of a train 
 def zeros_f64(n, device):
     """``n`` float64 zeros on ``device`` (16-byte aligned), cut from a pooled chunk: ONE fill launch per chunk instead of one per
     accumulator (the GroupNorm kernels add into zeroed f64 statistics: 18 tiny fills per step).  A slice is handed out once; the
-    chunk lives as long as any of its slices."""
+    chunk lives as long as any of its slices.  Under hipGraph capture every accumulator gets its own captured fill."""
     n_al = (n + 1) & ~1
-    if n_al > ZERO_POOL_DOUBLES // 4:
+    # under stream capture the fill has to be a node of the graph (a replay must start from zeros again): no pooling there
+    if n_al > ZERO_POOL_DOUBLES // 4 or (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
         return torch.zeros(n, dtype=torch.float64, device=device)
     key = (device.type, device.index)
     slot = _ZERO_POOL.get(key)
