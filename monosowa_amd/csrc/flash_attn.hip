@@ -37,6 +37,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef ATTN_OPDEPTH_KV
 #define ATTN_OPDEPTH_KV 0       // the same for bwd_dkdv's two operand streams (no scheduling directives there: with them the 170-register build spilled)
 #endif
+#ifndef ATTN_EARLY_STORE
+#define ATTN_EARLY_STORE 0   // measurement (round 5: 1.7 % SLOWER backward, forward +1 %, 7 instances spill): the next tile's LDS writes in
+                             // front of the LAST MFMA block of an iteration instead of behind it -- at 3 - 4 waves per SIMD the other
+                             // waves already cover the writes' completion latency in front of the barrier
+#endif
 #ifndef ATTN_PRIO
 #define ATTN_PRIO 0             // measurement builds only: 1 = waves inside an MFMA cluster issue ahead of waves in their vector sections
                                 // (s_setprio 2 around the clusters), 2 = the inverse (vector sections first)
@@ -235,6 +240,9 @@ __global__ __launch_bounds__(256, (fwd_waves<DROP, MASK, BITS>())) void fwd_kern
       }
       if (BITS) a.keep[keep_index(a, bh, blockIdx.x, kt, threadIdx.x)] = word;
     }
+#if ATTN_EARLY_STORE
+    if (kt + 1 < n_tiles) store_tile(buf ^ 1);
+#endif
     // O^T += V^T P^T
     ATTN_PRIO_MFMA();
     const float *v0 = &Vs[buf][(4 * h) * kVStride + r], *v1 = v0 + 32 * kVStride;
@@ -249,7 +257,9 @@ __global__ __launch_bounds__(256, (fwd_waves<DROP, MASK, BITS>())) void fwd_kern
       o = mfma(v1[row * kVStride], s1[t], o);
     }
     ATTN_PRIO_VALU();
+#if !ATTN_EARLY_STORE
     if (kt + 1 < n_tiles) store_tile(buf ^ 1);
+#endif
     __syncthreads();
   }
   lsum += xhalf(lsum);
@@ -388,6 +398,9 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dq_kernel(const Args 
         }
         s[v] = p * (dpe - delta);                                                          // dS^T
       }
+#if ATTN_EARLY_STORE
+      if (half == 1 && kt + 1 < n_tiles) store_tile(buf ^ 1);
+#endif
       ATTN_PRIO_MFMA();
 #if ATTN_OPDEPTH > 0 && !ATTN_PREFETCH
       // the A operands of the second-stage MFMAs ATTN_OPDEPTH steps ahead of their use (an LDS round trip is longer than the one
@@ -418,7 +431,9 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dq_kernel(const Args 
       }
 #endif
     }
+#if !ATTN_EARLY_STORE
     if (kt + 1 < n_tiles) store_tile(buf ^ 1);
+#endif
     __syncthreads();
   }
   if (q < a.Lq) {
@@ -567,6 +582,9 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dkdv_kernel(const Arg
         }
       }
       ATTN_PRIO_MFMA();
+#if ATTN_EARLY_STORE
+      if (half == 1 && qt + 1 < n_tiles) store_tile(buf ^ 1);
+#endif
 #if ATTN_OPDEPTH_KV > 0 && !ATTN_PREFETCH
       float dop[ATTN_OPDEPTH_KV], qop[ATTN_OPDEPTH_KV];      // (as in bwd_dq: the two A operands of step t + depth requested at step t)
 #pragma unroll
@@ -600,7 +618,9 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void bwd_dkdv_kernel(const Arg
       }
 #endif
     }
+#if !ATTN_EARLY_STORE
     if (qt + 1 < n_tiles) store_tile(buf ^ 1);
+#endif
     __syncthreads();
   }
   // (the lane's key and half re-derived from the lane counter and a scalar wave number: kept in a VGPR across the tile loop, `key`

@@ -1,6 +1,6 @@
 // Weight AND bias gradient of a linear layer over a few thousand tokens, two launches (round 5):
 //
-//     dW[M, N] = dY[R, M]^T . X[R, N]          db[M] = sum_r dY[r, m]            R = 2,048 .. 32,767 rows, M, N multiples of 64
+//     dW[M, N] = dY[R, M]^T . X[R, N]          db[M] = sum_r dY[r, m]            R >= 64 rows (the step: 8,800 and 30,720), M, N multiples of 64
 //
 // (autograd's AddmmBackward / MmBackward of the nn.Linear layers of the reference's decoder and depth-token encoder,
 // depthaware_transformer.py:339-354,440-515: 8,800 rows of queries, 30,720 of depth tokens.)  The product's output is tiny and its
