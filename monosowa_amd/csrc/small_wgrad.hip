@@ -28,7 +28,7 @@
 // piece costs the issuing wave 100 - 160 cycles and slows the others' LDS reads); separate loader waves, by LDS-DMA or through registers (a
 // loader that shares a SIMD with an MFMA wave only gets to run while that wave waits at the barrier: the MFMA waves spent 370 of 890
 // cycles per stage there); 64 x 32 per wave straight from global memory with 8-byte loads and no LDS (18.6, and twice the partial images).
-// The column sums' one v_add_f32 per MFMA costs 1.9 of the 17.4 us (-DMONO_WGRAD_NOBIAS build: 15.6); as packed adds the compiler splits them again.
+// The column sums' one v_add_f32 per MFMA costs 1.9 of the 17.4 us (15.6 with the adds compiled out); written as packed adds the compiler splits them again.
 #pragma once
 #include <hip/hip_runtime.h>
 
